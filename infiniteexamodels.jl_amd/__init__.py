@@ -1,0 +1,13 @@
+"""MI355X-native NLP evaluation backend for InfiniteOpt → ExaModels transcriptions.
+
+Host-side mirror (Python) of the reference's plug point
+``ExaTranscriptionBackend(solver; backend = …)`` and of the ExaModels builder /
+NLPModels evaluation surface it drives; all arithmetic runs in hand-written HIP
+for gfx950 behind the C-ABI of ``include/iem.h`` (``libiem_hip.so``).
+"""
+from .nodes import (Const, DataField, DataSource, Node, Null, ParameterNode, Var, FUNCS, nary)
+from .items import Items
+from .core import ExaCore, Variable, Parameter
+
+__all__ = ["Const", "DataField", "DataSource", "Node", "Null", "ParameterNode", "Var", "FUNCS",
+           "nary", "Items", "ExaCore", "Variable", "Parameter"]

@@ -1,0 +1,528 @@
+"""InfiniteModel → ExaCore: host mirror of ``/root/reference/src/transform.jl``.
+
+Function names and the build order follow the reference one-to-one
+(``build_exa_core!``, ``transform.jl:771-796``) so that template order — hence row
+offsets and the COO block order — is the reference's:
+
+  1 ``_build_base_iterators``        (:2-38)
+  2 ``_add_finite_parameters``       (:120-131)
+  3 ``_add_finite_variables``        (:104-117)
+  4 ``_add_infinite_variables``      (:134-158)  variables, then derivative variables
+  5 ``_add_parameter_functions``     (:161-183)
+  6 ``_add_semi_infinite_variables`` (:235-256)   7 ``_add_point_variables`` (:273-287)
+  8 ``_add_constraints``             (:420-462)
+  9 ``_add_derivative_approximations`` (:511-562)
+ 10 ``_add_collocation_restrictions``  (:565-601)  (orthogonal collocation: not yet built)
+ 11 ``_add_objective``               (:708-767)
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import nodes as N
+from .core import ExaCore, Parameter, Variable
+from .infinite import (DerivativeRef, FiniteParameterRef, FiniteVariableRef, InfiniteModel,
+                       InfiniteParameterRef, InfiniteVariableRef, MeasureRef, ParameterFunctionRef,
+                       PointVariableRef, SemiInfiniteVariableRef, VarInfo,
+                       parameter_group_int_indices)
+from .items import Field, Items
+from .jump_expr import (AffExpr, NonlinearExpr, QuadExpr, VariableRef, all_expression_variables,
+                        is_number, map_expression)
+from .operators import nl_op
+
+_ObjMeasureExpansionWarn = (
+    "Unable to convert objective measures into a form that is efficient for ExaModels using "
+    "existing heuristics. Performance may be significantly degraded. Try simplying the objective "
+    "structure. if you think this form should be supported, please open an issue.")
+
+
+class ExaMappingData:
+    """``InfiniteExaModels.ExaMappingData`` (``src/infiniteopt_backend.jl:12-57``)."""
+
+    def __init__(self):
+        self.infvar_mappings: Dict[VariableRef, Variable] = {}
+        self.finvar_mappings: Dict[VariableRef, N.Var] = {}
+        self.param_mappings: Dict[VariableRef, Parameter] = {}
+        self.constraint_mappings: Dict[object, object] = {}
+        self.param_alias: Dict[VariableRef, str] = {}
+        self.group_alias: List[str] = []
+        self.base_itrs: List[Items] = []
+        self.support_to_index: Dict[Tuple[int, tuple], int] = {}
+        self.semivar_info: Dict[VariableRef, tuple] = {}
+        self.has_internal_supps: List[bool] = []
+        self.support_labels: List[list] = []
+
+
+def _supp_key(values) -> tuple:
+    return tuple(float(v) for v in np.atleast_1d(values))
+
+
+# 1 ---------------------------------------------------------------------------
+def _build_base_iterators(data: ExaMappingData, m: InfiniteModel) -> None:
+    raw = 0
+    for g in m.groups:
+        raw += 1
+        for pref in g.prefs:
+            data.param_alias[pref] = f"dp{raw}{pref.pos + 1}" if g.dependent else f"ip{raw}"
+        itr_sym = f"group_idx{len(data.group_alias) + 1}"
+        data.group_alias.append(itr_sym)
+        for i in range(g.num_supports):
+            data.support_to_index[(g.index, _supp_key(g.supports[i]))] = i + 1
+        vals = {data.param_alias[p]: np.ascontiguousarray(g.supports[:, p.pos]) for p in g.prefs}
+        data.base_itrs.append(Items.from_supports(itr_sym, g.num_supports, vals, group_id=g.index))
+        data.has_internal_supps.append(False)
+
+
+# bounds / start ----------------------------------------------------------------
+def _eval_over_supports(val, m: InfiniteModel, group_idxs: List[int], dims: Tuple[int, ...]) -> np.ndarray:
+    """Evaluate a function-valued bound/start over the support product
+    (``_get_variable_bounds_and_start``, transform.jl:78-101)."""
+    cols = []
+    for ax, gi in enumerate(group_idxs):
+        g = m.groups[gi - 1]
+        for c in range(g.supports.shape[1]):
+            shape = [1] * len(dims)
+            shape[ax] = dims[ax]
+            cols.append(g.supports[:, c].reshape(shape))
+    try:
+        out = np.asarray(val(*cols), dtype=np.float64)
+        return np.broadcast_to(out, dims).copy()
+    except Exception:
+        out = np.zeros(dims)
+        for idx in np.ndindex(*dims):
+            supp = [float(c[tuple(i if c.shape[a] > 1 else 0 for a, i in enumerate(idx))]) for c in cols]
+            out[idx] = val(*supp)
+        return out
+
+
+def _get_variable_bounds_and_start(info: VarInfo, m: InfiniteModel = None, group_idxs=None, dims=None):
+    lb, ub, start = -np.inf, np.inf, 0.0
+
+    def proc(v):
+        return _eval_over_supports(v, m, group_idxs, dims) if callable(v) else v
+
+    if info.fix is not None:
+        lb = ub = proc(info.fix)
+    if info.lb is not None:
+        lb = proc(info.lb)
+    if info.ub is not None:
+        ub = proc(info.ub)
+    if info.start is not None:
+        start = proc(info.start)
+    return lb, ub, start
+
+
+# 2-5 -----------------------------------------------------------------------------
+def _add_finite_parameters(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for pref in m.finite_parameters:
+        data.param_mappings[pref] = core.add_par([pref.value])
+
+
+def _add_finite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for vref in m.finite_variables:
+        lb, ub, start = _get_variable_bounds_and_start(vref.info)
+        new_var = core.add_var(1, start=start, lvar=lb, uvar=ub)
+        data.finvar_mappings[vref] = new_var[1]
+
+
+def _add_infinite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for vref in list(m.infinite_variables) + list(m.derivatives):
+        group_idxs = vref.group_idxs
+        dims = tuple(len(data.base_itrs[g - 1]) for g in group_idxs)
+        lb, ub, start = _get_variable_bounds_and_start(vref.info, m, group_idxs, dims)
+        data.infvar_mappings[vref] = core.add_var(*dims, start=start, lvar=lb, uvar=ub)
+
+
+def _add_parameter_functions(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for pfref in m.parameter_functions:
+        group_idxs = pfref.group_idxs
+        dims = tuple(len(data.base_itrs[g - 1]) for g in group_idxs)
+        vals = _eval_over_supports(pfref.func, m, group_idxs, dims)
+        data.param_mappings[pfref] = core.add_par(vals)
+
+
+# 6-7 -----------------------------------------------------------------------------
+def _process_semi_infinite_var(vref: SemiInfiniteVariableRef, data: ExaMappingData):
+    ivref = vref.ivref
+    orig_groups = ivref.group_idxs
+    free_groups = vref.group_idxs
+    indexing: List[object] = []
+    for g in orig_groups:
+        if g in free_groups:
+            indexing.append(data.group_alias[g - 1])
+        else:
+            supp = [a for a, p in zip(vref.args, ivref.prefs) if p.group.index == g]
+            indexing.append(data.support_to_index[(g, _supp_key(supp))])
+    mapped = data.param_mappings[ivref] if isinstance(ivref, ParameterFunctionRef) else data.infvar_mappings[ivref]
+    data.semivar_info[vref] = (mapped, indexing)
+    return data.semivar_info[vref]
+
+
+def _update_bounds_and_start(core: ExaCore, info: VarInfo, var: N.Var) -> None:
+    i = int(var.i) - 1
+    if info.lb is not None:
+        core.lvar[i] = -np.inf if np.isnan(info.lb) else info.lb
+    if info.ub is not None:
+        core.uvar[i] = np.inf if np.isnan(info.ub) else info.ub
+    if info.fix is not None:
+        core.lvar[i] = core.uvar[i] = info.fix
+    if info.start is not None:
+        core.x0[i] = info.start
+
+
+def _add_semi_infinite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for vref in m.semi_infinite_variables:
+        mapped, indexing = _process_semi_infinite_var(vref, data)
+        info = vref.info
+        if any(v is not None for v in (info.lb, info.ub, info.fix, info.start)):
+            ranges = [[idx] if isinstance(idx, int) else range(1, mapped.size[i] + 1)
+                      for i, idx in enumerate(indexing)]
+            for idx in np.ndindex(*[len(r) for r in ranges]):
+                var = mapped[tuple(r[j] for r, j in zip(ranges, idx))]
+                _update_bounds_and_start(core, info, var)
+
+
+def _process_point_var(vref: PointVariableRef, data: ExaMappingData) -> N.Var:
+    ivref = vref.ivref
+    idxs = []
+    for g in ivref.group_idxs:
+        supp = [a for a, p in zip(vref.values, ivref.prefs) if p.group.index == g]
+        idxs.append(data.support_to_index[(g, _supp_key(supp))])
+    return data.infvar_mappings[ivref][tuple(idxs)]
+
+
+def _add_point_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for vref in m.point_variables:
+        pt = _process_point_var(vref, data)
+        data.finvar_mappings[vref] = pt
+        _update_bounds_and_start(core, vref.info, pt)
+
+
+# _map_variable / _exafy ------------------------------------------------------------
+def _map_variable(vref: VariableRef, data_src, data: ExaMappingData):
+    if isinstance(vref, FiniteVariableRef):
+        return data.finvar_mappings[vref]
+    if isinstance(vref, PointVariableRef):
+        if vref not in data.finvar_mappings:
+            data.finvar_mappings[vref] = _process_point_var(vref, data)
+        return data.finvar_mappings[vref]
+    if isinstance(vref, InfiniteVariableRef):      # infinite variable or derivative
+        idx = tuple(data_src[data.group_alias[g - 1]] for g in vref.group_idxs)
+        return data.infvar_mappings[vref][idx]
+    if isinstance(vref, SemiInfiniteVariableRef):
+        if vref not in data.semivar_info:
+            _process_semi_infinite_var(vref, data)
+        ivar, inds = data.semivar_info[vref]
+        return ivar[tuple(i if isinstance(i, int) else data_src[i] for i in inds)]
+    if isinstance(vref, InfiniteParameterRef):
+        return data_src[data.param_alias[vref]]
+    if isinstance(vref, FiniteParameterRef):
+        return data.param_mappings[vref][1]
+    if isinstance(vref, ParameterFunctionRef):
+        idx = tuple(data_src[data.group_alias[g - 1]] for g in vref.group_idxs)
+        return data.param_mappings[vref][idx]
+    raise TypeError(f"Unable to add `{vref!r}` to an ExaModel, it's index type `{vref.kind}` "
+                    "is not yet supported by InfiniteExaModels.")
+
+
+def _sum(gen):
+    """Julia ``sum(generator)``: left fold without an initial zero."""
+    acc = None
+    for v in gen:
+        acc = v if acc is None else acc + v
+    return acc
+
+
+def _exafy(expr, data_src, data: ExaMappingData):
+    """``_exafy`` (transform.jl:337-389)."""
+    if isinstance(expr, VariableRef):
+        if isinstance(expr, MeasureRef):
+            raise TypeError("measures must be expanded before `_exafy`")
+        return _map_variable(expr, data_src, data)
+    if is_number(expr):
+        return expr
+    if isinstance(expr, AffExpr):
+        c = expr.constant
+        if expr.terms:
+            ex = _sum((_exafy(v, data_src, data) if coef == 1.0 else coef * _exafy(v, data_src, data))
+                      for coef, v in expr.linear_terms())
+            return ex if c == 0.0 else ex + c
+        return c
+    if isinstance(expr, QuadExpr):
+        aff = _exafy(expr.aff, data_src, data)
+        if expr.terms:
+            def term(c, v1, v2):
+                if v1 is v2:
+                    v_ex = _exafy(v1, data_src, data)
+                    return N.FUNCS["abs2"](v_ex) if c == 1.0 else c * N.FUNCS["abs2"](v_ex)
+                v1_ex = _exafy(v1, data_src, data)
+                v2_ex = _exafy(v2, data_src, data)
+                return v1_ex * v2_ex if c == 1.0 else c * v1_ex * v2_ex
+            ex = _sum(term(c, v1, v2) for c, v1, v2 in expr.quad_terms())
+            return ex if expr.aff.is_zero() else ex + aff
+        return aff
+    if isinstance(expr, NonlinearExpr):
+        return nl_op(expr.head)(*[_exafy(a, data_src, data) for a in expr.args])
+    raise TypeError(f"cannot transcribe expression of type {type(expr).__name__}")
+
+
+def _finalize_expr(expr):
+    return N.Null(expr) if is_number(expr) else expr
+
+
+# 8 ---------------------------------------------------------------------------------
+def _product_itr(itrs: List[Items]) -> Items:
+    out = itrs[0]
+    for it in itrs[1:]:
+        out = out.product(it)
+    return out
+
+
+def _restriction_mask(restriction, itr: Items, data: ExaMappingData) -> np.ndarray:
+    cols = [itr.column(data.param_alias[p]) for p in restriction.parameter_refs]
+    try:
+        mask = np.asarray(restriction.func(*cols))
+        if mask.shape == cols[0].shape and mask.dtype == bool:
+            return mask
+    except Exception:
+        pass
+    return np.array([bool(restriction.func(*[float(c[k]) for c in cols])) for k in range(len(itr))])
+
+
+def _add_constraints(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for cref in m.constraints:
+        expr = cref.func
+        if any(isinstance(v, MeasureRef) for v in all_expression_variables(expr)):
+            warnings.warn("Constrained measures can lead to poor performance with ExaModels.")
+            raise NotImplementedError("constrained measures (expand_measures) are not built yet")
+        group_idxs = parameter_group_int_indices(expr)
+        if not group_idxs:
+            itr = Items.single()
+        elif len(group_idxs) == 1:
+            itr = data.base_itrs[group_idxs[0] - 1]
+        else:
+            itr = _product_itr([data.base_itrs[g - 1] for g in group_idxs])
+        if cref.restriction is not None:
+            itr = itr.filter(_restriction_mask(cref.restriction, itr, data))
+        data_src = N.DataSource()
+        em_expr = _finalize_expr(_exafy(expr, data_src, data))
+        cref.mapping = core.add_con(em_expr, itr, lcon=cref.lb, ucon=cref.ub)
+        data.constraint_mappings[cref] = cref.mapping
+
+
+# 9 ---------------------------------------------------------------------------------
+def _make_reduced_expr(vref, pref, idx, data_src, data: ExaMappingData):
+    """``InfiniteOpt.make_reduced_expr`` extension (transform.jl:471-508): the variable
+    at support index expression ``idx`` along ``pref``'s group."""
+    alias = data.group_alias[pref.group.index - 1]
+    if isinstance(vref, SemiInfiniteVariableRef):
+        ivar, inds = data.semivar_info[vref]
+        return ivar[tuple(i if isinstance(i, int) else (idx if i == alias else data_src[i]) for i in inds)]
+    pars = tuple(idx if data.group_alias[g - 1] == alias else data_src[data.group_alias[g - 1]]
+                 for g in vref.group_idxs)
+    return data.infvar_mappings[vref][pars]
+
+
+def derivative_expr_data(method: tuple, supps: np.ndarray):
+    """``InfiniteOpt.derivative_expr_data`` for finite differences [EXT]:
+    (0-based item → support positions, per-item coefficient columns)."""
+    n = len(supps)
+    kind = method[0]
+    if kind == "fd_backward":
+        return np.arange(1, n), [supps[1:] - supps[:-1]]
+    if kind == "fd_forward":
+        return np.arange(0, n - 1), [supps[1:] - supps[:-1]]
+    if kind == "fd_central":
+        return np.arange(1, n - 1), [supps[2:] - supps[:-2]]
+    raise NotImplementedError(f"derivative method {method!r}")
+
+
+def make_indexed_derivative_expr(dref, vref, pref, idx, data_src, data, method: tuple, d_args):
+    """``InfiniteOpt.make_indexed_derivative_expr`` [EXT]; first order, finite differences.
+    Backward: ``h·∂y[i] − y[i] + y[i−1]`` with ``h = tᵢ − tᵢ₋₁``."""
+    d = _make_reduced_expr(dref, pref, idx, data_src, data)
+    kind = method[0]
+    if kind == "fd_backward":
+        return d_args[0] * d - _make_reduced_expr(vref, pref, idx, data_src, data) \
+            + _make_reduced_expr(vref, pref, idx - 1, data_src, data)
+    if kind == "fd_forward":
+        return d_args[0] * d - _make_reduced_expr(vref, pref, idx + 1, data_src, data) \
+            + _make_reduced_expr(vref, pref, idx, data_src, data)
+    if kind == "fd_central":
+        return d_args[0] * d - _make_reduced_expr(vref, pref, idx + 1, data_src, data) \
+            + _make_reduced_expr(vref, pref, idx - 1, data_src, data)
+    raise NotImplementedError(kind)
+
+
+def _add_derivative_approximations(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    for dref in m.derivatives:
+        vref, pref = dref.arg, dref.pref
+        method = pref.group.derivative_method
+        group_idxs = vref.group_idxs
+        pref_group = pref.group.index
+        p_alias = data.param_alias[pref]
+        base_itr = data.base_itrs[pref_group - 1]
+        supps = base_itr.column(p_alias)
+        if pref.group.dependent:
+            order = np.argsort(supps, kind="stable")
+            srt_itr, supps = base_itr.take(order), supps[order]
+        else:
+            srt_itr = base_itr
+        idxs, arg_cols = derivative_expr_data(method, supps)
+        aliases = [f"d_arg{i + 1}" for i in range(len(arg_cols))]
+        pref_itr = srt_itr.take(idxs)
+        for a, col in zip(aliases, arg_cols):
+            pref_itr = pref_itr.with_float(a, col)
+        if len(group_idxs) > 1:
+            itr = _product_itr([pref_itr if g == pref_group else data.base_itrs[g - 1] for g in group_idxs])
+        else:
+            itr = pref_itr
+        data_src = N.DataSource()
+        em_expr = make_indexed_derivative_expr(
+            dref, vref, pref, data_src[data.group_alias[pref_group - 1]], data_src, data, method,
+            [data_src[a] for a in aliases])
+        core.add_con(em_expr, itr)
+
+
+# 10 --------------------------------------------------------------------------------
+def _add_collocation_restrictions(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
+    # transform.jl:565-601 only acts on parameters with generative (collocation) supports,
+    # which this layer does not create yet.
+    return
+
+
+# 11 --------------------------------------------------------------------------------
+def _add_generic_objective_term(core: ExaCore, expr, data: ExaMappingData):
+    em_expr = _finalize_expr(_exafy(expr, {}, data))
+    return core.add_obj(em_expr, Items.single())
+
+
+def _measure_data(mref: MeasureRef):
+    """supports (n, len(prefs)) and coefficients of a measure [EXT: InfiniteOpt
+    UniTrapezoid / sample-average defaults]."""
+    g = mref.prefs[0].group
+    if mref.method == "trapezoid":
+        s = g.supports[:, 0]
+        d = np.diff(s)
+        c = np.zeros_like(s)
+        c[:-1] += d / 2
+        c[1:] += d / 2
+        return s.reshape(-1, 1), c
+    n = g.num_supports
+    return g.supports[:, [p.pos for p in mref.prefs]], np.full(n, 1.0 / n)
+
+
+def _make_measure_itr(mref: MeasureRef, data: ExaMappingData) -> Items:
+    supps, coeffs = _measure_data(mref)
+    g = mref.prefs[0].group
+    assert len(mref.prefs) == len(g.prefs)  # no partially measured dependent parameters (:628)
+    alias = data.group_alias[g.index - 1]
+    itr = data.base_itrs[g.index - 1]      # measure supports == group supports, in order
+    return itr.with_float("c", coeffs)
+
+
+def _has_variable(expr, vref) -> bool:
+    return any(v is vref for v in all_expression_variables(expr))
+
+
+def _terms_can_be_moved_inside_measure(expr, mref) -> bool:
+    if isinstance(expr, (VariableRef, AffExpr)):
+        return True
+    if isinstance(expr, QuadExpr):
+        return not any((k.a is mref and k.b is mref) for k in expr.terms)
+    if isinstance(expr, NonlinearExpr):
+        m_inds = [a for a in expr.args if not is_number(a) and _has_variable(a, mref)]
+        if expr.head in ("+", "-"):
+            return all(_terms_can_be_moved_inside_measure(a, mref) for a in m_inds)
+        if expr.head == "*":
+            return len(m_inds) <= 1 and _terms_can_be_moved_inside_measure(m_inds[0], mref)
+        return False
+    return False
+
+
+def _process_measure_sum(vref: MeasureRef, data: ExaMappingData, prev_itr: Optional[Items] = None):
+    mexpr = vref.func
+    curr_itr = _make_measure_itr(vref, data)
+    if prev_itr is None:
+        itr = curr_itr
+    else:
+        # [(i[1]..., i[2]..., c = i[1].c * i[2].c) for i in product(curr_itr, prev_itr)]
+        itr = curr_itr.product(prev_itr)
+        cc = np.outer(prev_itr.column("c"), curr_itr.column("c")).reshape(-1)
+        steps, s = [], 1
+        for n in itr.dims:
+            steps.append(s)
+            s *= n
+        itr.fields["c"] = Field("float", "gather", 0, tuple(steps), np.ascontiguousarray(cc))
+    vrefs = all_expression_variables(mexpr)
+    mrefs = [v for v in vrefs if isinstance(v, MeasureRef)]
+    if not mrefs:
+        return mexpr, itr
+    if len(mrefs) == 1 and _terms_can_be_moved_inside_measure(mexpr, mrefs[0]):
+        mref = mrefs[0]
+        inner_mexpr, new_itr = _process_measure_sum(mref, data, itr)
+        return map_expression(lambda v: inner_mexpr if v is mref else v, mexpr), new_itr
+    warnings.warn(_ObjMeasureExpansionWarn)
+    raise NotImplementedError("expand_measures fallback is not built yet")
+
+
+def _add_objective_aff_term(core: ExaCore, coef, vref: VariableRef, data: ExaMappingData) -> None:
+    if isinstance(vref, MeasureRef):
+        mexpr, itr = _process_measure_sum(vref, data)
+        data_src = N.DataSource()
+        em_expr = data_src.c * _exafy(coef * mexpr, data_src, data)
+        core.add_obj(_finalize_expr(em_expr), itr)
+    else:
+        _add_generic_objective_term(core, coef * vref, data)
+
+
+def _add_objective(core: ExaCore, expr, data: ExaMappingData, m: InfiniteModel) -> None:
+    if isinstance(expr, VariableRef):
+        _add_objective_aff_term(core, 1.0, expr, data)
+    elif isinstance(expr, AffExpr):
+        for coef, vref in expr.linear_terms():
+            _add_objective_aff_term(core, coef, vref, data)
+        if expr.constant != 0.0:
+            core.add_obj(N.Null(expr.constant))
+    elif isinstance(expr, QuadExpr):
+        for coef, v1, v2 in expr.quad_terms():
+            if isinstance(v1, MeasureRef) and isinstance(v2, MeasureRef):
+                warnings.warn(_ObjMeasureExpansionWarn)
+                raise NotImplementedError("expand_measures fallback is not built yet")
+            elif isinstance(v1, MeasureRef):
+                _add_objective_aff_term(core, coef * v2, v1, data)
+            else:
+                _add_objective_aff_term(core, coef * v1, v2, data)
+        _add_objective(core, expr.aff, data, m)
+    else:
+        if any(isinstance(v, MeasureRef) for v in all_expression_variables(expr)):
+            warnings.warn(_ObjMeasureExpansionWarn)
+            raise NotImplementedError("expand_measures fallback is not built yet")
+        _add_generic_objective_term(core, expr, data)
+
+
+def build_exa_core(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> ExaCore:
+    """``build_exa_core!`` (transform.jl:771-796)."""
+    _build_base_iterators(data, m)
+    _add_finite_parameters(core, data, m)
+    _add_finite_variables(core, data, m)
+    _add_infinite_variables(core, data, m)
+    _add_parameter_functions(core, data, m)
+    _add_semi_infinite_variables(core, data, m)
+    _add_point_variables(core, data, m)
+    _add_constraints(core, data, m)
+    _add_derivative_approximations(core, data, m)
+    _add_collocation_restrictions(core, data, m)
+    if m.objective_sense is not None:
+        _add_objective(core, m.objective_function, data, m)
+    return core
+
+
+def exa_core(m: InfiniteModel, data: Optional[ExaMappingData] = None, backend=None) -> ExaCore:
+    """``ExaModels.ExaCore(inf_model, data; backend)`` (transform.jl:808-817)."""
+    data = data if data is not None else ExaMappingData()
+    core = ExaCore(backend=backend, minimize=(m.objective_sense != "max"))
+    return build_exa_core(core, data, m)
