@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json: jac_coord!+hess_coord! evaluation pairs
+per second on the quadrotor transcription (examples/quadrotor.jl) at 10^6 supports,
+with the achieved fraction of the gfx950 HBM roofline and a CPU baseline timed in the
+same run.
+
+  python bench.py --gpus N --steps K --warmup W [--supports S] [--scaling weak|strong]
+
+A "step" is one jac_coord! + one hess_coord! over the resident model (inputs already
+in HBM).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the time
+axis is sharded into contiguous support blocks (halo of one support for the
+finite-difference rows); jac_coord!/hess_coord! need no collective, so ranks only meet
+at the barriers that bracket the timed region.  Weak scaling (default): every rank owns
+S supports of an N*S-support horizon; value = (supports all ranks processed per second)
+/ 1e6, i.e. evaluation pairs per second normalised to the 10^6-support problem.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def eval_point(nvar, ncon, x0, S_local, seed=0):
+    """x = x0 + 0.1 N(0,1) (seed 0), |x8| clipped to 1.2; y ~ N(0,1) (seed 1)."""
+    x = x0 + 0.1 * np.random.default_rng(seed).standard_normal(nvar)
+    x[7 * S_local:8 * S_local] = np.clip(x[7 * S_local:8 * S_local], -1.2, 1.2)
+    y = np.random.default_rng(seed + 1).standard_normal(ncon)
+    return x, y
+
+
+def cpu_baseline(sample_supports: int, seconds: float = 12.0):
+    """The oracle (CPU restatement of the reference algorithm, kind 'port') timed on this
+    box's host cores on a bounded sample: the same quadrotor model at `sample_supports`
+    supports; reported in the metric's unit (pairs/s normalised to 1e6 supports)."""
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    from pyoracle import OracleModel
+    core = transcribe.exa_core(workloads.quadrotor(sample_supports))
+    om = OracleModel(core.to_blob())
+    x, y = eval_point(om.nvar, om.ncon, om.x0, sample_supports)
+    out = {}
+    for label, threads in (("1", 1), ("all", om.max_threads())):
+        om.set_threads(threads)
+        om.jac_coord(x); om.hess_coord(x, y, 1.0)   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            om.jac_coord(x); om.hess_coord(x, y, 1.0)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds / 2 or n >= 50:
+                break
+        out[label] = (n / dt * sample_supports / 1e6, threads)
+    return {
+        "value": out["1"][0], "unit": "jac+hess pairs/s (1e6-support quadrotor equivalent)", "cores": 1,
+        "kind": "port",
+        "sample": f"quadrotor at {sample_supports} supports, oracle/iem_oracle.c (generic tree interpreter, "
+                  f"gcc -O2 -ffp-contract=off), scaled by supports/1e6",
+        "value_all_cores": out["all"][0], "all_cores": out["all"][1],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--supports", type=int, default=1_000_000, help="supports per rank (weak) / total (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--store-mode", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd import shard, transcribe, workloads
+    from infiniteexamodels.jl_amd.model import ExaModel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    iemlib.build_library()
+    iemlib.set_option("store_mode", args.store_mode)
+
+    if args.scaling == "weak":
+        S_global, S_local = args.supports * world, args.supports
+    else:
+        S_global, S_local = args.supports, None
+    if world == 1:
+        core = transcribe.exa_core(workloads.quadrotor(S_global))
+        S_local = S_global
+    else:
+        core, S_local = shard.quadrotor_shard(S_global, rank, world)
+    blob = core.to_blob()
+    gm = ExaModel(core, device=local_rank, blob=blob)
+    del blob
+    x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22, seed=rank * 2)
+    xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
+    jac = torch.empty(gm.meta.nnzj, dtype=torch.float64, device=dev)
+    hess = torch.empty(gm.meta.nnzh, dtype=torch.float64, device=dev)
+
+    def step():
+        gm.jac_coord(xd, jac)
+        gm.hess_coord(xd, yd, hess, obj_weight=1.0)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        sl = torch.tensor([float(S_local)], device=dev, dtype=torch.float64)
+        dist.all_reduce(sl)
+        supports_total = float(sl.item())
+    else:
+        supports_total = float(S_local)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = supports_total / 1e6 * args.steps / dt
+        # roofline of the dominant kernel, timed live with HIP events on the launch stream
+        ms_jac, ms_hess = gm.time_kernels(xd, yd, jac, hess, iters=30)
+        ks = {k["kind"]: k for k in gm.kernels() if k["kind"] in ("jac", "hess") and k["grid"][0] > 1}
+        dom = "hess" if ms_hess >= ms_jac else "jac"
+        kd = ks[dom]
+        alg = kd["alg_bytes_read"] + kd["alg_bytes_written"]
+        ms_dom = ms_hess if dom == "hess" else ms_jac
+        achieved = alg / (ms_dom * 1e-3) / 1e9
+        pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())
+        line = {
+            "metric": "jac_coord!+hess_coord! evals/sec, quadrotor 1e6 supports; % HBM roofline",
+            "value": value, "unit": "jac+hess pairs/s (1e6-support quadrotor equivalent)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"quadrotor (examples/quadrotor.jl), backward FD, {int(supports_total)} supports total, "
+                                   f"{S_local} per GPU, jac_coord!+hess_coord! only, seed 0/1 inputs resident in HBM",
+                       "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
+                       "store_mode": args.store_mode, "parallelism": f"support-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes": alg, "kernel_ms": ms_dom,
+                         "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
+                         "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

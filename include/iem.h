@@ -1,0 +1,131 @@
+/* iem.h — C-ABI of libiem_hip.so: the MI355X evaluation backend for
+ * InfiniteOpt → ExaModels transcriptions.
+ *
+ * The reference reaches its evaluator through Julia method calls on an
+ * ExaModels.ExaModel built at /root/reference/src/infiniteopt_backend.jl:155-156
+ * (`ExaModels.ExaCore(model, data; backend)` → `ExaModels.ExaModel(core)`); the NLP
+ * solvers then call the NLPModels API on it every iteration
+ * (/root/reference/ext/InfiniteExaModelsIpopt.jl:48-49,59-60,
+ *  /root/reference/ext/InfiniteExaModelsMadNLP.jl:49-50,64).  Each entry point
+ * below replaces one of those calls; a Julia `ccall` / Python `ctypes` shim binds
+ * them one to one.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative IEM_E_* code otherwise; the
+ *     message is in iem_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - `d_` arguments are DEVICE pointers (ROCArray / torch data_ptr), `h_` are HOST
+ *     pointers.  The caller owns every array; outputs are fully overwritten.
+ *   - evaluation calls are enqueued on the handle's stream and return immediately,
+ *     except iem_obj (returns a host scalar) and the *_structure calls.
+ *   - a handle is not thread-safe; use one per solver.
+ */
+#ifndef IEM_H
+#define IEM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iem_model iem_model;
+
+enum {
+  IEM_OK = 0,
+  IEM_E_BLOB = -1,    /* malformed / unsupported blob                     */
+  IEM_E_HIP = -2,     /* HIP runtime error                                */
+  IEM_E_COMPILE = -3, /* kernel generation / hiprtc failure               */
+  IEM_E_ARG = -4,     /* bad argument                                     */
+  IEM_E_NODEVICE = -5 /* no usable gfx950 device                          */
+};
+
+/* mirrors NLPModels' `meta` fields the reference reads
+ * (infiniteopt_backend.jl:600-601 get_x0/get_y0; ext/*.jl solver construction) */
+typedef struct iem_meta_t {
+  int64_t nvar, ncon, npar;
+  int64_t nnzj, nnzh;
+  int64_t n_templates;
+  int32_t minimize;
+  int32_t n_kernels; /* fused kernels generated for this model */
+} iem_meta_t;
+
+/* which host mirror iem_get_host returns */
+enum { IEM_X0 = 0, IEM_LVAR = 1, IEM_UVAR = 2, IEM_LCON = 3, IEM_UCON = 4, IEM_Y0 = 5, IEM_THETA = 6 };
+
+/* per-template layout (ExaModels SIMDFunction offsets o0/o1/o2 and steps) */
+typedef struct iem_template_info_t {
+  int64_t kind; /* 0 objective, 1 constraint */
+  int64_t n_items, o0, o1, o2, o1step, o2step;
+} iem_template_info_t;
+
+/* one fused kernel of the model: launch shape and ALGORITHMIC traffic (every distinct
+ * input element read once, every output element written once) — what the roofline
+ * line of bench.py is computed from */
+typedef struct iem_kernel_info_t {
+  char name[64];
+  int32_t kind; /* 0 cons, 1 jac, 2 hess, 3 obj, 4 grad */
+  int32_t jit;  /* 1 if this model's code object was compiled by hiprtc (cache miss) */
+  int64_t grid[3];
+  int64_t lds_bytes;
+  int64_t alg_bytes_read, alg_bytes_written;
+} iem_kernel_info_t;
+
+/* ---- lifecycle -----------------------------------------------------------
+ * iem_create   replaces ExaModels.ExaModel(core) with backend = MI355XBackend()
+ *              (infiniteopt_backend.jl:155-156; README.md:41 `backend = CUDABackend()`).
+ *              `blob` is the transcribed model (include/iem_blob.h). */
+int iem_create(const void *blob, size_t nbytes, int device, iem_model **out);
+int iem_destroy(iem_model *m);
+int iem_meta(const iem_model *m, iem_meta_t *out);
+int iem_template_info(const iem_model *m, int64_t i, iem_template_info_t *out);
+int iem_kernel_info(const iem_model *m, int k, iem_kernel_info_t *out);
+int iem_get_host(const iem_model *m, int which, double *h_out);
+int iem_set_stream(iem_model *m, void *hip_stream);
+int iem_synchronize(iem_model *m);
+
+/* ExaModels.set_parameter!(core, param, vals)  (infiniteopt_backend.jl:522-526,546):
+ * overwrite θ[off .. off+len) (0-based offset) from a host array. */
+int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_vals);
+
+/* ---- NLPModels evaluation API ------------------------------------------------
+ * obj / grad! / cons! / jac_coord! / hess_coord!(m, x, y, vals; obj_weight) as called by
+ * the solvers (ext/InfiniteExaModelsIpopt.jl:49, ext/InfiniteExaModelsMadNLP.jl:50). */
+int iem_obj(iem_model *m, const double *d_x, double *h_out);
+int iem_obj_device(iem_model *m, const double *d_x, double *d_out); /* async variant */
+int iem_grad(iem_model *m, const double *d_x, double *d_g);
+int iem_cons(iem_model *m, const double *d_x, double *d_c);
+int iem_jac_coord(iem_model *m, const double *d_x, double *d_vals);
+int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_vals);
+
+/* jac_structure! / hess_structure! — one-off; `base` = 1 for Julia, 0 for C/Python.
+ * Hessian pairs are lower-triangular (row >= col); COO may repeat positions. */
+int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base);
+int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base);
+int iem_jac_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base);
+int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base);
+
+/* ---- kernel generation (no device needed) ---------------------------------------
+ * The evaluator of a model is specialised HIP source generated from its templates
+ * and compiled for gfx950 (offline into a code-object cache, or by hiprtc on a cache
+ * miss).  These two calls expose the generator so a build step can pre-compile. */
+int iem_emit_source(const void *blob, size_t nbytes, char **out_src, uint64_t *out_key);
+/* text description of the launches (kernel name, grid, argument tables) — for tooling/tests */
+int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt);
+void iem_free(void *p);
+
+/* knobs: "store_mode" 0 = direct strided stores, 1 = LDS-transposed coalesced stores */
+int iem_set_option(const char *name, int64_t value);
+
+/* per-kernel timing of the last jac/hess call pair, measured with HIP events on the
+ * handle's stream (used by bench.py for the roofline line) */
+int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess,
+                     int iters, double *h_ms_jac, double *h_ms_hess);
+
+const char *iem_last_error(void);
+const char *iem_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IEM_H */

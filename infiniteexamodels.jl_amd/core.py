@@ -347,4 +347,5 @@ class ExaCore:
                 parts.append(payload.tobytes())
         blob = b"".join(parts)
         assert len(blob) == 8 * total
+        self._blob_arrays = arrays   # array table of the last blob (tooling/tests)
         return blob

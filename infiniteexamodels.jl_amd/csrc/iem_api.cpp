@@ -1,0 +1,554 @@
+// iem_api.cpp — libiem_hip.so: C-ABI (include/iem.h) over the generated gfx950 kernels.
+//
+// Host side of the drop-in boundary: parses the transcribed model, generates and loads
+// its fused kernels (code-object cache → hiprtc on a miss), keeps θ / item-data arrays
+// resident in HBM, and enqueues one launch per support grid for each NLPModels call.
+// There is NO CPU evaluation path in this library: without a HIP device iem_create
+// fails with IEM_E_NODEVICE.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/iem.h"
+#include "iem_codegen.hpp"
+#include "iem_model.hpp"
+
+static const char *kDeviceHeader =
+#include "iem_device_h.inc"
+    ;
+
+namespace {
+
+thread_local std::string g_err;
+iem::Options g_opt;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(IEM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+  } while (0)
+
+std::string full_source(const iem::Program &p) {
+  std::string s;
+  s += "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+  s += kDeviceHeader;
+  s += "\n";
+  s += p.source;
+  return s;
+}
+
+std::string lib_dir() {
+  Dl_info info;
+  if (dladdr((void *)&iem_version, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    size_t k = p.find_last_of('/');
+    if (k != std::string::npos) return p.substr(0, k);
+  }
+  return ".";
+}
+
+std::string cache_dir() {
+  const char *e = std::getenv("IEM_KERNEL_CACHE");
+  if (e && *e) return e;
+  return lib_dir() + "/../kernels";
+}
+
+std::string key_hex(uint64_t k) {
+  char b[32];
+  std::snprintf(b, sizeof b, "%016llx", (unsigned long long)k);
+  return b;
+}
+
+bool read_file(const std::string &path, std::vector<char> &out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  f.seekg(0, std::ios::end);
+  std::streamsize n = f.tellg();
+  if (n <= 0) return false;
+  f.seekg(0);
+  out.resize((size_t)n);
+  return (bool)f.read(out.data(), n);
+}
+
+}  // namespace
+
+struct iem_model {
+  iem::Model model;
+  iem::Program prog;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipModule_t mod = nullptr;
+  std::vector<hipFunction_t> fns;
+  hipFunction_t fn_reduce = nullptr;
+  double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
+  double *h_obj = nullptr;  // pinned
+  std::map<int, void *> d_arrays;  // model array id -> device copy
+  std::vector<double> theta_host;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool jit = false;
+};
+
+namespace {
+
+int upload_array(iem_model *m, int id, bool as_int) {
+  if (m->d_arrays.count(id)) return IEM_OK;
+  const iem::ArrayDesc &a = m->model.arrs[id];
+  void *d = nullptr;
+  size_t bytes = (size_t)std::max<int64_t>(a.n, 1) * 8;
+  HIP_TRY(hipMalloc(&d, bytes));
+  if (a.kind == IEM_A_F64_DATA || a.kind == IEM_A_I64_DATA) {
+    bool src_int = a.kind == IEM_A_I64_DATA;
+    if (src_int == as_int) {
+      HIP_TRY(hipMemcpy(d, a.data, (size_t)a.n * 8, hipMemcpyHostToDevice));
+    } else if (as_int) {
+      std::vector<int64_t> tmp(a.n);
+      for (int64_t j = 0; j < a.n; ++j) tmp[j] = a.i(j);
+      HIP_TRY(hipMemcpy(d, tmp.data(), (size_t)a.n * 8, hipMemcpyHostToDevice));
+    } else {
+      std::vector<double> tmp(a.n);
+      for (int64_t j = 0; j < a.n; ++j) tmp[j] = a.f(j);
+      HIP_TRY(hipMemcpy(d, tmp.data(), (size_t)a.n * 8, hipMemcpyHostToDevice));
+    }
+  } else if (as_int) {
+    std::vector<int64_t> tmp(a.n);
+    for (int64_t j = 0; j < a.n; ++j) tmp[j] = a.i(j);
+    HIP_TRY(hipMemcpy(d, tmp.data(), (size_t)a.n * 8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> tmp(a.n);
+    for (int64_t j = 0; j < a.n; ++j) tmp[j] = a.f(j);
+    HIP_TRY(hipMemcpy(d, tmp.data(), (size_t)a.n * 8, hipMemcpyHostToDevice));
+  }
+  m->d_arrays[id] = d;
+  return IEM_OK;
+}
+
+int compile_or_load(iem_model *m) {
+  const std::string src = full_source(m->prog);
+  const uint64_t key = iem::fnv1a64(src);
+  const std::string dir = cache_dir();
+  const std::string path = dir + "/iem_" + key_hex(key) + ".hsaco";
+  std::vector<char> code;
+  if (!read_file(path, code)) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, m->device));
+    std::string arch = prop.gcnArchName;
+    size_t colon = arch.find(':');
+    if (colon != std::string::npos) arch = arch.substr(0, colon);
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "iem_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+      return fail(IEM_E_COMPILE, "hiprtcCreateProgram failed");
+    std::string archopt = "--offload-arch=" + arch;
+    const char *opts[] = {archopt.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n, '\0');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      return fail(IEM_E_COMPILE, "hiprtc: " + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code.resize(n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    m->jit = true;
+    mkdir(dir.c_str(), 0755);
+    std::ofstream f(path + ".tmp", std::ios::binary);
+    if (f) {
+      f.write(code.data(), (std::streamsize)code.size());
+      f.close();
+      std::rename((path + ".tmp").c_str(), path.c_str());
+    }
+  }
+  HIP_TRY(hipModuleLoadData(&m->mod, code.data()));
+  m->fns.resize(m->prog.kernels.size());
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));
+  HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_reduce_partials"));
+  return IEM_OK;
+}
+
+int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w) {
+  const iem::KernelDesc &kd = m->prog.kernels[k];
+  std::vector<uint64_t> buf;
+  auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
+  push_ptr(x); push_ptr(m->d_theta); push_ptr(y); push_ptr(out);
+  uint64_t wb; std::memcpy(&wb, &w, 8); buf.push_back(wb);
+  for (int64_t v : kd.ip) buf.push_back((uint64_t)v);
+  if (kd.ip.empty()) buf.push_back(0);
+  for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); buf.push_back(b); }
+  if (kd.dp.empty()) buf.push_back(0);
+  for (int id : kd.fa) push_ptr(m->d_arrays[id]);
+  if (kd.fa.empty()) buf.push_back(0);
+  for (int id : kd.ia) push_ptr(m->d_arrays[id]);
+  if (kd.ia.empty()) buf.push_back(0);
+  size_t sz = buf.size() * 8;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], 256, 1, 1, 0,
+                                m->stream, nullptr, cfg));
+  return IEM_OK;
+}
+
+int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w) {
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    if (m->prog.kernels[k].kind == kind) {
+      int rc = launch(m, k, x, y, out, w);
+      if (rc) return rc;
+    }
+  return IEM_OK;
+}
+
+// host-side item index evaluation for the structure calls
+struct ItemIdx {
+  const iem::Model &m;
+  const iem::Template &t;
+  std::vector<int64_t> ifv, idx;
+  ItemIdx(const iem::Model &mm, const iem::Template &tt) : m(mm), t(tt), ifv(tt.ifields.size()), idx(tt.idx.size()) {}
+  void eval(int64_t k) {
+    int64_t kc[3] = {k % t.dims[0], (k / t.dims[0]) % t.dims[1], k / (t.dims[0] * t.dims[1])};
+    for (size_t f = 0; f < t.ifields.size(); ++f) {
+      const iem::FieldDesc &fl = t.ifields[f];
+      int64_t p = fl.base + fl.step[0] * kc[0] + fl.step[1] * kc[1] + fl.step[2] * kc[2];
+      ifv[f] = fl.mode == IEM_F_AFFINE ? p : m.arrs[fl.arr].i(p);
+    }
+    for (size_t i = 0; i < t.idx.size(); ++i) {
+      int64_t v = t.idx[i].c0;
+      for (int j = 0; j < t.idx[i].nterms; ++j) v += t.idx[i].coef[j] * ifv[t.idx[i].field[j]];
+      idx[i] = v;
+    }
+  }
+};
+
+void jac_structure_host(const iem::Model &m, int64_t *rows, int64_t *cols, int base) {
+  for (const iem::Template &t : m.tpl) {
+    if (t.kind != IEM_T_CON || t.o1step == 0) continue;
+    ItemIdx it(m, t);
+    for (int64_t k = 0; k < t.n_items; ++k) {
+      it.eval(k);
+      int64_t o = t.o1 + (int64_t)t.o1step * k;
+      for (int s = 0; s < t.o1step; ++s) {
+        rows[o + s] = t.o0 + k + base;
+        cols[o + s] = it.idx[t.slot1_idx[s]] - 1 + base;
+      }
+    }
+  }
+}
+
+void hess_structure_host(const iem::Model &m, int64_t *rows, int64_t *cols, int base) {
+  for (const iem::Template &t : m.tpl) {
+    if (t.o2step == 0) continue;
+    ItemIdx it(m, t);
+    for (int64_t k = 0; k < t.n_items; ++k) {
+      it.eval(k);
+      int64_t o = t.o2 + (int64_t)t.o2step * k;
+      for (int s = 0; s < t.o2step; ++s) {
+        int64_t a = it.idx[t.slot2_i[s]], b = it.idx[t.slot2_j[s]];
+        rows[o + s] = (a >= b ? a : b) - 1 + base;
+        cols[o + s] = (a >= b ? b : a) - 1 + base;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *iem_last_error(void) { return g_err.c_str(); }
+const char *iem_version(void) { return "iem-hip 0.1 (gfx950)"; }
+
+void iem_free(void *p) { std::free(p); }
+
+int iem_set_option(const char *name, int64_t value) {
+  if (!name) return fail(IEM_E_ARG, "null option name");
+  if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
+  return fail(IEM_E_ARG, std::string("unknown option ") + name);
+}
+
+int iem_emit_source(const void *blob, size_t nbytes, char **out_src, uint64_t *out_key) {
+  try {
+    iem::Model model;
+    iem::parse_blob(blob, nbytes, model);
+    iem::Program p = iem::generate(model, g_opt);
+    std::string s = full_source(p);
+    if (out_src) {
+      *out_src = (char *)std::malloc(s.size() + 1);
+      std::memcpy(*out_src, s.c_str(), s.size() + 1);
+    }
+    if (out_key) *out_key = iem::fnv1a64(s);
+    return IEM_OK;
+  } catch (const std::exception &e) {
+    return fail(IEM_E_BLOB, e.what());
+  }
+}
+
+int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
+  try {
+    iem::Model model;
+    iem::parse_blob(blob, nbytes, model);
+    iem::Program p = iem::generate(model, g_opt);
+    std::ostringstream os;
+    os.precision(17);
+    os << "partials " << p.n_partials << "\n";
+    for (const iem::KernelDesc &kd : p.kernels) {
+      os << "kernel " << kd.name << " kind " << kd.kind << " grid " << kd.grid[0] << " " << kd.grid[1] << " " << kd.grid[2]
+         << " lds " << kd.lds_bytes << "\n";
+      os << "ip " << kd.ip.size(); for (int64_t v : kd.ip) os << " " << v; os << "\n";
+      os << "dp " << kd.dp.size(); for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); os << " " << b; } os << "\n";
+      os << "fa " << kd.fa.size(); for (int v : kd.fa) os << " " << v; os << "\n";
+      os << "ia " << kd.ia.size(); for (int v : kd.ia) os << " " << v; os << "\n";
+    }
+    std::string s = os.str();
+    if (out_txt) {
+      *out_txt = (char *)std::malloc(s.size() + 1);
+      std::memcpy(*out_txt, s.c_str(), s.size() + 1);
+    }
+    return IEM_OK;
+  } catch (const std::exception &e) {
+    return fail(IEM_E_BLOB, e.what());
+  }
+}
+
+int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
+  if (!blob || !out) return fail(IEM_E_ARG, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(IEM_E_NODEVICE, "no HIP device visible: libiem_hip has no CPU path");
+  if (device < 0 || device >= ndev) return fail(IEM_E_ARG, "device ordinal out of range");
+  iem_model *m = new iem_model();
+  m->device = device;
+  try {
+    iem::parse_blob(blob, nbytes, m->model);
+    m->prog = iem::generate(m->model, g_opt);
+  } catch (const std::exception &e) {
+    delete m;
+    return fail(IEM_E_BLOB, e.what());
+  }
+  int rc = IEM_OK;
+  auto bail = [&](int code) { iem_destroy(m); return code; };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(IEM_E_HIP, "hipSetDevice failed"));
+  if ((rc = compile_or_load(m)) != IEM_OK) return bail(rc);
+  const iem::Model &M = m->model;
+  m->theta_host.resize((size_t)std::max<int64_t>(M.npar, 1));
+  for (int64_t i = 0; i < M.npar; ++i) m->theta_host[i] = M.arrs[M.arr_theta].f(i);
+  if (hipMalloc((void **)&m->d_theta, m->theta_host.size() * 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc theta"));
+  if (hipMemcpy(m->d_theta, m->theta_host.data(), m->theta_host.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+    return bail(fail(IEM_E_HIP, "upload theta"));
+  if (hipMalloc((void **)&m->d_partials, (size_t)std::max<int64_t>(m->prog.n_partials, 1) * 8) != hipSuccess)
+    return bail(fail(IEM_E_HIP, "hipMalloc partials"));
+  if (hipMalloc((void **)&m->d_obj, 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc obj"));
+  if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocDefault) != hipSuccess) return bail(fail(IEM_E_HIP, "hipHostMalloc"));
+  for (const iem::KernelDesc &kd : m->prog.kernels) {
+    for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return bail(rc);
+    for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return bail(rc);
+  }
+  if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) return bail(fail(IEM_E_HIP, "hipEventCreate"));
+  *out = m;
+  return IEM_OK;
+}
+
+int iem_destroy(iem_model *m) {
+  if (!m) return IEM_OK;
+  if (m->d_theta) hipFree(m->d_theta);
+  if (m->d_partials) hipFree(m->d_partials);
+  if (m->d_obj) hipFree(m->d_obj);
+  if (m->h_obj) hipHostFree(m->h_obj);
+  for (auto &kv : m->d_arrays) hipFree(kv.second);
+  if (m->ev0) hipEventDestroy(m->ev0);
+  if (m->ev1) hipEventDestroy(m->ev1);
+  if (m->mod) hipModuleUnload(m->mod);
+  delete m;
+  return IEM_OK;
+}
+
+int iem_meta(const iem_model *m, iem_meta_t *out) {
+  if (!m || !out) return fail(IEM_E_ARG, "null argument");
+  out->nvar = m->model.nvar; out->ncon = m->model.ncon; out->npar = m->model.npar;
+  out->nnzj = m->model.nnzj; out->nnzh = m->model.nnzh;
+  out->n_templates = (int64_t)m->model.tpl.size();
+  out->minimize = m->model.minimize;
+  out->n_kernels = (int32_t)m->prog.kernels.size();
+  return IEM_OK;
+}
+
+int iem_template_info(const iem_model *m, int64_t i, iem_template_info_t *out) {
+  if (!m || !out || i < 0 || i >= (int64_t)m->model.tpl.size()) return fail(IEM_E_ARG, "bad template index");
+  const iem::Template &t = m->model.tpl[i];
+  out->kind = t.kind; out->n_items = t.n_items; out->o0 = t.o0; out->o1 = t.o1; out->o2 = t.o2;
+  out->o1step = t.o1step; out->o2step = t.o2step;
+  return IEM_OK;
+}
+
+int iem_kernel_info(const iem_model *m, int k, iem_kernel_info_t *out) {
+  if (!m || !out || k < 0 || k >= (int)m->prog.kernels.size()) return fail(IEM_E_ARG, "bad kernel index");
+  const iem::KernelDesc &kd = m->prog.kernels[k];
+  std::memset(out, 0, sizeof *out);
+  std::strncpy(out->name, kd.name.c_str(), sizeof(out->name) - 1);
+  out->kind = kd.kind;
+  for (int d = 0; d < 3; ++d) out->grid[d] = kd.grid[d];
+  out->lds_bytes = kd.lds_bytes;
+  out->alg_bytes_read = kd.alg_bytes_read;
+  out->alg_bytes_written = kd.alg_bytes_written;
+  out->jit = m->jit ? 1 : 0;
+  return IEM_OK;
+}
+
+int iem_get_host(const iem_model *m, int which, double *h_out) {
+  if (!m || !h_out) return fail(IEM_E_ARG, "null argument");
+  const iem::Model &M = m->model;
+  switch (which) {
+    case IEM_X0: case IEM_LVAR: case IEM_UVAR: {
+      const iem::ArrayDesc &a = M.arrs[which == IEM_X0 ? M.arr_x0 : which == IEM_LVAR ? M.arr_lvar : M.arr_uvar];
+      for (int64_t i = 0; i < M.nvar; ++i) h_out[i] = a.f(i);
+      return IEM_OK;
+    }
+    case IEM_LCON: case IEM_UCON:
+      for (const iem::Template &t : M.tpl) {
+        if (t.kind != IEM_T_CON) continue;
+        int mode = which == IEM_LCON ? t.lmode : t.umode;
+        for (int64_t k = 0; k < t.n_items; ++k)
+          h_out[t.o0 + k] = mode ? M.arrs[which == IEM_LCON ? t.larr : t.uarr].f(k) : (which == IEM_LCON ? t.lval : t.uval);
+      }
+      return IEM_OK;
+    case IEM_Y0:
+      for (int64_t i = 0; i < M.ncon; ++i) h_out[i] = 0.0;
+      return IEM_OK;
+    case IEM_THETA:
+      std::memcpy(h_out, m->theta_host.data(), (size_t)M.npar * 8);
+      return IEM_OK;
+  }
+  return fail(IEM_E_ARG, "unknown array selector");
+}
+
+int iem_set_stream(iem_model *m, void *hip_stream) {
+  if (!m) return fail(IEM_E_ARG, "null handle");
+  m->stream = (hipStream_t)hip_stream;
+  return IEM_OK;
+}
+
+int iem_synchronize(iem_model *m) {
+  if (!m) return fail(IEM_E_ARG, "null handle");
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return IEM_OK;
+}
+
+int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_vals) {
+  if (!m || !h_vals) return fail(IEM_E_ARG, "null argument");
+  if (off < 0 || len < 0 || off + len > m->model.npar) return fail(IEM_E_ARG, "parameter range out of bounds");
+  std::memcpy(m->theta_host.data() + off, h_vals, (size_t)len * 8);
+  HIP_TRY(hipMemcpyAsync(m->d_theta + off, m->theta_host.data() + off, (size_t)len * 8, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return IEM_OK;
+}
+
+int iem_obj_device(iem_model *m, const double *d_x, double *d_out) {
+  if (!m || !d_x || !d_out) return fail(IEM_E_ARG, "null argument");
+  int rc = launch_kind(m, iem::KK_OBJ, d_x, nullptr, m->d_partials, 0.0);
+  if (rc) return rc;
+  long long n = m->prog.n_partials;
+  void *args[] = {(void *)&m->d_partials, (void *)&n, (void *)&d_out};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_reduce, 1, 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
+  return IEM_OK;
+}
+
+int iem_obj(iem_model *m, const double *d_x, double *h_out) {
+  if (!h_out) return fail(IEM_E_ARG, "null argument");
+  int rc = iem_obj_device(m, d_x, m ? m->d_obj : nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(m->h_obj, m->d_obj, 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *h_out = *m->h_obj;
+  return IEM_OK;
+}
+
+int iem_grad(iem_model *m, const double *d_x, double *d_g) {
+  if (!m || !d_x || !d_g) return fail(IEM_E_ARG, "null argument");
+  HIP_TRY(hipMemsetAsync(d_g, 0, (size_t)m->model.nvar * 8, m->stream));
+  return launch_kind(m, iem::KK_GRAD, d_x, nullptr, d_g, 0.0);
+}
+
+int iem_cons(iem_model *m, const double *d_x, double *d_c) {
+  if (!m || !d_x || (!d_c && m->model.ncon)) return fail(IEM_E_ARG, "null argument");
+  return launch_kind(m, iem::KK_CONS, d_x, nullptr, d_c, 0.0);
+}
+
+int iem_jac_coord(iem_model *m, const double *d_x, double *d_vals) {
+  if (!m || !d_x || (!d_vals && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
+  return launch_kind(m, iem::KK_JAC, d_x, nullptr, d_vals, 0.0);
+}
+
+int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_vals) {
+  if (!m || !d_x || (!d_y && m->model.ncon) || (!d_vals && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  return launch_kind(m, iem::KK_HESS, d_x, d_y, d_vals, obj_weight);
+}
+
+int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
+  if (!m || ((!h_rows || !h_cols) && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
+  jac_structure_host(m->model, h_rows, h_cols, base);
+  return IEM_OK;
+}
+
+int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
+  if (!m || ((!h_rows || !h_cols) && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  hess_structure_host(m->model, h_rows, h_cols, base);
+  return IEM_OK;
+}
+
+int iem_jac_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
+  if (!m) return fail(IEM_E_ARG, "null handle");
+  std::vector<int64_t> r((size_t)m->model.nnzj), c((size_t)m->model.nnzj);
+  jac_structure_host(m->model, r.data(), c.data(), base);
+  HIP_TRY(hipMemcpy(d_rows, r.data(), r.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_cols, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  return IEM_OK;
+}
+
+int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
+  if (!m) return fail(IEM_E_ARG, "null handle");
+  std::vector<int64_t> r((size_t)m->model.nnzh), c((size_t)m->model.nnzh);
+  hess_structure_host(m->model, r.data(), c.data(), base);
+  HIP_TRY(hipMemcpy(d_rows, r.data(), r.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_cols, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  return IEM_OK;
+}
+
+int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess, int iters,
+                     double *h_ms_jac, double *h_ms_hess) {
+  if (!m || iters <= 0) return fail(IEM_E_ARG, "bad argument");
+  for (int which = 0; which < 2; ++which) {
+    float total = 0.f;
+    for (int it = 0; it < iters; ++it) {
+      HIP_TRY(hipEventRecord(m->ev0, m->stream));
+      int rc = which == 0 ? iem_jac_coord(m, d_x, d_jac) : iem_hess_coord(m, d_x, d_y, 1.0, d_hess);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(m->ev1, m->stream));
+      HIP_TRY(hipEventSynchronize(m->ev1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+      total += ms;
+    }
+    (which == 0 ? *h_ms_jac : *h_ms_hess) = total / iters;
+  }
+  return IEM_OK;
+}
+
+}  // extern "C"

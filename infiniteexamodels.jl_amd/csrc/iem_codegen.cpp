@@ -1,0 +1,1162 @@
+// iem_codegen.cpp — specialising generator: templates → fused gfx950 lane programs.
+//
+// Design: templates that iterate over the same support grid are fused
+// into ONE kernel per NLPModels call (cons!/jac_coord!/hess_coord!/obj/grad!), lane =
+// grid point.  Every template of the group is differentiated symbolically into a
+// hash-consed expression DAG following the reverse sweeps ExaModels performs per item
+// (first order: depth-first adjoint walk; second order: hrpass0/hrpass/hdrpass — same
+// visit order, same accumulation order as the CPU restatement), so
+//   * x[off_k + q] is loaded once per lane however many templates read it,
+//   * sin/cos/tan of a state are computed once per lane (sincos pairing),
+//   * a template's item block goes out through iem_store_rows<NS> (iem_device.h).
+// The emitted code is size-independent: slab offsets, extents and COO offsets are
+// kernel arguments, so one code object serves 10² and 10⁶ supports.
+#include "iem_codegen.hpp"
+
+#include <algorithm>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <set>
+#include <sstream>
+#include <unordered_map>
+
+namespace iem {
+
+uint64_t fnv1a64(const std::string &s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+namespace {
+
+constexpr double kD2R = 0.017453292519943295;
+constexpr double kR2D = 57.29577951308232;
+constexpr double kLN2 = 0.6931471805599453;
+constexpr double kLN10 = 2.302585092994046;
+
+struct AffQ {
+  int64_t c = 0, k[3] = {0, 0, 0};
+  bool operator<(const AffQ &o) const {
+    if (c != o.c) return c < o.c;
+    for (int d = 0; d < 3; ++d) if (k[d] != o.k[d]) return k[d] < o.k[d];
+    return false;
+  }
+  bool operator==(const AffQ &o) const { return c == o.c && k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2]; }
+};
+
+struct Group {
+  int64_t grid_id = -1;
+  int nd = 1;
+  int64_t lo[3] = {0, 0, 0}, ext[3] = {1, 1, 1};
+  std::vector<int> tpls, scalars;
+};
+
+std::string hexf(double v) {
+  if (std::isnan(v)) return "__builtin_nan(\"\")";
+  if (std::isinf(v)) return v > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%a", v);
+  std::string s(buf);
+  if (s[0] == '-') return "(" + s + ")";
+  return s;
+}
+
+// pseudo unary ops beyond the blob vocabulary
+enum { U_SGN = 1000 };
+
+// ---------------------------------------------------------------------------
+// expression DAG
+// ---------------------------------------------------------------------------
+enum VOp { VC = 0, VDP = 1, VLD = 2, VUN = 3, VBIN = 4, VW = 5, VSEL = 6 };
+
+struct VNode {
+  int op, sub, a, b, c;
+  double imm;
+};
+
+struct VKey {
+  int op, sub, a, b, c;
+  uint64_t bits;
+  bool operator<(const VKey &o) const {
+    if (op != o.op) return op < o.op;
+    if (sub != o.sub) return sub < o.sub;
+    if (a != o.a) return a < o.a;
+    if (b != o.b) return b < o.b;
+    if (c != o.c) return c < o.c;
+    return bits < o.bits;
+  }
+};
+
+struct IdxVal {  // 1-based variable/parameter index or 0-based array position
+  AffQ aff;
+  std::vector<std::pair<int64_t, int>> ind;  // coef × iload id
+  bool operator<(const IdxVal &o) const {
+    if (!(aff == o.aff)) return aff < o.aff;
+    return ind < o.ind;
+  }
+};
+
+struct ILoad {
+  int ia_slot;
+  AffQ pos;
+  std::set<int> guards;
+};
+
+struct Load {
+  int arr;       // 0 x, 1 theta, 2 y, 3 fa[slot]
+  int slot;
+  int idxval;    // position (0-based) as IdxVal id
+  std::set<int> guards;
+};
+
+struct Output {
+  int kind;          // KernelKind
+  int tpl;
+  int guard;
+  int pos_idx;       // IdxVal id: position of slot 0 / the row / unused
+  std::vector<int> vals;      // DAG ids
+  std::vector<int> grad_idx;  // KK_GRAD: IdxVal ids (0-based) per value
+  std::vector<int> grad_mode; // 0 exclusive store, 1 wave-uniform, 2 atomic
+};
+
+class KernelBuilder {
+ public:
+  KernelBuilder(const Model &m, const Group &g, int kind, const Options &opt, const std::string &name)
+      : m_(m), g_(g), kind_(kind), opt_(opt), name_(name) {}
+
+  // ---- parameters ---------------------------------------------------------
+  std::string ip(int64_t v) {
+    auto it = ip_ids_.find(v);
+    if (it == ip_ids_.end()) {
+      it = ip_ids_.emplace(v, (int)ipv_.size()).first;
+      ipv_.push_back(v);
+    }
+    return "A.ip[" + std::to_string(it->second) + "]";
+  }
+  std::string coefstr(int64_t v) {
+    if (v >= -16 && v <= 16) return std::to_string(v) + "LL";
+    return ip(v);
+  }
+  int dp(double v) {
+    uint64_t b; std::memcpy(&b, &v, 8);
+    auto it = dp_ids_.find(b);
+    if (it == dp_ids_.end()) { it = dp_ids_.emplace(b, (int)dpv_.size()).first; dpv_.push_back(v); }
+    return it->second;
+  }
+  int fa_slot(int arr) {
+    auto it = fa_ids_.find(arr);
+    if (it == fa_ids_.end()) { it = fa_ids_.emplace(arr, (int)fav_.size()).first; fav_.push_back(arr); }
+    return it->second;
+  }
+  int ia_slot(int arr) {
+    auto it = ia_ids_.find(arr);
+    if (it == ia_ids_.end()) { it = ia_ids_.emplace(arr, (int)iav_.size()).first; iav_.push_back(arr); }
+    return it->second;
+  }
+
+  // ---- DAG ------------------------------------------------------------------
+  int mk(int op, int sub, int a, int b, int c, double imm) {
+    uint64_t bits; std::memcpy(&bits, &imm, 8);
+    VKey k{op, sub, a, b, c, bits};
+    auto it = memo_.find(k);
+    if (it != memo_.end()) return it->second;
+    int id = (int)v_.size();
+    v_.push_back(VNode{op, sub, a, b, c, imm});
+    memo_.emplace(k, id);
+    return id;
+  }
+  int C(double x) { return mk(VC, 0, -1, -1, -1, x); }
+  bool isC(int id, double *val = nullptr) const {
+    if (v_[id].op != VC) return false;
+    if (val) *val = v_[id].imm;
+    return true;
+  }
+  bool isCv(int id, double x) const { return v_[id].op == VC && v_[id].imm == x; }
+  int neg(int a) {
+    double x;
+    if (isC(a, &x)) return C(-x);
+    if (v_[a].op == VUN && v_[a].sub == IEM_OP_NEG) return v_[a].a;
+    return mk(VUN, IEM_OP_NEG, a, -1, -1, 0);
+  }
+  int un(int op, int a) {
+    if (op == IEM_OP_NEG) return neg(a);
+    if (op == IEM_OP_POS) return a;
+    return mk(VUN, op, a, -1, -1, 0);
+  }
+  int add(int a, int b) {
+    double x, y;
+    if (isC(a, &x) && isC(b, &y)) return C(x + y);
+    if (isCv(a, 0.0)) return b;
+    if (isCv(b, 0.0)) return a;
+    return mk(VBIN, IEM_OP_ADD, a, b, -1, 0);
+  }
+  int sub(int a, int b) {
+    double x, y;
+    if (isC(a, &x) && isC(b, &y)) return C(x - y);
+    if (isCv(b, 0.0)) return a;
+    if (isCv(a, 0.0)) return neg(b);
+    return mk(VBIN, IEM_OP_SUB, a, b, -1, 0);
+  }
+  int mul(int a, int b) {
+    double x, y;
+    if (isC(a, &x) && isC(b, &y)) return C(x * y);
+    if (isCv(a, 0.0) || isCv(b, 0.0)) return C(0.0);
+    if (isCv(a, 1.0)) return b;
+    if (isCv(b, 1.0)) return a;
+    if (isCv(a, -1.0)) return neg(b);
+    if (isCv(b, -1.0)) return neg(a);
+    return mk(VBIN, IEM_OP_MUL, a, b, -1, 0);
+  }
+  int div(int a, int b) {
+    double x, y;
+    if (isC(a, &x) && isC(b, &y)) return C(x / y);
+    if (isCv(b, 1.0)) return a;
+    return mk(VBIN, IEM_OP_DIV, a, b, -1, 0);
+  }
+  int powv(int a, int b) {
+    if (isCv(b, 1.0)) return a;
+    return mk(VBIN, IEM_OP_POW, a, b, -1, 0);
+  }
+
+  // ---- index values -----------------------------------------------------------
+  int idxval(const IdxVal &iv) {
+    auto it = idx_ids_.find(iv);
+    if (it != idx_ids_.end()) return it->second;
+    int id = (int)idx_.size();
+    idx_.push_back(iv);
+    idx_ids_.emplace(iv, id);
+    return id;
+  }
+  int iload(int ia, const AffQ &pos, int guard) {
+    for (size_t i = 0; i < iloads_.size(); ++i)
+      if (iloads_[i].ia_slot == ia && iloads_[i].pos == pos) { iloads_[i].guards.insert(guard); return (int)i; }
+    iloads_.push_back(ILoad{ia, pos, {guard}});
+    return (int)iloads_.size() - 1;
+  }
+  int load(int arr, int slot, int idxv, int guard) {
+    auto key = std::make_tuple(arr, slot, idxv);
+    auto it = load_ids_.find(key);
+    int id;
+    if (it == load_ids_.end()) {
+      id = (int)loads_.size();
+      loads_.push_back(Load{arr, slot, idxv, {}});
+      load_ids_.emplace(key, id);
+    } else id = it->second;
+    loads_[id].guards.insert(guard);
+    return mk(VLD, id, -1, -1, -1, 0);
+  }
+
+  // ---- template geometry --------------------------------------------------------
+  struct TGeo {
+    bool scalar = false;
+    int64_t sh[3] = {0, 0, 0};  // k_d = q_d + sh_d
+    int guard = 0;
+  };
+
+  // guard id: canonical text → id
+  int guard_id(const std::string &txt) {
+    auto it = guard_ids_.find(txt);
+    if (it == guard_ids_.end()) { it = guard_ids_.emplace(txt, (int)guards_.size()).first; guards_.push_back(txt); }
+    return it->second;
+  }
+
+  TGeo geo(int ti, bool scalar) {
+    const Template &t = m_.tpl[ti];
+    TGeo G;
+    G.scalar = scalar;
+    std::ostringstream os;
+    if (scalar) {
+      os << "(q0 == 0 && q1 == 0 && q2 == 0)";
+    } else {
+      os << "inb";
+      for (int d = 0; d < g_.nd; ++d) {
+        G.sh[d] = g_.lo[d] - t.origin[d];
+        int64_t qlo = -G.sh[d], qhi = t.dims[d] - G.sh[d];  // valid q range [qlo, qhi)
+        if (qlo > 0) os << " && q" << d << " >= " << coefstr(qlo);
+        if (qhi < g_.ext[d]) os << " && q" << d << " < " << ip(qhi);
+      }
+    }
+    G.guard = guard_id(os.str());
+    return G;
+  }
+
+  AffQ field_aff(const Template &t, const FieldDesc &f, const TGeo &G) const {
+    AffQ a;
+    a.c = f.base;
+    for (int d = 0; d < t.nd; ++d) {
+      if (G.scalar) continue;
+      a.c += f.step[d] * G.sh[d];
+      a.k[d] = f.step[d];
+    }
+    return a;
+  }
+
+  int tpl_idx(int ti, int idx_id, const TGeo &G, int64_t bias) {
+    const Template &t = m_.tpl[ti];
+    const IdxExpr &ix = t.idx[idx_id];
+    IdxVal iv;
+    iv.aff.c = ix.c0 + bias;
+    for (int j = 0; j < ix.nterms; ++j) {
+      const FieldDesc &f = t.ifields[ix.field[j]];
+      AffQ fa = field_aff(t, f, G);
+      if (f.mode == IEM_F_AFFINE) {
+        iv.aff.c += ix.coef[j] * fa.c;
+        for (int d = 0; d < 3; ++d) iv.aff.k[d] += ix.coef[j] * fa.k[d];
+      } else {
+        int il = iload(ia_slot(f.arr), fa, G.guard);
+        iv.ind.emplace_back(ix.coef[j], il);
+      }
+    }
+    std::sort(iv.ind.begin(), iv.ind.end());
+    return idxval(iv);
+  }
+
+  AffQ klin_aff(const Template &t, const TGeo &G, int64_t scale, int64_t off) const {
+    AffQ a;
+    a.c = off;
+    int64_t stride = 1;
+    for (int d = 0; d < t.nd; ++d) {
+      if (!G.scalar) {
+        a.c += scale * stride * G.sh[d];
+        a.k[d] = scale * stride;
+      }
+      stride *= t.dims[d];
+    }
+    return a;
+  }
+
+  // ---- per-template symbolic differentiation -----------------------------------
+  struct TplGen {
+    KernelBuilder &K;
+    int ti;
+    const Template &t;
+    TGeo G;
+    std::vector<int> val, y1, y2, h11, h12, h22;
+    std::vector<int> vidx;  // idx id -> IdxVal id (1-based value)
+    TplGen(KernelBuilder &k, int ti_, const TGeo &g) : K(k), ti(ti_), t(k.m_.tpl[ti_]), G(g) {
+      size_t n = t.nodes.size();
+      val.assign(n, -1); y1.assign(n, -1); y2.assign(n, -1); h11.assign(n, -1); h12.assign(n, -1); h22.assign(n, -1);
+      vidx.assign(t.idx.size(), -1);
+    }
+    int idx1(int id) {
+      if (vidx[id] < 0) vidx[id] = K.tpl_idx(ti, id, G, 0);
+      return vidx[id];
+    }
+    int pos0(int id) {  // 0-based position of a 1-based index
+      return K.tpl_idx(ti, id, G, -1);
+    }
+    void forward(int order) {
+      for (size_t n = 0; n < t.nodes.size(); ++n) {
+        const Node &nd = t.nodes[n];
+        switch (nd.op) {
+          case IEM_OP_CONST: val[n] = K.C(nd.imm); break;
+          case IEM_OP_DATA: {
+            const FieldDesc &f = t.ffields[nd.a];
+            const ArrayDesc &ad = K.m_.arrs[f.arr];
+            if (ad.kind == IEM_A_F64_FILL) {
+              val[n] = K.mk(VDP, K.dp(ad.fill), -1, -1, -1, 0);
+            } else {
+              IdxVal iv;
+              iv.aff = K.field_aff(t, f, G);
+              val[n] = K.load(3, K.fa_slot(f.arr), K.idxval(iv), G.guard);
+            }
+            break;
+          }
+          case IEM_OP_PAR: val[n] = K.load(1, 0, pos0(nd.a), G.guard); break;
+          case IEM_OP_VAR: val[n] = K.load(0, 0, pos0(nd.a), G.guard); break;
+          default:
+            if (IEM_OP_IS_UNARY(nd.op)) unary((int)n, order);
+            else binary((int)n, order);
+        }
+      }
+    }
+    void unary(int n, int order) {
+      const Node &nd = t.nodes[n];
+      KernelBuilder &B = K;
+      int x = val[nd.a];
+      int f = -1, d = -1, h = -1;
+      auto Cn = [&](double v) { return B.C(v); };
+      bool need = order >= 1 && nd.kind != K_REAL;
+      switch (nd.op) {
+        case IEM_OP_NEG: f = B.neg(x); d = Cn(-1); h = Cn(0); break;
+        case IEM_OP_POS: f = x; d = Cn(1); h = Cn(0); break;
+        case IEM_OP_INV: { int u = B.div(Cn(1), x); f = u; if (need) { d = B.neg(B.mul(u, u)); h = B.mul(B.mul(Cn(2), B.mul(u, u)), u); } break; }
+        case IEM_OP_SQRT: { int s = B.un(IEM_OP_SQRT, x); f = s; if (need) { d = B.div(Cn(0.5), s); h = B.div(Cn(-0.25), B.mul(x, s)); } break; }
+        case IEM_OP_CBRT: { int c = B.un(IEM_OP_CBRT, x); f = c; if (need) { d = B.div(Cn(1), B.mul(B.mul(Cn(3), c), c)); h = B.div(Cn(-2), B.mul(B.mul(B.mul(Cn(9), x), c), c)); } break; }
+        case IEM_OP_ABS: f = B.un(IEM_OP_ABS, x); if (need) { d = B.mk(VUN, U_SGN, x, -1, -1, 0); h = Cn(0); } break;
+        case IEM_OP_ABS2: f = B.mul(x, x); if (need) { d = B.mul(Cn(2), x); h = Cn(2); } break;
+        case IEM_OP_EXP: f = B.un(IEM_OP_EXP, x); d = f; h = f; break;
+        case IEM_OP_EXP2: f = B.un(IEM_OP_EXP2, x); if (need) { d = B.mul(f, Cn(kLN2)); h = B.mul(B.mul(f, Cn(kLN2)), Cn(kLN2)); } break;
+        case IEM_OP_LOG: f = B.un(IEM_OP_LOG, x); if (need) { int u = B.div(Cn(1), x); d = u; h = B.neg(B.mul(u, u)); } break;
+        case IEM_OP_LOG2: f = B.un(IEM_OP_LOG2, x); if (need) { int u = B.div(Cn(1), x); d = B.div(u, Cn(kLN2)); h = B.div(B.neg(B.mul(u, u)), Cn(kLN2)); } break;
+        case IEM_OP_LOG10: f = B.un(IEM_OP_LOG10, x); if (need) { int u = B.div(Cn(1), x); d = B.div(u, Cn(kLN10)); h = B.div(B.neg(B.mul(u, u)), Cn(kLN10)); } break;
+        case IEM_OP_LOG1P: f = B.un(IEM_OP_LOG1P, x); if (need) { int u = B.div(Cn(1), B.add(Cn(1), x)); d = u; h = B.neg(B.mul(u, u)); } break;
+        case IEM_OP_SIN: f = B.un(IEM_OP_SIN, x); if (need) { d = B.un(IEM_OP_COS, x); h = B.neg(f); } break;
+        case IEM_OP_COS: f = B.un(IEM_OP_COS, x); if (need) { d = B.neg(B.un(IEM_OP_SIN, x)); h = B.neg(f); } break;
+        case IEM_OP_TAN: { f = B.un(IEM_OP_TAN, x); if (need) { int u = B.add(Cn(1), B.mul(f, f)); d = u; h = B.mul(B.mul(Cn(2), f), u); } break; }
+        case IEM_OP_ASIN: { f = B.un(IEM_OP_ASIN, x); if (need) { int u = B.sub(Cn(1), B.mul(x, x)); int s = B.un(IEM_OP_SQRT, u); d = B.div(Cn(1), s); h = B.div(x, B.mul(u, s)); } break; }
+        case IEM_OP_ACOS: { f = B.un(IEM_OP_ACOS, x); if (need) { int u = B.sub(Cn(1), B.mul(x, x)); int s = B.un(IEM_OP_SQRT, u); d = B.div(Cn(-1), s); h = B.div(B.neg(x), B.mul(u, s)); } break; }
+        case IEM_OP_CSC: { int s = B.div(Cn(1), B.un(IEM_OP_SIN, x)); f = s; if (need) { int tt = B.mul(B.un(IEM_OP_COS, x), s); d = B.mul(B.neg(s), tt); h = B.mul(s, B.add(B.mul(tt, tt), B.mul(s, s))); } break; }
+        case IEM_OP_SEC: { int c = B.div(Cn(1), B.un(IEM_OP_COS, x)); f = c; if (need) { int tt = B.mul(B.un(IEM_OP_SIN, x), c); d = B.mul(c, tt); h = B.mul(c, B.add(B.mul(tt, tt), B.mul(c, c))); } break; }
+        case IEM_OP_COT: { int tt = B.div(Cn(1), B.un(IEM_OP_TAN, x)); f = tt; if (need) { int u = B.add(Cn(1), B.mul(tt, tt)); d = B.neg(u); h = B.mul(B.mul(Cn(2), tt), u); } break; }
+        case IEM_OP_ATAN: { f = B.un(IEM_OP_ATAN, x); if (need) { int u = B.div(Cn(1), B.add(Cn(1), B.mul(x, x))); d = u; h = B.mul(B.mul(B.mul(Cn(-2), x), u), u); } break; }
+        case IEM_OP_ACOT: { f = B.un(IEM_OP_ATAN, B.div(Cn(1), x)); if (need) { int u = B.div(Cn(1), B.add(Cn(1), B.mul(x, x))); d = B.neg(u); h = B.mul(B.mul(B.mul(Cn(2), x), u), u); } break; }
+        case IEM_OP_SIND: { int xr = B.mul(x, Cn(kD2R)); f = B.un(IEM_OP_SIN, xr); if (need) { d = B.mul(Cn(kD2R), B.un(IEM_OP_COS, xr)); h = B.mul(Cn(-(kD2R * kD2R)), f); } break; }
+        case IEM_OP_COSD: { int xr = B.mul(x, Cn(kD2R)); f = B.un(IEM_OP_COS, xr); if (need) { d = B.mul(Cn(-kD2R), B.un(IEM_OP_SIN, xr)); h = B.mul(Cn(-(kD2R * kD2R)), f); } break; }
+        case IEM_OP_TAND: { int xr = B.mul(x, Cn(kD2R)); f = B.un(IEM_OP_TAN, xr); if (need) { int u = B.add(Cn(1), B.mul(f, f)); d = B.mul(Cn(kD2R), u); h = B.mul(B.mul(Cn((kD2R * kD2R) * 2.0), f), u); } break; }
+        case IEM_OP_CSCD: { int xr = B.mul(x, Cn(kD2R)); int s = B.div(Cn(1), B.un(IEM_OP_SIN, xr)); f = s; if (need) { int tt = B.mul(B.un(IEM_OP_COS, xr), s); d = B.mul(B.mul(Cn(-kD2R), s), tt); h = B.mul(B.mul(Cn(kD2R * kD2R), s), B.add(B.mul(tt, tt), B.mul(s, s))); } break; }
+        case IEM_OP_SECD: { int xr = B.mul(x, Cn(kD2R)); int c = B.div(Cn(1), B.un(IEM_OP_COS, xr)); f = c; if (need) { int tt = B.mul(B.un(IEM_OP_SIN, xr), c); d = B.mul(B.mul(Cn(kD2R), c), tt); h = B.mul(B.mul(Cn(kD2R * kD2R), c), B.add(B.mul(tt, tt), B.mul(c, c))); } break; }
+        case IEM_OP_COTD: { int xr = B.mul(x, Cn(kD2R)); int tt = B.div(Cn(1), B.un(IEM_OP_TAN, xr)); f = tt; if (need) { int u = B.add(Cn(1), B.mul(tt, tt)); d = B.mul(Cn(-kD2R), u); h = B.mul(B.mul(Cn((kD2R * kD2R) * 2.0), tt), u); } break; }
+        case IEM_OP_ATAND: { f = B.mul(Cn(kR2D), B.un(IEM_OP_ATAN, x)); if (need) { int u = B.div(Cn(1), B.add(Cn(1), B.mul(x, x))); d = B.mul(Cn(kR2D), u); h = B.mul(B.mul(B.mul(Cn(-kR2D * 2.0), x), u), u); } break; }
+        case IEM_OP_ACOTD: { f = B.mul(Cn(kR2D), B.un(IEM_OP_ATAN, B.div(Cn(1), x))); if (need) { int u = B.div(Cn(1), B.add(Cn(1), B.mul(x, x))); d = B.mul(Cn(-kR2D), u); h = B.mul(B.mul(B.mul(Cn(kR2D * 2.0), x), u), u); } break; }
+        case IEM_OP_SINH: f = B.un(IEM_OP_SINH, x); if (need) { d = B.un(IEM_OP_COSH, x); h = f; } break;
+        case IEM_OP_COSH: f = B.un(IEM_OP_COSH, x); if (need) { d = B.un(IEM_OP_SINH, x); h = f; } break;
+        case IEM_OP_TANH: { f = B.un(IEM_OP_TANH, x); if (need) { int u = B.sub(Cn(1), B.mul(f, f)); d = u; h = B.mul(B.mul(Cn(-2), f), u); } break; }
+        case IEM_OP_CSCH: { int s = B.div(Cn(1), B.un(IEM_OP_SINH, x)); f = s; if (need) { int tt = B.mul(B.un(IEM_OP_COSH, x), s); d = B.mul(B.neg(s), tt); h = B.mul(s, B.add(B.mul(tt, tt), B.mul(s, s))); } break; }
+        case IEM_OP_SECH: { int c = B.div(Cn(1), B.un(IEM_OP_COSH, x)); f = c; if (need) { int tt = B.un(IEM_OP_TANH, x); d = B.mul(B.neg(c), tt); h = B.mul(c, B.sub(B.mul(tt, tt), B.mul(c, c))); } break; }
+        case IEM_OP_COTH: { int tt = B.div(Cn(1), B.un(IEM_OP_TANH, x)); f = tt; if (need) { int u = B.sub(Cn(1), B.mul(tt, tt)); d = u; h = B.mul(B.mul(Cn(-2), tt), u); } break; }
+        case IEM_OP_ATANH: { f = B.un(IEM_OP_ATANH, x); if (need) { int u = B.div(Cn(1), B.sub(Cn(1), B.mul(x, x))); d = u; h = B.mul(B.mul(B.mul(Cn(2), x), u), u); } break; }
+        case IEM_OP_ACOTH: { f = B.un(IEM_OP_ATANH, B.div(Cn(1), x)); if (need) { int u = B.div(Cn(1), B.sub(Cn(1), B.mul(x, x))); d = u; h = B.mul(B.mul(B.mul(Cn(2), x), u), u); } break; }
+        default: throw std::runtime_error("codegen: unsupported unary opcode " + std::to_string(nd.op));
+      }
+      val[n] = f;
+      if (need) { y1[n] = d; h11[n] = h; }
+    }
+    void binary(int n, int order) {
+      const Node &nd = t.nodes[n];
+      KernelBuilder &B = K;
+      int a = val[nd.a], b = val[nd.b];
+      auto Cn = [&](double v) { return B.C(v); };
+      switch (nd.op) {
+        case IEM_OP_ADD: val[n] = B.add(a, b); break;
+        case IEM_OP_SUB: val[n] = B.sub(a, b); break;
+        case IEM_OP_MUL: val[n] = B.mul(a, b); break;
+        case IEM_OP_DIV: val[n] = B.div(a, b); break;
+        case IEM_OP_POW: val[n] = B.powv(a, b); break;
+        default: throw std::runtime_error("codegen: unsupported binary opcode");
+      }
+      if (order < 1 || nd.kind == K_REAL) return;
+      int p1 = Cn(0), p2 = Cn(0), q11 = Cn(0), q12 = Cn(0), q22 = Cn(0);
+      int need = nd.fixed;
+      switch (nd.op) {
+        case IEM_OP_ADD: p1 = Cn(1); p2 = Cn(1); break;
+        case IEM_OP_SUB: p1 = Cn(1); p2 = Cn(-1); break;
+        case IEM_OP_MUL: p1 = b; p2 = a; q12 = Cn(1); break;
+        case IEM_OP_DIV: {
+          int ib = B.div(Cn(1), b);
+          p1 = ib;
+          if (need != FX_SECOND) {
+            p2 = B.mul(B.mul(B.neg(a), ib), ib);
+            q22 = B.mul(B.mul(B.mul(B.mul(Cn(2), a), ib), ib), ib);
+          }
+          if (need == FX_NONE) q12 = B.neg(B.mul(ib, ib));
+          break;
+        }
+        case IEM_OP_POW: {
+          if (need != FX_FIRST) {
+            p1 = B.mul(b, B.powv(a, B.sub(b, Cn(1))));
+            q11 = B.mul(B.mul(b, B.sub(b, Cn(1))), B.powv(a, B.sub(b, Cn(2))));
+          }
+          if (need != FX_SECOND) {
+            int la = B.un(IEM_OP_LOG, a), p = val[n];
+            p2 = B.mul(p, la);
+            q22 = B.mul(B.mul(p, la), la);
+            if (need == FX_NONE) q12 = B.mul(B.powv(a, B.sub(b, Cn(1))), B.add(Cn(1), B.mul(b, la)));
+          }
+          break;
+        }
+      }
+      if (nd.fixed == FX_FIRST) { y1[n] = p2; h11[n] = q22; }
+      else if (nd.fixed == FX_SECOND) { y1[n] = p1; h11[n] = q11; }
+      else { y1[n] = p1; y2[n] = p2; h11[n] = q11; h12[n] = q12; h22[n] = q22; }
+    }
+
+    // first-order reverse sweep → per-slot sums
+    std::vector<int> slots1;
+    int gr(int n, int cnt, int adj) {
+      const Node &nd = t.nodes[n];
+      switch (nd.kind) {
+        case K_VAR: {
+          int s = t.comp1[cnt];
+          slots1[s] = slots1[s] < 0 ? adj : K.add(slots1[s], adj);
+          return cnt + 1;
+        }
+        case K_N1: return gr(nd.inner, cnt, K.mul(adj, y1[n]));
+        case K_N2:
+          cnt = gr(nd.a, cnt, K.mul(adj, y1[n]));
+          return gr(nd.b, cnt, K.mul(adj, y2[n]));
+        default: return cnt;
+      }
+    }
+    // second-order
+    std::vector<int> slots2;
+    void acc2(int cnt, int v) {
+      int s = t.comp2[cnt];
+      slots2[s] = slots2[s] < 0 ? v : K.add(slots2[s], v);
+    }
+    int hd(int n1, int n2, int cnt, int adj) {
+      const Node &a = t.nodes[n1], &b = t.nodes[n2];
+      if (a.kind == K_REAL || b.kind == K_REAL) return cnt;
+      if (a.kind == K_VAR && b.kind == K_VAR) {
+        int two = K.mul(K.C(2.0), adj);
+        int ia = idx1(a.a), ib = idx1(b.a);
+        int v;
+        if (ia == ib) v = two;
+        else {
+          const IdxVal &A = K.idx_[ia], &Bv = K.idx_[ib];
+          bool never = A.ind.empty() && Bv.ind.empty() && A.aff.k[0] == Bv.aff.k[0] && A.aff.k[1] == Bv.aff.k[1] &&
+                       A.aff.k[2] == Bv.aff.k[2] && A.aff.c != Bv.aff.c;
+          v = never ? adj : K.mk(VSEL, K.sel_id(ia, ib), two, adj, -1, 0);
+        }
+        acc2(cnt, v);
+        return cnt + 1;
+      } else if (a.kind == K_N1 && b.kind == K_N1) {
+        return hd(a.inner, b.inner, cnt, K.mul(K.mul(adj, y1[n1]), y1[n2]));
+      } else if (a.kind == K_VAR && b.kind == K_N1) {
+        return hd(n1, b.inner, cnt, K.mul(adj, y1[n2]));
+      } else if (a.kind == K_N1 && b.kind == K_VAR) {
+        return hd(a.inner, n2, cnt, K.mul(adj, y1[n1]));
+      } else if (a.kind == K_N2 && b.kind == K_N2) {
+        cnt = hd(a.a, b.a, cnt, K.mul(K.mul(adj, y1[n1]), y1[n2]));
+        cnt = hd(a.a, b.b, cnt, K.mul(K.mul(adj, y1[n1]), y2[n2]));
+        cnt = hd(a.b, b.a, cnt, K.mul(K.mul(adj, y2[n1]), y1[n2]));
+        return hd(a.b, b.b, cnt, K.mul(K.mul(adj, y2[n1]), y2[n2]));
+      } else if (a.kind == K_N1 && b.kind == K_N2) {
+        cnt = hd(a.inner, b.a, cnt, K.mul(K.mul(adj, y1[n1]), y1[n2]));
+        return hd(a.inner, b.b, cnt, K.mul(K.mul(adj, y1[n1]), y2[n2]));
+      } else if (a.kind == K_N2 && b.kind == K_N1) {
+        cnt = hd(a.a, b.inner, cnt, K.mul(K.mul(adj, y1[n1]), y1[n2]));
+        return hd(a.b, b.inner, cnt, K.mul(K.mul(adj, y2[n1]), y1[n2]));
+      } else if (a.kind == K_VAR && b.kind == K_N2) {
+        cnt = hd(n1, b.a, cnt, K.mul(adj, y1[n2]));
+        return hd(n1, b.b, cnt, K.mul(adj, y2[n2]));
+      } else {
+        cnt = hd(a.a, n2, cnt, K.mul(adj, y1[n1]));
+        return hd(a.b, n2, cnt, K.mul(adj, y2[n1]));
+      }
+    }
+    int hr(int n, int cnt, int adj, int adj2) {
+      const Node &nd = t.nodes[n];
+      switch (nd.kind) {
+        case K_VAR: acc2(cnt, adj2); return cnt + 1;
+        case K_N1: {
+          int y = y1[n];
+          return hr(nd.inner, cnt, K.mul(adj, y), K.add(K.mul(adj2, K.mul(y, y)), K.mul(adj, h11[n])));
+        }
+        case K_N2: {
+          int ya = y1[n], yb = y2[n];
+          int adj2y1y2 = K.mul(K.mul(adj2, ya), yb);
+          int adjh12 = K.mul(adj, h12[n]);
+          cnt = hr(nd.a, cnt, K.mul(adj, ya), K.add(K.mul(adj2, K.mul(ya, ya)), K.mul(adj, h11[n])));
+          cnt = hr(nd.b, cnt, K.mul(adj, yb), K.add(K.mul(adj2, K.mul(yb, yb)), K.mul(adj, h22[n])));
+          return hd(nd.a, nd.b, cnt, K.add(adj2y1y2, adjh12));
+        }
+        default: return cnt;
+      }
+    }
+    int hr0(int n, int cnt, int adj, int adj2) {
+      const Node &nd = t.nodes[n];
+      if (nd.kind == K_VAR || nd.kind == K_REAL) return cnt;
+      if (is_linear_n1(nd)) {
+        int y = y1[n];
+        return hr0(nd.inner, cnt, K.mul(adj, y), K.mul(adj2, K.mul(y, y)));
+      }
+      if (nd.kind == K_N2 && (nd.op == IEM_OP_ADD || nd.op == IEM_OP_SUB)) {
+        cnt = hr0(nd.a, cnt, K.mul(adj, y1[n]), adj2);
+        return hr0(nd.b, cnt, K.mul(adj, y2[n]), adj2);
+      }
+      return hr(n, cnt, adj, adj2);
+    }
+  };
+
+  int sel_id(int ia, int ib) {
+    for (size_t i = 0; i < sels_.size(); ++i)
+      if (sels_[i].first == ia && sels_[i].second == ib) return (int)i;
+    sels_.emplace_back(ia, ib);
+    return (int)sels_.size() - 1;
+  }
+
+  // ---- build the kernel's outputs ---------------------------------------------
+  bool relevant(const Template &t) const {
+    switch (kind_) {
+      case KK_CONS: return t.kind == IEM_T_CON;
+      case KK_JAC: return t.kind == IEM_T_CON && t.o1step > 0;
+      case KK_HESS: return t.o2step > 0;
+      case KK_OBJ: return t.kind == IEM_T_OBJ;
+      case KK_GRAD: return t.kind == IEM_T_OBJ && t.o1step > 0;
+    }
+    return false;
+  }
+
+  bool build(const std::vector<std::pair<AffQ, std::pair<int64_t, int64_t>>> *grad_ranges) {
+    (void)grad_ranges;
+    std::vector<std::pair<int, bool>> order;
+    for (int ti : g_.tpls) order.emplace_back(ti, false);
+    for (int ti : g_.scalars) order.emplace_back(ti, true);
+    std::sort(order.begin(), order.end());
+    for (auto &pr : order) {
+      int ti = pr.first;
+      const Template &t = m_.tpl[ti];
+      if (!relevant(t)) continue;
+      TGeo G = geo(ti, pr.second);
+      TplGen tg(*this, ti, G);
+      Output o;
+      o.kind = kind_; o.tpl = ti; o.guard = G.guard; o.pos_idx = -1;
+      switch (kind_) {
+        case KK_CONS: {
+          tg.forward(0);
+          IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
+          o.pos_idx = idxval(iv);
+          o.vals = {tg.val[t.root]};
+          alg_w_ += t.n_items;
+          break;
+        }
+        case KK_OBJ:
+          tg.forward(0);
+          o.vals = {tg.val[t.root]};
+          break;
+        case KK_JAC:
+        case KK_GRAD: {
+          tg.forward(1);
+          tg.slots1.assign(t.o1step, -1);
+          tg.gr(t.root, 0, C(1.0));
+          o.vals = tg.slots1;
+          if (kind_ == KK_JAC) {
+            IdxVal iv; iv.aff = klin_aff(t, G, t.o1step, t.o1);
+            o.pos_idx = idxval(iv);
+            alg_w_ += t.n_items * t.o1step;
+          } else {
+            for (int s = 0; s < t.o1step; ++s) {
+              int id = tg.pos0(t.slot1_idx[s]);
+              o.grad_idx.push_back(id);
+              o.grad_mode.push_back(2);
+              alg_w_ += t.n_items;
+            }
+          }
+          break;
+        }
+        case KK_HESS: {
+          tg.forward(2);
+          tg.slots2.assign(t.o2step, -1);
+          int adj;
+          if (t.kind == IEM_T_OBJ) adj = mk(VW, 0, -1, -1, -1, 0);
+          else {
+            IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
+            adj = load(2, 0, idxval(iv), G.guard);
+          }
+          tg.hr0(t.root, 0, adj, C(0.0));
+          o.vals = tg.slots2;
+          IdxVal iv; iv.aff = klin_aff(t, G, t.o2step, t.o2);
+          o.pos_idx = idxval(iv);
+          alg_w_ += t.n_items * t.o2step;
+          break;
+        }
+      }
+      for (int &v : o.vals) if (v < 0) v = C(0.0);
+      outs_.push_back(std::move(o));
+    }
+    return !outs_.empty();
+  }
+
+  // gradient store classification (needs every objective slot of the model)
+  std::vector<Output> &outputs() { return outs_; }
+  const std::vector<IdxVal> &idxvals() const { return idx_; }
+
+  // ---- emission -----------------------------------------------------------------
+  std::string aff_str(const AffQ &a) {
+    std::ostringstream os;
+    bool any = false;
+    if (a.c != 0) { os << ip(a.c); any = true; }
+    for (int d = 0; d < 3; ++d) {
+      if (a.k[d] == 0) continue;
+      if (any) os << " + ";
+      if (a.k[d] == 1) os << "q" << d;
+      else os << coefstr(a.k[d]) << " * q" << d;
+      any = true;
+    }
+    if (!any) os << "0LL";
+    return os.str();
+  }
+
+  std::string guard_or(const std::set<int> &gs) {
+    // weakest guard: plain `inb` subsumes every non-scalar guard
+    int inb_id = -1;
+    auto it = guard_ids_.find("inb");
+    if (it != guard_ids_.end()) inb_id = it->second;
+    if (inb_id >= 0 && gs.count(inb_id)) return "g" + std::to_string(inb_id);
+    std::ostringstream os;
+    bool first = true;
+    for (int g : gs) { os << (first ? "" : " || ") << "g" << g; first = false; }
+    return gs.size() > 1 ? "(" + os.str() + ")" : os.str();
+  }
+
+  void emit_val(int id, std::ostringstream &os, std::vector<char> &done, const std::vector<char> &live) {
+    if (done[id]) return;
+    const VNode &n = v_[id];
+    // iterative post-order
+    std::vector<std::pair<int, int>> st;
+    st.emplace_back(id, 0);
+    while (!st.empty()) {
+      int cur = st.back().first;
+      int &phase = st.back().second;
+      if (done[cur]) { st.pop_back(); continue; }
+      const VNode &c = v_[cur];
+      if (phase == 0) {
+        phase = 1;
+        if (c.op == VUN) { if (!done[c.a]) st.emplace_back(c.a, 0); }
+        else if (c.op == VBIN) { if (!done[c.b]) st.emplace_back(c.b, 0); if (!done[c.a]) st.emplace_back(c.a, 0); }
+        else if (c.op == VSEL) { if (!done[c.b]) st.emplace_back(c.b, 0); if (!done[c.a]) st.emplace_back(c.a, 0); }
+        continue;
+      }
+      emit_one(cur, os, done, live);
+      st.pop_back();
+    }
+    (void)n;
+  }
+
+  static const char *fn_name(int op) {
+    switch (op) {
+      case IEM_OP_SQRT: return "sqrt"; case IEM_OP_CBRT: return "cbrt"; case IEM_OP_ABS: return "fabs";
+      case IEM_OP_EXP: return "exp"; case IEM_OP_EXP2: return "exp2"; case IEM_OP_LOG: return "log";
+      case IEM_OP_LOG2: return "log2"; case IEM_OP_LOG10: return "log10"; case IEM_OP_LOG1P: return "log1p";
+      case IEM_OP_SIN: return "sin"; case IEM_OP_COS: return "cos"; case IEM_OP_TAN: return "tan";
+      case IEM_OP_ASIN: return "asin"; case IEM_OP_ACOS: return "acos"; case IEM_OP_ATAN: return "atan";
+      case IEM_OP_SINH: return "sinh"; case IEM_OP_COSH: return "cosh"; case IEM_OP_TANH: return "tanh";
+      case IEM_OP_ATANH: return "atanh";
+    }
+    return nullptr;
+  }
+
+  void emit_one(int id, std::ostringstream &os, std::vector<char> &done, const std::vector<char> &live) {
+    const VNode &n = v_[id];
+    std::string nm = "v" + std::to_string(id);
+    switch (n.op) {
+      case VC: os << "  const double " << nm << " = " << hexf(n.imm) << ";\n"; break;
+      case VDP: os << "  const double " << nm << " = A.dp[" << n.sub << "];\n"; break;
+      case VW: os << "  const double " << nm << " = A.w;\n"; break;
+      case VLD: os << "  const double " << nm << " = l" << n.sub << ";\n"; break;
+      case VSEL: {
+        const auto &pr = sels_[n.sub];
+        os << "  const double " << nm << " = (i" << pr.first << " == i" << pr.second << ") ? v" << n.a << " : v" << n.b << ";\n";
+        break;
+      }
+      case VUN: {
+        if (n.sub == IEM_OP_NEG) { os << "  const double " << nm << " = -v" << n.a << ";\n"; break; }
+        if (n.sub == U_SGN) { os << "  const double " << nm << " = (v" << n.a << " >= 0.0) ? 1.0 : -1.0;\n"; break; }
+        if (n.sub == IEM_OP_SIN || n.sub == IEM_OP_COS) {
+          int other = n.sub == IEM_OP_SIN ? IEM_OP_COS : IEM_OP_SIN;
+          uint64_t zb = 0;
+          auto it = memo_.find(VKey{VUN, other, n.a, -1, -1, zb});
+          if (it != memo_.end() && live[it->second] && !done[it->second]) {
+            int oid = it->second;
+            std::string s = n.sub == IEM_OP_SIN ? nm : "v" + std::to_string(oid);
+            std::string c = n.sub == IEM_OP_SIN ? "v" + std::to_string(oid) : nm;
+            os << "  double " << s << ", " << c << "; sincos(v" << n.a << ", &" << s << ", &" << c << ");\n";
+            done[oid] = 1;
+            break;
+          }
+        }
+        const char *f = fn_name(n.sub);
+        if (!f) throw std::runtime_error("codegen: no device function for opcode " + std::to_string(n.sub));
+        os << "  const double " << nm << " = " << f << "(v" << n.a << ");\n";
+        break;
+      }
+      case VBIN: {
+        const char *o = n.sub == IEM_OP_ADD ? "+" : n.sub == IEM_OP_SUB ? "-" : n.sub == IEM_OP_MUL ? "*" : n.sub == IEM_OP_DIV ? "/" : nullptr;
+        if (o) os << "  const double " << nm << " = v" << n.a << " " << o << " v" << n.b << ";\n";
+        else os << "  const double " << nm << " = pow(v" << n.a << ", v" << n.b << ");\n";
+        break;
+      }
+    }
+    done[id] = 1;
+  }
+
+  void mark_live(int id, std::vector<char> &live) {
+    std::vector<int> st{id};
+    while (!st.empty()) {
+      int c = st.back(); st.pop_back();
+      if (live[c]) continue;
+      live[c] = 1;
+      const VNode &n = v_[c];
+      if (n.op == VUN) st.push_back(n.a);
+      else if (n.op == VBIN || n.op == VSEL) { st.push_back(n.a); st.push_back(n.b); }
+    }
+  }
+
+  std::string emit(KernelDesc &kd) {
+    std::ostringstream body;
+    std::vector<char> live(v_.size(), 0), done(v_.size(), 0);
+    for (auto &o : outs_) for (int v : o.vals) mark_live(v, live);
+    // which idx values must exist as variables: load positions (all), output positions, grad idx, sel operands
+    std::set<int> need_idx;
+    for (auto &l : loads_) need_idx.insert(l.idxval);
+    for (auto &o : outs_) { if (o.pos_idx >= 0) need_idx.insert(o.pos_idx); for (int g : o.grad_idx) need_idx.insert(g); }
+    for (auto &pr : sels_) { need_idx.insert(pr.first); need_idx.insert(pr.second); }
+
+    int max_ns = 1;
+    for (auto &o : outs_) if (kind_ == KK_JAC || kind_ == KK_HESS) max_ns = std::max<int>(max_ns, (int)o.vals.size());
+    bool use_lds = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 1;
+
+    // stores/outputs first into `tail` so that every ip() they need is registered before the struct is printed
+    std::ostringstream tail;
+    if (kind_ == KK_OBJ) tail << "  double acc = 0.0;\n";
+    for (auto &o : outs_) {
+      const Template &t = m_.tpl[o.tpl];
+      tail << "  // template " << o.tpl << " (" << (t.kind == IEM_T_OBJ ? "objective" : "constraint") << ", " << o.vals.size() << " value(s))\n";
+      for (int v : o.vals) emit_val(v, tail, done, live);
+      std::string g = "g" + std::to_string(o.guard);
+      switch (kind_) {
+        case KK_CONS:
+          tail << "  if (" << g << ") OUT[i" << o.pos_idx << "] = v" << o.vals[0] << ";\n";
+          break;
+        case KK_OBJ:
+          tail << "  acc += " << g << " ? v" << o.vals[0] << " : 0.0;\n";
+          break;
+        case KK_JAC:
+        case KK_HESS: {
+          int ns = (int)o.vals.size();
+          bool scalar_tpl = std::find(g_.scalars.begin(), g_.scalars.end(), o.tpl) != g_.scalars.end();
+          tail << "  { const double r[" << ns << "] = {";
+          for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
+          tail << "};\n";
+          if (use_lds && !scalar_tpl) tail << "    iem_store_rows<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r, lds_wave); }\n";
+          else tail << "    iem_store_rows_direct<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r); }\n";
+          break;
+        }
+        case KK_GRAD:
+          for (size_t s = 0; s < o.vals.size(); ++s) {
+            int mode = o.grad_mode[s];
+            if (mode == 0) tail << "  if (" << g << ") OUT[i" << o.grad_idx[s] << "] = v" << o.vals[s] << ";\n";
+            else if (mode == 1) tail << "  iem_grad_wave_uniform(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
+            else tail << "  iem_grad_atomic(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
+          }
+          break;
+      }
+    }
+    if (kind_ == KK_OBJ)
+      tail << "  iem_block_partial(acc, OUT, A.ip[" << ip_index(kd.partial_off) << "] + (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * (long long)blockIdx.z), lds4);\n";
+
+    // head: coordinates, guards, integer loads, index values, loads
+    std::ostringstream head;
+    head << "  const long long q0 = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;\n";
+    head << "  const long long q1 = blockIdx.y, q2 = blockIdx.z;\n";
+    head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+    for (size_t gi = 0; gi < guards_.size(); ++gi) head << "  const bool g" << gi << " = " << guards_[gi] << ";\n";
+    for (size_t i = 0; i < iloads_.size(); ++i) {
+      head << "  const long long il" << i << " = " << guard_or(iloads_[i].guards) << " ? IA" << "[" << iloads_[i].ia_slot << "]["
+           << aff_str(iloads_[i].pos) << "] : 0LL;\n";
+    }
+    for (int id : need_idx) {
+      const IdxVal &iv = idx_[id];
+      head << "  const long long i" << id << " = " << aff_str(iv.aff);
+      for (auto &pr : iv.ind) head << " + " << coefstr(pr.first) << " * il" << pr.second;
+      head << ";\n";
+    }
+    for (size_t i = 0; i < loads_.size(); ++i) {
+      const Load &l = loads_[i];
+      bool used = false;
+      for (size_t v = 0; v < v_.size(); ++v) if (v_[v].op == VLD && v_[v].sub == (int)i && live[v]) { used = true; break; }
+      if (!used) continue;
+      std::string arr = l.arr == 0 ? "X" : l.arr == 1 ? "TH" : l.arr == 2 ? "Y" : "FA[" + std::to_string(l.slot) + "]";
+      head << "  const double l" << i << " = " << guard_or(l.guards) << " ? " << arr << "[i" << l.idxval << "] : 0.0;\n";
+      alg_r_loads_++;
+      // algorithmic read footprint: index range of this load over the launch domain
+      const IdxVal &iv = idx_[l.idxval];
+      int64_t lo = iv.aff.c, hi = iv.aff.c;
+      for (int d = 0; d < 3; ++d) {
+        int64_t e = iv.aff.k[d] * (g_.ext[d] - 1);
+        if (e < 0) lo += e; else hi += e;
+      }
+      if (!iv.ind.empty()) { lo = 0; hi = g_.ext[0] * g_.ext[1] * g_.ext[2] - 1; }
+      int akey = l.arr == 3 ? 100 + l.slot : l.arr;
+      ranges_[akey].emplace_back(lo, hi);
+    }
+    {
+      int64_t elems = 0;
+      for (auto &kv : ranges_) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end());
+        int64_t cur_lo = v[0].first, cur_hi = v[0].second;
+        for (size_t i = 1; i < v.size(); ++i) {
+          if (v[i].first <= cur_hi + 1) cur_hi = std::max(cur_hi, v[i].second);
+          else { elems += cur_hi - cur_lo + 1; cur_lo = v[i].first; cur_hi = v[i].second; }
+        }
+        elems += cur_hi - cur_lo + 1;
+      }
+      kd.alg_bytes_read = 8 * (elems + (int64_t)iloads_.size() * g_.ext[0] * g_.ext[1] * g_.ext[2]);
+      kd.alg_bytes_written = 8 * alg_w_;
+      if (kind_ == KK_OBJ) kd.alg_bytes_written = 8 * kd.n_blocks;
+    }
+
+    // assemble
+    std::ostringstream os;
+    size_t nip = std::max<size_t>(1, ipv_.size()), ndp = std::max<size_t>(1, dpv_.size());
+    size_t nfa = std::max<size_t>(1, fav_.size()), nia = std::max<size_t>(1, iav_.size());
+    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; double* out; double w;\n"
+       << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
+    os << "extern \"C\" __global__ __launch_bounds__(IEM_BLOCK) void " << name_ << "(const Args_" << name_ << " A) {\n";
+    os << "  const double* __restrict__ X = A.x; const double* __restrict__ TH = A.th; const double* __restrict__ Y = A.y;\n";
+    os << "  double* __restrict__ OUT = A.out;\n";
+    os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
+    os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
+    if (use_lds) {
+      os << "  __shared__ double lds_all[" << (IEM_BLOCK_WAVES * 64 * max_ns) << "];\n";
+      os << "  double* lds_wave = lds_all + iem_wave() * " << (64 * max_ns) << ";\n";
+      kd.lds_bytes = IEM_BLOCK_WAVES * 64 * max_ns * 8;
+    }
+    if (kind_ == KK_OBJ) os << "  __shared__ double lds4[4];\n";
+    os << head.str() << tail.str() << "}\n\n";
+    kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
+    return os.str();
+  }
+
+  int ip_index(int64_t v) {
+    ip(v);
+    return ip_ids_[v];
+  }
+
+  static constexpr int IEM_BLOCK_WAVES = 4;
+
+  const Model &m_;
+  const Group &g_;
+  int kind_;
+  Options opt_;
+  std::string name_;
+  std::vector<VNode> v_;
+  std::map<VKey, int> memo_;
+  std::vector<IdxVal> idx_;
+  std::map<IdxVal, int> idx_ids_;
+  std::vector<ILoad> iloads_;
+  std::vector<Load> loads_;
+  std::map<std::tuple<int, int, int>, int> load_ids_;
+  std::vector<std::pair<int, int>> sels_;
+  std::vector<std::string> guards_;
+  std::map<std::string, int> guard_ids_;
+  std::vector<Output> outs_;
+  std::map<int64_t, int> ip_ids_;
+  std::vector<int64_t> ipv_;
+  std::map<uint64_t, int> dp_ids_;
+  std::vector<double> dpv_;
+  std::map<int, int> fa_ids_, ia_ids_;
+  std::vector<int> fav_, iav_;
+  int64_t alg_w_ = 0, alg_r_loads_ = 0;
+  std::map<int, std::vector<std::pair<int64_t, int64_t>>> ranges_;
+};
+
+// ---------------------------------------------------------------------------
+// grouping + validation
+// ---------------------------------------------------------------------------
+std::vector<Group> make_groups(const Model &m) {
+  std::vector<Group> groups;
+  std::map<std::pair<int64_t, int>, int> by_key;
+  std::vector<int> scalars;
+  for (size_t ti = 0; ti < m.tpl.size(); ++ti) {
+    const Template &t = m.tpl[ti];
+    if (t.grid_id == 0 || (t.n_items == 1 && t.ifields.empty() && t.ffields.empty())) {
+      scalars.push_back((int)ti);
+      continue;
+    }
+    int gi;
+    if (t.grid_id > 0) {
+      auto key = std::make_pair(t.grid_id, t.nd);
+      auto it = by_key.find(key);
+      if (it == by_key.end()) {
+        gi = (int)groups.size();
+        groups.emplace_back();
+        groups[gi].grid_id = t.grid_id;
+        groups[gi].nd = t.nd;
+        for (int d = 0; d < 3; ++d) { groups[gi].lo[d] = d < t.nd ? t.origin[d] : 0; groups[gi].ext[d] = d < t.nd ? t.origin[d] + t.dims[d] : 1; }
+        by_key.emplace(key, gi);
+      } else {
+        gi = it->second;
+        for (int d = 0; d < t.nd; ++d) {
+          groups[gi].lo[d] = std::min(groups[gi].lo[d], t.origin[d]);
+          groups[gi].ext[d] = std::max(groups[gi].ext[d], t.origin[d] + t.dims[d]);  // hi for now
+        }
+      }
+    } else {
+      gi = (int)groups.size();
+      groups.emplace_back();
+      groups[gi].grid_id = -1 - (int64_t)ti;
+      groups[gi].nd = t.nd;
+      for (int d = 0; d < 3; ++d) { groups[gi].lo[d] = 0; groups[gi].ext[d] = d < t.nd ? t.dims[d] : 1; }
+    }
+    groups[gi].tpls.push_back((int)ti);
+  }
+  for (auto &g : groups)
+    if (g.grid_id > 0)
+      for (int d = 0; d < g.nd; ++d) g.ext[d] -= g.lo[d];  // hi -> extent
+  if (!scalars.empty()) {
+    if (groups.empty()) {
+      groups.emplace_back();
+      groups[0].grid_id = 0;
+    }
+    size_t best = 0;
+    int64_t vol = -1;
+    for (size_t i = 0; i < groups.size(); ++i) {
+      int64_t v = groups[i].ext[0] * groups[i].ext[1] * groups[i].ext[2];
+      if (v > vol) { vol = v; best = i; }
+    }
+    groups[best].scalars = scalars;
+  }
+  return groups;
+}
+
+// min / max of an index expression over the template's item box — host-side safety check
+void validate_indices(const Model &m) {
+  for (size_t ti = 0; ti < m.tpl.size(); ++ti) {
+    const Template &t = m.tpl[ti];
+    std::vector<std::pair<int64_t, int64_t>> frange(t.ifields.size());
+    for (size_t f = 0; f < t.ifields.size(); ++f) {
+      const FieldDesc &fd = t.ifields[f];
+      if (fd.mode == IEM_F_AFFINE) {
+        int64_t lo = fd.base, hi = fd.base;
+        for (int d = 0; d < 3; ++d) {
+          int64_t e = fd.step[d] * (t.dims[d] - 1);
+          if (e < 0) lo += e; else hi += e;
+        }
+        frange[f] = {lo, hi};
+      } else {
+        const ArrayDesc &a = m.arrs[fd.arr];
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int64_t j = 0; j < a.n; ++j) { int64_t v = a.i(j); lo = std::min(lo, v); hi = std::max(hi, v); }
+        frange[f] = {lo, hi};
+      }
+    }
+    std::vector<std::pair<int64_t, int64_t>> irange(t.idx.size());
+    for (size_t i = 0; i < t.idx.size(); ++i) {
+      const IdxExpr &ix = t.idx[i];
+      int64_t lo = ix.c0, hi = ix.c0;
+      // affine terms over the same box are correlated; evaluate the box corners exactly when all affine
+      bool all_aff = true;
+      for (int j = 0; j < ix.nterms; ++j) if (t.ifields[ix.field[j]].mode != IEM_F_AFFINE) all_aff = false;
+      if (all_aff) {
+        int64_t c = ix.c0, k[3] = {0, 0, 0};
+        for (int j = 0; j < ix.nterms; ++j) {
+          const FieldDesc &fd = t.ifields[ix.field[j]];
+          c += ix.coef[j] * fd.base;
+          for (int d = 0; d < 3; ++d) k[d] += ix.coef[j] * fd.step[d];
+        }
+        lo = hi = c;
+        for (int d = 0; d < 3; ++d) {
+          int64_t e = k[d] * (t.dims[d] - 1);
+          if (e < 0) lo += e; else hi += e;
+        }
+      } else {
+        for (int j = 0; j < ix.nterms; ++j) {
+          int64_t a = ix.coef[j] * frange[ix.field[j]].first, b = ix.coef[j] * frange[ix.field[j]].second;
+          lo += std::min(a, b); hi += std::max(a, b);
+        }
+      }
+      irange[i] = {lo, hi};
+    }
+    for (const Node &nd : t.nodes) {
+      if (nd.op != IEM_OP_VAR && nd.op != IEM_OP_PAR) continue;
+      int64_t lim = nd.op == IEM_OP_VAR ? m.nvar : m.npar;
+      if (irange[nd.a].first < 1 || irange[nd.a].second > lim)
+        throw std::runtime_error("template " + std::to_string(ti) + ": " + (nd.op == IEM_OP_VAR ? "variable" : "parameter") +
+                                 " index range [" + std::to_string(irange[nd.a].first) + ", " + std::to_string(irange[nd.a].second) +
+                                 "] outside 1:" + std::to_string(lim));
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+Program generate(const Model &m, const Options &opt) {
+  validate_indices(m);
+  Program P;
+  std::vector<Group> groups = make_groups(m);
+  std::ostringstream src;
+  src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";
+  static const char *kname[] = {"cons", "jac", "hess", "obj", "grad"};
+
+  // gradient slot classification needs a global view of every objective slot's index range
+  struct GSlot { int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; };
+  std::vector<GSlot> gslots;
+  std::vector<std::unique_ptr<KernelBuilder>> builders;
+  std::vector<KernelDesc> descs;
+
+  int64_t partial_off = 0;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const Group &g = groups[gi];
+    if (g.ext[1] > 65535 || g.ext[2] > 65535) throw std::runtime_error("support grid too large in dims 2/3 (limit 65535)");
+    for (int kind = 0; kind < 5; ++kind) {
+      std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
+      auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
+      if (!kb->build(nullptr)) continue;
+      KernelDesc kd;
+      kd.name = name;
+      kd.kind = kind;
+      kd.grid[0] = (g.ext[0] + 255) / 256; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
+      kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
+      if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
+      if (kind == KK_GRAD) {
+        auto &outs = kb->outputs();
+        for (size_t oi = 0; oi < outs.size(); ++oi) {
+          const Template &t = m.tpl[outs[oi].tpl];
+          bool scalar = std::find(g.scalars.begin(), g.scalars.end(), outs[oi].tpl) != g.scalars.end();
+          for (size_t s = 0; s < outs[oi].grad_idx.size(); ++s) {
+            const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
+            GSlot gs{(int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
+            if (gs.pure) {
+              int64_t lo = iv.aff.c, hi = iv.aff.c;
+              // q range of this template: q_d in [origin-lo, origin-lo+dims)
+              bool inj = true;
+              int64_t reach = 0;  // largest offset reachable through the lower dims
+              for (int d = 0; d < 3; ++d) {
+                int64_t n = scalar ? 1 : (d < t.nd ? t.dims[d] : 1);
+                int64_t q_lo = scalar ? 0 : (d < t.nd ? t.origin[d] - g.lo[d] : 0);
+                int64_t a = iv.aff.k[d] * q_lo, b = iv.aff.k[d] * (q_lo + n - 1);
+                lo += std::min(a, b); hi += std::max(a, b);
+                if (n > 1) {
+                  if (iv.aff.k[d] <= reach) inj = false;
+                  reach += iv.aff.k[d] * (n - 1);
+                }
+              }
+              gs.lo = lo; gs.hi = hi; gs.injective = inj;
+              gs.uniform0 = !scalar && iv.aff.k[0] == 0 && t.dims[0] > 1;
+            } else {
+              gs.lo = INT64_MIN; gs.hi = INT64_MAX;
+            }
+            gslots.push_back(gs);
+          }
+        }
+      }
+      builders.push_back(std::move(kb));
+      descs.push_back(kd);
+    }
+  }
+  // classify gradient slots: exclusive iff injective and its range meets no other slot's range
+  for (size_t i = 0; i < gslots.size(); ++i) {
+    GSlot &a = gslots[i];
+    int mode = 2;
+    if (a.pure && a.injective) {
+      bool clash = false;
+      for (size_t j = 0; j < gslots.size() && !clash; ++j) {
+        if (i == j) continue;
+        const GSlot &b = gslots[j];
+        if (!(b.hi < a.lo || b.lo > a.hi)) clash = true;
+      }
+      if (!clash) mode = 0;
+    }
+    if (mode == 2 && a.pure && a.uniform0) mode = 1;
+    builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;
+  }
+  for (size_t k = 0; k < builders.size(); ++k) {
+    src << builders[k]->emit(descs[k]);
+    P.kernels.push_back(descs[k]);
+  }
+  P.n_partials = partial_off;
+  P.source = src.str();
+  P.key = fnv1a64(P.source + (opt.store_mode ? "|lds" : "|direct"));
+  return P;
+}
+
+}  // namespace iem

@@ -1,0 +1,43 @@
+// iem_codegen.hpp — model → fused HIP kernels (source + launch descriptors).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "iem_model.hpp"
+
+namespace iem {
+
+enum KernelKind { KK_CONS = 0, KK_JAC = 1, KK_HESS = 2, KK_OBJ = 3, KK_GRAD = 4 };
+
+struct KernelDesc {
+  std::string name;
+  int kind = 0;
+  int64_t grid[3] = {1, 1, 1};  // workgroups
+  // argument block, in this order after the fixed head {x, th, y, out, w}:
+  std::vector<int64_t> ip;  // long long ip[]
+  std::vector<double> dp;   // double dp[]
+  std::vector<int> fa;      // const double* fa[]  (model array ids, uploaded as f64)
+  std::vector<int> ia;      // const long long* ia[] (model array ids, uploaded as i64)
+  int lds_bytes = 0;
+  int64_t partial_off = 0;  // KK_OBJ: first partial slot written by this kernel
+  int64_t n_blocks = 1;
+  // bookkeeping for the roofline line
+  int64_t alg_bytes_read = 0, alg_bytes_written = 0;
+};
+
+struct Options {
+  int store_mode = 1;  // 0 direct strided stores, 1 LDS-transposed coalesced stores
+};
+
+struct Program {
+  std::string source;
+  uint64_t key = 0;
+  std::vector<KernelDesc> kernels;
+  int64_t n_partials = 0;
+};
+
+Program generate(const Model &m, const Options &opt);
+uint64_t fnv1a64(const std::string &s);
+
+}  // namespace iem

@@ -1,0 +1,293 @@
+// iem_model.hpp — parsed form of a transcribed model (include/iem_blob.h) plus the
+// per-template slot analysis the kernels are generated from.
+//
+// A template corresponds to one ExaModels SIMDFunction created by an add_con/add_obj
+// call of /root/reference/src/transform.jl (:458,559,597,614,700,741).  The analysis
+// reproduces how ExaModels lays a template's derivatives out:
+//   * reals (constants, item data, θ) fold into "fixed" unary nodes,
+//   * Jacobian slots  = first-occurrence-unique variable index expressions met by a
+//     left-to-right depth-first walk                                    (o1step),
+//   * Hessian slots   = first-occurrence-unique ordered index pairs met by the
+//     second-order walk (top-level +,-,real-scaling pass through; below that every
+//     variable visit owns a diagonal slot, every binary node crosses its subtrees)
+//                                                                         (o2step),
+//   * offsets o0/o1/o2 are running counters in add_con/add_obj call order.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/iem_blob.h"
+
+namespace iem {
+
+enum NodeKind { K_REAL = 0, K_VAR = 1, K_N1 = 2, K_N2 = 3 };
+enum Fixed { FX_NONE = 0, FX_FIRST = 1, FX_SECOND = 2 };
+
+struct Node {
+  int op = 0, a = 0, b = 0;
+  double imm = 0.0;
+  int kind = K_REAL, fixed = FX_NONE, inner = -1;
+};
+
+struct FieldDesc {
+  int mode = 0;
+  int64_t base = 0, step[3] = {0, 0, 0};
+  int arr = -1;
+};
+
+struct IdxExpr {
+  int64_t c0 = 0;
+  int nterms = 0;
+  int field[IEM_MAX_IDX_TERMS] = {0, 0, 0};
+  int64_t coef[IEM_MAX_IDX_TERMS] = {0, 0, 0};
+};
+
+struct ArrayDesc {
+  int kind = 0;
+  int64_t n = 0;
+  const void *data = nullptr;  // into the owned blob copy
+  double fill = 0.0;
+  int64_t r0 = 0, rstep = 0;
+  double f(int64_t j) const {
+    switch (kind) {
+      case IEM_A_F64_DATA: return static_cast<const double *>(data)[j];
+      case IEM_A_I64_DATA: return (double)static_cast<const int64_t *>(data)[j];
+      case IEM_A_F64_FILL: return fill;
+      default: return (double)(r0 + rstep * j);
+    }
+  }
+  int64_t i(int64_t j) const {
+    switch (kind) {
+      case IEM_A_I64_DATA: return static_cast<const int64_t *>(data)[j];
+      case IEM_A_I64_RANGE: return r0 + rstep * j;
+      case IEM_A_F64_DATA: return (int64_t) static_cast<const double *>(data)[j];
+      default: return (int64_t)fill;
+    }
+  }
+};
+
+struct Template {
+  int kind = 0, nd = 1;
+  int64_t n_items = 0, dims[3] = {1, 1, 1};
+  int64_t grid_id = -1, origin[3] = {0, 0, 0};
+  int root = 0;
+  std::vector<FieldDesc> ifields, ffields;
+  std::vector<IdxExpr> idx;
+  std::vector<Node> nodes;
+  int lmode = 0, umode = 0, larr = -1, uarr = -1;
+  double lval = 0, uval = 0;
+  // layout
+  int64_t o0 = 0, o1 = 0, o2 = 0;
+  int o1step = 0, o2step = 0;
+  std::vector<int> comp1, comp2;          // visit -> slot
+  std::vector<int> slot1_idx;             // slot -> idx id
+  std::vector<int> slot2_i, slot2_j;      // slot -> idx ids (unswapped)
+};
+
+struct Model {
+  std::vector<int64_t> blob;  // owned copy
+  int64_t nvar = 0, npar = 0, ncon = 0, nnzj = 0, nnzh = 0;
+  int minimize = 1;
+  int arr_x0 = 0, arr_lvar = 0, arr_uvar = 0, arr_theta = 0;
+  std::vector<ArrayDesc> arrs;
+  std::vector<Template> tpl;
+};
+
+inline double w2d(int64_t w) {
+  double d;
+  std::memcpy(&d, &w, 8);
+  return d;
+}
+
+inline bool is_linear_n1(const Node &nd) {
+  if (nd.kind != K_N1) return false;
+  if (nd.fixed != FX_NONE) return nd.op == IEM_OP_MUL || nd.op == IEM_OP_ADD || nd.op == IEM_OP_SUB;
+  return nd.op == IEM_OP_NEG || nd.op == IEM_OP_POS;
+}
+
+// ---- symbolic walks (visit sequences) ---------------------------------------
+struct SymWalk {
+  const Template &t;
+  std::vector<int> v1, vi, vj;
+  explicit SymWalk(const Template &tt) : t(tt) {}
+  void gr(int n) {
+    const Node &nd = t.nodes[n];
+    if (nd.kind == K_VAR) v1.push_back(nd.a);
+    else if (nd.kind == K_N1) gr(nd.inner);
+    else if (nd.kind == K_N2) { gr(nd.a); gr(nd.b); }
+  }
+  void hd(int n1, int n2) {
+    const Node &a = t.nodes[n1], &b = t.nodes[n2];
+    if (a.kind == K_REAL || b.kind == K_REAL) return;
+    if (a.kind == K_VAR && b.kind == K_VAR) { vi.push_back(a.a); vj.push_back(b.a); }
+    else if (a.kind == K_N1 && b.kind == K_N1) hd(a.inner, b.inner);
+    else if (a.kind == K_VAR && b.kind == K_N1) hd(n1, b.inner);
+    else if (a.kind == K_N1 && b.kind == K_VAR) hd(a.inner, n2);
+    else if (a.kind == K_N2 && b.kind == K_N2) { hd(a.a, b.a); hd(a.a, b.b); hd(a.b, b.a); hd(a.b, b.b); }
+    else if (a.kind == K_N1 && b.kind == K_N2) { hd(a.inner, b.a); hd(a.inner, b.b); }
+    else if (a.kind == K_N2 && b.kind == K_N1) { hd(a.a, b.inner); hd(a.b, b.inner); }
+    else if (a.kind == K_VAR && b.kind == K_N2) { hd(n1, b.a); hd(n1, b.b); }
+    else { hd(a.a, n2); hd(a.b, n2); }
+  }
+  void hr(int n) {
+    const Node &nd = t.nodes[n];
+    if (nd.kind == K_VAR) { vi.push_back(nd.a); vj.push_back(nd.a); }
+    else if (nd.kind == K_N1) hr(nd.inner);
+    else if (nd.kind == K_N2) { hr(nd.a); hr(nd.b); hd(nd.a, nd.b); }
+  }
+  void hr0(int n) {
+    const Node &nd = t.nodes[n];
+    if (nd.kind == K_VAR || nd.kind == K_REAL) return;
+    if (is_linear_n1(nd)) hr0(nd.inner);
+    else if (nd.kind == K_N2 && (nd.op == IEM_OP_ADD || nd.op == IEM_OP_SUB)) { hr0(nd.a); hr0(nd.b); }
+    else hr(n);
+  }
+};
+
+inline void analyse_template(Template &t) {
+  for (size_t n = 0; n < t.nodes.size(); ++n) {
+    Node &nd = t.nodes[n];
+    nd.fixed = FX_NONE;
+    nd.inner = -1;
+    if (nd.op == IEM_OP_VAR) nd.kind = K_VAR;
+    else if (nd.op <= IEM_OP_PAR) nd.kind = K_REAL;
+    else if (IEM_OP_IS_UNARY(nd.op)) {
+      nd.kind = t.nodes[nd.a].kind == K_REAL ? K_REAL : K_N1;
+      nd.inner = nd.a;
+    } else if (IEM_OP_IS_BINARY(nd.op)) {
+      int ka = t.nodes[nd.a].kind, kb = t.nodes[nd.b].kind;
+      if (ka == K_REAL && kb == K_REAL) nd.kind = K_REAL;
+      else if (ka == K_REAL) { nd.kind = K_N1; nd.fixed = FX_FIRST; nd.inner = nd.b; }
+      else if (kb == K_REAL) { nd.kind = K_N1; nd.fixed = FX_SECOND; nd.inner = nd.a; }
+      else nd.kind = K_N2;
+    } else {
+      throw std::runtime_error("unknown opcode " + std::to_string(nd.op));
+    }
+  }
+  SymWalk w(t);
+  w.gr(t.root);
+  w.hr0(t.root);
+  t.comp1.clear(); t.slot1_idx.clear();
+  for (int id : w.v1) {
+    int s = -1;
+    for (size_t j = 0; j < t.slot1_idx.size(); ++j)
+      if (t.slot1_idx[j] == id) { s = (int)j; break; }
+    if (s < 0) { s = (int)t.slot1_idx.size(); t.slot1_idx.push_back(id); }
+    t.comp1.push_back(s);
+  }
+  t.o1step = (int)t.slot1_idx.size();
+  t.comp2.clear(); t.slot2_i.clear(); t.slot2_j.clear();
+  for (size_t v = 0; v < w.vi.size(); ++v) {
+    int s = -1;
+    for (size_t j = 0; j < t.slot2_i.size(); ++j)
+      if (t.slot2_i[j] == w.vi[v] && t.slot2_j[j] == w.vj[v]) { s = (int)j; break; }
+    if (s < 0) { s = (int)t.slot2_i.size(); t.slot2_i.push_back(w.vi[v]); t.slot2_j.push_back(w.vj[v]); }
+    t.comp2.push_back(s);
+  }
+  t.o2step = (int)t.slot2_i.size();
+}
+
+inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
+  if (nbytes < 8 * IEM_HDR_WORDS || nbytes % 8) throw std::runtime_error("blob too small / not word aligned");
+  const int64_t *w0 = static_cast<const int64_t *>(blob);
+  if (w0[0] != IEM_BLOB_MAGIC) throw std::runtime_error("bad blob magic");
+  if (w0[1] != IEM_BLOB_VERSION) throw std::runtime_error("unsupported blob version");
+  if ((size_t)w0[8] * 8 != nbytes) throw std::runtime_error("blob length mismatch");
+  m.blob.assign(w0, w0 + nbytes / 8);
+  const int64_t *w = m.blob.data();
+  const int64_t total = w[8];
+  m.nvar = w[2]; m.npar = w[3]; m.ncon = w[4];
+  int64_t n_tpl = w[5], n_arr = w[6];
+  m.minimize = (int)w[7];
+  m.arr_x0 = (int)w[10]; m.arr_lvar = (int)w[11]; m.arr_uvar = (int)w[12]; m.arr_theta = (int)w[13];
+  if (IEM_HDR_WORDS + IEM_ARR_WORDS * n_arr + n_tpl > total) throw std::runtime_error("blob tables overrun");
+  m.arrs.resize(n_arr);
+  const int64_t *aw = w + IEM_HDR_WORDS;
+  for (int64_t i = 0; i < n_arr; ++i, aw += IEM_ARR_WORDS) {
+    ArrayDesc &a = m.arrs[i];
+    a.kind = (int)aw[0]; a.n = aw[1];
+    if (a.kind == IEM_A_F64_DATA || a.kind == IEM_A_I64_DATA) {
+      if (aw[2] < 0 || aw[2] + a.n > total) throw std::runtime_error("array payload out of range");
+      a.data = w + aw[2];
+    }
+    a.fill = w2d(aw[3]); a.r0 = aw[3]; a.rstep = aw[4];
+  }
+  auto chk_arr = [&](int id, int64_t need, const char *what) {
+    if (id < 0 || id >= (int)n_arr || m.arrs[id].n < need) throw std::runtime_error(std::string("bad array for ") + what);
+  };
+  chk_arr(m.arr_x0, m.nvar, "x0"); chk_arr(m.arr_lvar, m.nvar, "lvar");
+  chk_arr(m.arr_uvar, m.nvar, "uvar"); chk_arr(m.arr_theta, m.npar, "theta");
+  const int64_t *tw = w + IEM_HDR_WORDS + IEM_ARR_WORDS * n_arr;
+  m.tpl.resize(n_tpl);
+  int64_t o0 = 0, o1 = 0, o2 = 0;
+  for (int64_t i = 0; i < n_tpl; ++i) {
+    if (tw[i] < 0 || tw[i] + IEM_TPL_FIXED_WORDS > total) throw std::runtime_error("template offset out of range");
+    const int64_t *p = w + tw[i];
+    Template &t = m.tpl[i];
+    t.kind = (int)*p++; t.n_items = *p++; t.nd = (int)*p++;
+    for (int d = 0; d < 3; ++d) t.dims[d] = *p++;
+    t.grid_id = *p++;
+    for (int d = 0; d < 3; ++d) t.origin[d] = *p++;
+    int n_if = (int)*p++, n_ff = (int)*p++, n_idx = (int)*p++, n_nodes = (int)*p++;
+    t.root = (int)*p++;
+    t.lmode = (int)*p++; t.lval = w2d(*p++); t.larr = (int)*p++;
+    t.umode = (int)*p++; t.uval = w2d(*p++); t.uarr = (int)*p++;
+    if (t.nd < 1 || t.nd > 3 || t.n_items != t.dims[0] * t.dims[1] * t.dims[2] || t.n_items < 0)
+      throw std::runtime_error("bad template item box");
+    int64_t need = (int64_t)IEM_FIELD_WORDS * (n_if + n_ff) + (int64_t)IEM_IDX_WORDS * n_idx + (int64_t)IEM_NODE_WORDS * n_nodes;
+    if (n_if < 0 || n_ff < 0 || n_idx < 0 || n_nodes <= 0 || (p - w) + need > total)
+      throw std::runtime_error("template record overruns blob");
+    auto rd_field = [&](FieldDesc &f) {
+      f.mode = (int)*p++; f.base = *p++;
+      for (int d = 0; d < 3; ++d) f.step[d] = *p++;
+      f.arr = (int)*p++;
+      if (f.mode == IEM_F_GATHER) {
+        if (f.arr < 0 || f.arr >= (int)n_arr) throw std::runtime_error("field array id out of range");
+        int64_t lo = f.base, hi = f.base;
+        for (int d = 0; d < 3; ++d) {
+          int64_t e = f.step[d] * (t.dims[d] - 1);
+          if (e < 0) lo += e; else hi += e;
+        }
+        if (lo < 0 || hi >= m.arrs[f.arr].n) throw std::runtime_error("field gather out of array bounds");
+      }
+    };
+    t.ifields.resize(n_if); t.ffields.resize(n_ff);
+    for (auto &f : t.ifields) rd_field(f);
+    for (auto &f : t.ffields) rd_field(f);
+    t.idx.resize(n_idx);
+    for (auto &ix : t.idx) {
+      ix.c0 = *p++; ix.nterms = (int)*p++;
+      if (ix.nterms < 0 || ix.nterms > IEM_MAX_IDX_TERMS) throw std::runtime_error("bad index expression");
+      for (int j = 0; j < IEM_MAX_IDX_TERMS; ++j) {
+        ix.field[j] = (int)*p++; ix.coef[j] = *p++;
+        if (j < ix.nterms && (ix.field[j] < 0 || ix.field[j] >= n_if)) throw std::runtime_error("index field out of range");
+      }
+    }
+    t.nodes.resize(n_nodes);
+    for (int n = 0; n < n_nodes; ++n) {
+      Node &nd = t.nodes[n];
+      nd.op = (int)*p++; nd.a = (int)*p++; nd.b = (int)*p++; nd.imm = w2d(*p++);
+      bool bin = IEM_OP_IS_BINARY(nd.op), un = IEM_OP_IS_UNARY(nd.op);
+      if ((bin || un) && (nd.a < 0 || nd.a >= n)) throw std::runtime_error("node child out of order");
+      if (bin && (nd.b < 0 || nd.b >= n)) throw std::runtime_error("node child out of order");
+      if ((nd.op == IEM_OP_VAR || nd.op == IEM_OP_PAR) && (nd.a < 0 || nd.a >= n_idx)) throw std::runtime_error("node index id out of range");
+      if (nd.op == IEM_OP_DATA && (nd.a < 0 || nd.a >= n_ff)) throw std::runtime_error("node field id out of range");
+    }
+    if (t.root < 0 || t.root >= n_nodes) throw std::runtime_error("bad root");
+    analyse_template(t);
+    t.o2 = o2; o2 += t.n_items * t.o2step;
+    if (t.kind == IEM_T_CON) {
+      t.o0 = o0; o0 += t.n_items;
+      t.o1 = o1; o1 += t.n_items * t.o1step;
+    } else if (t.kind != IEM_T_OBJ) {
+      throw std::runtime_error("bad template kind");
+    }
+  }
+  if (o0 != m.ncon) throw std::runtime_error("ncon does not match the constraint templates");
+  m.nnzj = o1; m.nnzh = o2;
+}
+
+}  // namespace iem

@@ -1,0 +1,143 @@
+"""ctypes binding of ``libiem_hip.so`` (the C-ABI of ``include/iem.h``).
+
+The library is the product path: if it is missing this module raises — there is no
+Python/CPU fallback for evaluation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiem_hip.so")
+KERNEL_DIR = os.path.join(_HERE, "kernels")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+_lib = None
+
+
+class IemError(RuntimeError):
+    pass
+
+
+class Meta(C.Structure):
+    _fields_ = [("nvar", C.c_int64), ("ncon", C.c_int64), ("npar", C.c_int64), ("nnzj", C.c_int64),
+                ("nnzh", C.c_int64), ("n_templates", C.c_int64), ("minimize", C.c_int32),
+                ("n_kernels", C.c_int32)]
+
+
+class TemplateInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("kind", "n_items", "o0", "o1", "o2", "o1step", "o2step")]
+
+
+class KernelInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("kind", C.c_int32), ("jit", C.c_int32), ("grid", C.c_int64 * 3),
+                ("lds_bytes", C.c_int64), ("alg_bytes_read", C.c_int64), ("alg_bytes_written", C.c_int64)]
+
+
+# every symbol include/iem.h declares (tests check the export list against the header)
+SYMBOLS = ["iem_create", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
+           "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
+           "iem_jac_coord", "iem_hess_coord", "iem_jac_structure", "iem_hess_structure",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_emit_source", "iem_emit_launch_plan", "iem_free",
+           "iem_set_option", "iem_time_kernels", "iem_last_error", "iem_version"]
+
+
+def build_library(force: bool = False) -> str:
+    """Compile ``libiem_hip.so`` in-tree (host C++; links libamdhip64 + libhiprtc)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir)
+                 if f.endswith((".cpp", ".hpp", ".h")) and f != "iem_device_h.inc")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IemError(f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the evaluation path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    L.iem_last_error.restype = C.c_char_p
+    L.iem_version.restype = C.c_char_p
+    L.iem_create.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(vp)]
+    L.iem_destroy.argtypes = [vp]
+    L.iem_meta.argtypes = [vp, C.POINTER(Meta)]
+    L.iem_template_info.argtypes = [vp, i64, C.POINTER(TemplateInfo)]
+    L.iem_kernel_info.argtypes = [vp, i32, C.POINTER(KernelInfo)]
+    L.iem_get_host.argtypes = [vp, i32, vp]
+    L.iem_set_stream.argtypes = [vp, vp]
+    L.iem_synchronize.argtypes = [vp]
+    L.iem_set_parameter.argtypes = [vp, i64, i64, vp]
+    L.iem_obj.argtypes = [vp, vp, C.POINTER(dbl)]
+    L.iem_obj_device.argtypes = [vp, vp, vp]
+    L.iem_grad.argtypes = [vp, vp, vp]
+    L.iem_cons.argtypes = [vp, vp, vp]
+    L.iem_jac_coord.argtypes = [vp, vp, vp]
+    L.iem_hess_coord.argtypes = [vp, vp, vp, dbl, vp]
+    for f in ("iem_jac_structure", "iem_hess_structure", "iem_jac_structure_device", "iem_hess_structure_device"):
+        getattr(L, f).argtypes = [vp, vp, vp, i32]
+    L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    L.iem_emit_source.restype = i32
+    L.iem_free.argtypes = [vp]
+    L.iem_set_option.argtypes = [C.c_char_p, i64]
+    L.iem_time_kernels.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise IemError(f"libiem_hip error {rc}: {lib().iem_last_error().decode(errors='replace')}")
+
+
+def set_option(name: str, value: int):
+    check(lib().iem_set_option(name.encode(), int(value)))
+
+
+def emit_source(blob: bytes):
+    """Generated HIP source of a model and its cache key (no device needed)."""
+    L = lib()
+    L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    p = C.c_void_p()
+    key = C.c_uint64()
+    check(L.iem_emit_source(blob, len(blob), C.byref(p), C.byref(key)))
+    try:
+        src = C.string_at(p).decode()
+    finally:
+        L.iem_free(p)
+    return src, int(key.value)
+
+
+def emit_launch_plan(blob: bytes) -> str:
+    L = lib()
+    L.iem_emit_launch_plan.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    p = C.c_void_p()
+    check(L.iem_emit_launch_plan(blob, len(blob), C.byref(p)))
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.iem_free(p)
+
+
+def precompile(blob: bytes, arch: str = "gfx950", force: bool = False) -> str:
+    """Offline-compile a model's kernels into the in-tree code-object cache
+    (``hipcc --genco --offload-arch=gfx950``); returns the ``.hsaco`` path."""
+    src, key = emit_source(blob)
+    os.makedirs(KERNEL_DIR, exist_ok=True)
+    out = os.path.join(KERNEL_DIR, f"iem_{key:016x}.hsaco")
+    if os.path.exists(out) and not force:
+        return out
+    hip = os.path.join(KERNEL_DIR, f"iem_{key:016x}.hip")
+    with open(hip, "w") as f:
+        f.write(src)
+    cmd = [os.path.join(ROCM, "bin", "hipcc"), "--genco", f"--offload-arch={arch}", "-O3", "-ffp-contract=off",
+           "-std=c++17", "-o", out + ".tmp", hip]
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out

@@ -1,0 +1,197 @@
+"""``ExaModel``: the NLPModels evaluation surface over ``libiem_hip.so``.
+
+Mirror of what the reference obtains from ``ExaModels.ExaModel(core)``
+(``/root/reference/src/infiniteopt_backend.jl:156``) and what the solvers call on it
+every iteration (``ext/InfiniteExaModelsIpopt.jl:49``, ``ext/InfiniteExaModelsMadNLP.jl:50``):
+``obj, grad!, cons!, jac_structure!, jac_coord!, hess_structure!, hess_coord!``, the
+``meta`` block (``nvar, ncon, nnzj, nnzh, x0, y0, lvar, uvar, lcon, ucon, minimize``) and
+``θ``.  Vectors are torch float64 tensors resident in HBM (the ROCArray analogue);
+only raw device pointers cross the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+
+from . import lib as _lib
+from .core import ExaCore
+
+
+class MI355XBackend:
+    """Value for ``backend =`` that selects the HIP evaluator (the reference's
+    ``CUDABackend()`` slot, ``README.md:41``)."""
+
+    def __init__(self, device: int = 0):
+        self.device = int(device)
+
+    def __repr__(self):
+        return f"MI355XBackend(device={self.device})"
+
+
+def _ptr(t) -> int:
+    if t is None:
+        return 0
+    if hasattr(t, "data_ptr"):
+        return int(t.data_ptr())
+    return int(t)
+
+
+class ExaModel:
+    """Device-resident NLP model built from an :class:`ExaCore`."""
+
+    def __init__(self, core: ExaCore, device: Optional[int] = None, blob: Optional[bytes] = None):
+        import torch
+
+        if device is None:
+            device = core.backend.device if isinstance(core.backend, MI355XBackend) else 0
+        if not torch.cuda.is_available():
+            raise _lib.IemError("no GPU visible: the evaluation path has no CPU fallback")
+        self._torch = torch
+        self.core = core
+        self.device = torch.device("cuda", device)
+        self._L = _lib.lib()
+        blob = blob if blob is not None else core.to_blob()
+        h = C.c_void_p()
+        _lib.check(self._L.iem_create(blob, len(blob), device, C.byref(h)))
+        self._h = h
+        core._model = self
+        m = _lib.Meta()
+        _lib.check(self._L.iem_meta(self._h, C.byref(m)))
+        host = lambda which, n: self._host(which, n)
+        self.meta = SimpleNamespace(
+            nvar=int(m.nvar), ncon=int(m.ncon), npar=int(m.npar), nnzj=int(m.nnzj), nnzh=int(m.nnzh),
+            minimize=bool(m.minimize), n_templates=int(m.n_templates), n_kernels=int(m.n_kernels),
+            x0=host(0, m.nvar), lvar=host(1, m.nvar), uvar=host(2, m.nvar),
+            lcon=host(3, m.ncon), ucon=host(4, m.ncon), y0=host(5, m.ncon))
+        self.counters = SimpleNamespace(neval_obj=0, neval_grad=0, neval_cons=0, neval_jac=0, neval_hess=0)
+
+    # ---- lifecycle -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.iem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _host(self, which: int, n: int) -> np.ndarray:
+        out = np.zeros(max(int(n), 1))
+        _lib.check(self._L.iem_get_host(self._h, which, out.ctypes.data))
+        return out[:int(n)]
+
+    @property
+    def theta(self) -> np.ndarray:
+        """``model.θ`` (``infiniteopt_backend.jl:479``) — host mirror."""
+        return self._host(6, self.meta.npar)
+
+    def template_info(self, i: int) -> dict:
+        t = _lib.TemplateInfo()
+        _lib.check(self._L.iem_template_info(self._h, i, C.byref(t)))
+        return {k: int(getattr(t, k)) for k, _ in t._fields_}
+
+    def kernels(self):
+        """Launch shape and algorithmic traffic of every fused kernel of this model."""
+        out = []
+        for k in range(self.meta.n_kernels):
+            ki = _lib.KernelInfo()
+            _lib.check(self._L.iem_kernel_info(self._h, k, C.byref(ki)))
+            out.append(dict(name=ki.name.decode(), kind=("cons", "jac", "hess", "obj", "grad")[ki.kind],
+                            grid=tuple(ki.grid), lds_bytes=int(ki.lds_bytes), jit=bool(ki.jit),
+                            alg_bytes_read=int(ki.alg_bytes_read), alg_bytes_written=int(ki.alg_bytes_written)))
+        return out
+
+    def set_parameter(self, offset: int, vals) -> None:
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        _lib.check(self._L.iem_set_parameter(self._h, int(offset), v.shape[0], v.ctypes.data))
+
+    def _sync_stream(self):
+        s = self._torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.iem_set_stream(self._h, C.c_void_p(s)))
+
+    def _new(self, n: int):
+        return self._torch.empty(int(n), dtype=self._torch.float64, device=self.device)
+
+    def _chk(self, t, n: int, name: str):
+        if t.dtype != self._torch.float64 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"{name} must be a contiguous float64 CUDA tensor of length {n}")
+
+    # ---- NLPModels API ---------------------------------------------------------
+    def obj(self, x) -> float:
+        self._chk(x, self.meta.nvar, "x")
+        self._sync_stream()
+        out = C.c_double()
+        _lib.check(self._L.iem_obj(self._h, _ptr(x), C.byref(out)))
+        self.counters.neval_obj += 1
+        return float(out.value)
+
+    def grad(self, x, g=None):
+        """``grad!(m, x, g)``."""
+        self._chk(x, self.meta.nvar, "x")
+        g = g if g is not None else self._new(self.meta.nvar)
+        self._chk(g, self.meta.nvar, "g")
+        self._sync_stream()
+        _lib.check(self._L.iem_grad(self._h, _ptr(x), _ptr(g)))
+        self.counters.neval_grad += 1
+        return g
+
+    def cons(self, x, c=None):
+        """``cons!(m, x, c)``."""
+        self._chk(x, self.meta.nvar, "x")
+        c = c if c is not None else self._new(self.meta.ncon)
+        self._chk(c, self.meta.ncon, "c")
+        self._sync_stream()
+        _lib.check(self._L.iem_cons(self._h, _ptr(x), _ptr(c)))
+        self.counters.neval_cons += 1
+        return c
+
+    def jac_coord(self, x, vals=None):
+        """``jac_coord!(m, x, vals)``."""
+        self._chk(x, self.meta.nvar, "x")
+        vals = vals if vals is not None else self._new(self.meta.nnzj)
+        self._chk(vals, self.meta.nnzj, "vals")
+        self._sync_stream()
+        _lib.check(self._L.iem_jac_coord(self._h, _ptr(x), _ptr(vals)))
+        self.counters.neval_jac += 1
+        return vals
+
+    def hess_coord(self, x, y, vals=None, obj_weight: float = 1.0):
+        """``hess_coord!(m, x, y, vals; obj_weight)``."""
+        self._chk(x, self.meta.nvar, "x")
+        self._chk(y, self.meta.ncon, "y")
+        vals = vals if vals is not None else self._new(self.meta.nnzh)
+        self._chk(vals, self.meta.nnzh, "vals")
+        self._sync_stream()
+        _lib.check(self._L.iem_hess_coord(self._h, _ptr(x), _ptr(y), float(obj_weight), _ptr(vals)))
+        self.counters.neval_hess += 1
+        return vals
+
+    def jac_structure(self, base: int = 0):
+        """``jac_structure!(m, rows, cols)`` → host int64 arrays (``base`` 1 = Julia)."""
+        r = np.zeros(max(self.meta.nnzj, 1), dtype=np.int64)
+        c = np.zeros(max(self.meta.nnzj, 1), dtype=np.int64)
+        _lib.check(self._L.iem_jac_structure(self._h, r.ctypes.data, c.ctypes.data, base))
+        return r[:self.meta.nnzj], c[:self.meta.nnzj]
+
+    def hess_structure(self, base: int = 0):
+        r = np.zeros(max(self.meta.nnzh, 1), dtype=np.int64)
+        c = np.zeros(max(self.meta.nnzh, 1), dtype=np.int64)
+        _lib.check(self._L.iem_hess_structure(self._h, r.ctypes.data, c.ctypes.data, base))
+        return r[:self.meta.nnzh], c[:self.meta.nnzh]
+
+    def synchronize(self):
+        _lib.check(self._L.iem_synchronize(self._h))
+
+    def time_kernels(self, x, y, jac, hess, iters: int = 20):
+        """Average device time (ms) of one jac_coord! and one hess_coord! call, HIP events
+        on the launch stream."""
+        self._sync_stream()
+        a, b = C.c_double(), C.c_double()
+        _lib.check(self._L.iem_time_kernels(self._h, _ptr(x), _ptr(y), _ptr(jac), _ptr(hess), iters,
+                                            C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)

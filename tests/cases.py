@@ -1,0 +1,138 @@
+"""Model cases shared by the CPU tests, the GPU parity tests and build() (which
+pre-compiles their kernels for gfx950)."""
+from __future__ import annotations
+
+import numpy as np
+
+from infiniteexamodels.jl_amd import infinite as io
+from infiniteexamodels.jl_amd import transcribe, workloads
+from infiniteexamodels.jl_amd.infinite import DomainRestriction, InfiniteModel
+
+
+def ode_5x5():
+    """/root/reference/test/ipopt.jl:160-167 — nvar 51, ncon 70."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    x = m.infinite_parameter("x", -1, 1, num_supports=5)
+    y = m.variable("y", t, x, lb=0)
+    z = m.variable("z", start=10)
+    m.objective("min", m.integral(m.integral(y ** 2, t) + 2 * z, x))
+    m.constraint(m.deriv(y, t) == io.sin(y) + z + 1.2)
+    m.constraint(y + z <= 42 + t)
+    return m
+
+
+def test_problem_1():
+    """/root/reference/test/solve.jl:2-14 (restricted constraint, point + semi-infinite vars)."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    x = m.infinite_parameter("x", -1, 1, num_supports=5)
+    y = m.variable("y", t, x, lb=0)
+    z = m.variable("z", start=10)
+    m.objective("min", m.integral(m.integral(y ** 2, t), x) + 2 * y(0, 1))
+    m.constraint(m.deriv(y, t) == io.sin(y) + z + 1.2)
+    m.constraint(y + z <= 42 + t, restriction=DomainRestriction(lambda s: (0 <= s) & (s <= 0.5), t))
+    m.constraint(m.deriv(y(0, x), x) == 5)
+    return m
+
+
+def rosenbrock(p1=100.0, p2=1.0):
+    """/root/reference/test/solve.jl:134-143 — finite parameters p1, p2."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=3)
+    P1 = m.finite_parameter("p1", p1)
+    P2 = m.finite_parameter("p2", p2)
+    x = [m.variable(f"x[{i + 1}]", t) for i in range(2)]
+    m.objective("min", P1 * m.integral((x[1] - x[0] ** 2) ** 2, t) + m.integral((P2 - x[0]) ** 2, t))
+    for i, ub in enumerate([0.5, 3.0]):
+        m.constraint(x[i] <= ub)
+    m.constraint(x[0] * x[1] >= 1.0)
+    m.constraint(x[0] + x[1] ** 2 >= 0.0)
+    return m, (P1, P2)
+
+
+def pfun(k=0.2, f1=np.sin):
+    """/root/reference/test/solve.jl:173-186 — parameter functions pf1(t), pf2(t, s)."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=3)
+    s = m.infinite_parameter("s", 2, 3, num_supports=3)
+    v = m.variable("v", t, lb=0, ub=100)
+    z = m.variable("z", t, s, lb=0, ub=100)
+    pf1 = m.parameter_function("pf1", f1, t)
+    pf2 = m.parameter_function("pf2", lambda t, s: np.sin(t) * s + k, t, s)
+    m.constraint(v + pf1 <= 100, name="c1")
+    m.constraint(v * 2 + pf1 * pf2 <= 100, name="c2")
+    m.constraint(v >= 0.5 * pf2, name="c3")
+    m.constraint(z(t, 2.5) + pf2 * pf1 <= 40, name="c4")
+    m.objective("min", m.integral(v * pf1, t) + m.integral(m.integral(0.5 * z * pf2, t), s))
+    return m, (pf1, pf2)
+
+
+def operator_zoo():
+    """Every operator of /root/reference/src/operators.jl:3-44 in one model."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=70)
+    a = m.variable("a", t, start=0.6)
+    b = m.variable("b", t, start=1.7)
+    names = ["inv", "sqrt", "cbrt", "abs", "abs2", "exp", "exp2", "log", "log2", "log10", "log1p",
+             "sin", "cos", "tan", "asin", "acos", "csc", "sec", "cot", "atan", "acot",
+             "sind", "cosd", "tand", "cscd", "secd", "cotd", "atand", "acotd",
+             "sinh", "cosh", "tanh", "csch", "sech", "coth", "atanh"]
+    for n in names:
+        f = getattr(io, n)
+        m.constraint(f(a) * b + f(a * 0.5) >= -1e3)
+    m.constraint(io.acoth(b) * a >= -1e3)
+    m.constraint(a ** b + b ** 2.5 + 2.0 ** a + a / b + (a * b) ** 3 >= -1e3)
+    m.constraint(-io.sin(a) + (+b) - a / 2.0 + 3.0 / b >= -1e3)
+    m.objective("min", m.integral(io.exp(a) * io.sin(b) + (a - b) ** 2 / (1 + b ** 2), t))
+    return m
+
+
+def irregular():
+    """Explicit-column iterators: a domain restriction that is not a contiguous range."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=130)
+    y = m.variable("y", t, start=1.0)
+    w = m.variable("w", start=0.5)
+    m.constraint(y ** 2 * w >= 2, restriction=DomainRestriction(lambda s: np.sin(40 * s) >= 0.2, t))
+    m.constraint(m.deriv(y, t) == -y * w)
+    m.objective("min", m.integral(y ** 2, t) + w ** 2)
+    return m
+
+
+def small_cases():
+    """name -> (core builder, positive?)"""
+    return {
+        "quadrotor_5": lambda: workloads.quadrotor(5),
+        "quadrotor_100": lambda: workloads.quadrotor(100),
+        "quadrotor_1000": lambda: workloads.quadrotor(1000),
+        "pandemic_20x3": lambda: workloads.pandemic(20, 3),
+        "pandemic_300x7": lambda: workloads.pandemic(300, 7),
+        "farmer_5": lambda: workloads.farmer(5),
+        "farmer_1000": lambda: workloads.farmer(1000),
+        "ode_5x5": ode_5x5,
+        "test_problem_1": test_problem_1,
+        "rosenbrock": lambda: rosenbrock()[0],
+        "pfun": lambda: pfun()[0],
+        "operator_zoo": operator_zoo,
+        "irregular": irregular,
+    }
+
+
+def eval_point_for(name, om, seed=0):
+    """Seeded evaluation point kept inside every operator's domain."""
+    rng = np.random.default_rng(seed)
+    x = om.x0 + 0.1 * rng.standard_normal(om.nvar)
+    if name.startswith("quadrotor"):
+        pass
+    elif name == "operator_zoo":
+        n = om.nvar // 2
+        x = np.concatenate([0.3 + 0.5 * rng.random(n), 1.3 + 0.6 * rng.random(om.nvar - n)])
+    else:
+        x = np.abs(x) + 0.05
+    y = np.random.default_rng(seed + 1).standard_normal(om.ncon)
+    return x, y
+
+
+def build_core(name):
+    return transcribe.exa_core(small_cases()[name]())

@@ -1,0 +1,34 @@
+// emu_header.h — host stand-ins for the device primitives of iem_device.h so that the
+// GENERATED kernel bodies can be compiled with g++ and run one lane at a time
+// (tests/emu.py).  Test tool only; the HIP primitives themselves are exercised on the GPU.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#define IEM_BLOCK 256
+#define IEM_WAVE 64
+#define __global__
+#define __device__
+#define __forceinline__ inline
+#define __launch_bounds__(x)
+#define __restrict__
+#define __shared__ static
+
+struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };
+static emu_dim3 threadIdx, blockIdx, gridDim;
+
+inline int iem_lane() { return (int)(threadIdx.x & 63); }
+inline int iem_wave() { return (int)(threadIdx.x >> 6); }
+
+template <int NS>
+inline void iem_store_rows_direct(double *out, long long pos0, bool valid, const double (&v)[NS]) {
+  if (valid) for (int s = 0; s < NS; ++s) out[pos0 + s] = v[s];
+}
+template <int NS>
+inline void iem_store_rows(double *out, long long pos0, bool valid, const double (&v)[NS], double *) {
+  iem_store_rows_direct<NS>(out, pos0, valid, v);
+}
+inline void iem_block_partial(double v, double *partials, long long slot, double *) { partials[slot] += v; }
+inline void iem_grad_wave_uniform(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }
+inline void iem_grad_atomic(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }
