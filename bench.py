@@ -77,7 +77,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--supports", type=int, default=1_000_000, help="supports per rank (weak) / total (strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--store-mode", type=int, default=1)
+    ap.add_argument("--store-mode", type=int, default=2)
+    ap.add_argument("--nt", type=int, default=1)
+    ap.add_argument("--fma", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     args = ap.parse_args()
@@ -100,6 +103,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     iemlib.build_library()
     iemlib.set_option("store_mode", args.store_mode)
+    iemlib.set_option("nt_stores", args.nt)
+    iemlib.set_option("fp_contract", args.fma)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        iemlib.set_option(k, int(v))
 
     if args.scaling == "weak":
         S_global, S_local = args.supports * world, args.supports

@@ -44,9 +44,16 @@ int fail(int code, const std::string &msg) {
       return fail(IEM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
   } while (0)
 
+std::string contract_flag() { return g_opt.fp_contract ? "-ffp-contract=fast" : "-ffp-contract=off"; }
+
+// first line carries the compile flags so that an offline build (lib.precompile) and the
+// hiprtc path compile the same key with the same options
 std::string full_source(const iem::Program &p) {
   std::string s;
+  s += "// iem-flags: -O3 " + contract_flag() + " -std=c++17\n";
   s += "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+  s += std::string("#define IEM_NT ") + (g_opt.nt_stores ? "1" : "0") + "\n";
+  if (g_opt.ablate) s += "#define IEM_ABLATE " + std::to_string(g_opt.ablate & 1) + "  // timing experiment, results are wrong\n";
   s += kDeviceHeader;
   s += "\n";
   s += p.source;
@@ -154,7 +161,8 @@ int compile_or_load(iem_model *m) {
     if (hiprtcCreateProgram(&prog, src.c_str(), "iem_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       return fail(IEM_E_COMPILE, "hiprtcCreateProgram failed");
     std::string archopt = "--offload-arch=" + arch;
-    const char *opts[] = {archopt.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
+    std::string cflag = contract_flag();
+    const char *opts[] = {archopt.c_str(), "-O3", cflag.c_str(), "-std=c++17"};
     hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
     if (r != HIPRTC_SUCCESS) {
       size_t n = 0;
@@ -280,6 +288,11 @@ void iem_free(void *p) { std::free(p); }
 int iem_set_option(const char *name, int64_t value) {
   if (!name) return fail(IEM_E_ARG, "null option name");
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "reorder") == 0) { g_opt.reorder = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "min_waves") == 0) { g_opt.min_waves = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fp_contract") == 0) { g_opt.fp_contract = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -310,7 +323,7 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     os << "partials " << p.n_partials << "\n";
     for (const iem::KernelDesc &kd : p.kernels) {
       os << "kernel " << kd.name << " kind " << kd.kind << " grid " << kd.grid[0] << " " << kd.grid[1] << " " << kd.grid[2]
-         << " lds " << kd.lds_bytes << "\n";
+         << " lds " << kd.lds_bytes << " rbytes " << kd.alg_bytes_read << " wbytes " << kd.alg_bytes_written << "\n";
       os << "ip " << kd.ip.size(); for (int64_t v : kd.ip) os << " " << v; os << "\n";
       os << "dp " << kd.dp.size(); for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); os << " " << b; } os << "\n";
       os << "fa " << kd.fa.size(); for (int v : kd.fa) os << " " << v; os << "\n";

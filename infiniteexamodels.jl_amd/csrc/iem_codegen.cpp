@@ -122,6 +122,8 @@ struct Output {
   std::vector<int> vals;      // DAG ids
   std::vector<int> grad_idx;  // KK_GRAD: IdxVal ids (0-based) per value
   std::vector<int> grad_mode; // 0 exclusive store, 1 wave-uniform, 2 atomic
+  bool scalar = false;
+  int64_t qlo[3] = {0, 0, 0}, qhi[3] = {1, 1, 1};  // valid q range of the template in the launch domain
 };
 
 class KernelBuilder {
@@ -256,6 +258,7 @@ class KernelBuilder {
     bool scalar = false;
     int64_t sh[3] = {0, 0, 0};  // k_d = q_d + sh_d
     int guard = 0;
+    int64_t qlo[3] = {0, 0, 0}, qhi[3] = {1, 1, 1};
   };
 
   // guard id: canonical text → id
@@ -277,6 +280,7 @@ class KernelBuilder {
       for (int d = 0; d < g_.nd; ++d) {
         G.sh[d] = g_.lo[d] - t.origin[d];
         int64_t qlo = -G.sh[d], qhi = t.dims[d] - G.sh[d];  // valid q range [qlo, qhi)
+        G.qlo[d] = qlo; G.qhi[d] = qhi;
         if (qlo > 0) os << " && q" << d << " >= " << coefstr(qlo);
         if (qhi < g_.ext[d]) os << " && q" << d << " < " << ip(qhi);
       }
@@ -607,6 +611,8 @@ class KernelBuilder {
       TplGen tg(*this, ti, G);
       Output o;
       o.kind = kind_; o.tpl = ti; o.guard = G.guard; o.pos_idx = -1;
+      o.scalar = pr.second;
+      for (int d = 0; d < 3; ++d) { o.qlo[d] = G.qlo[d]; o.qhi[d] = G.qhi[d]; }
       switch (kind_) {
         case KK_CONS: {
           tg.forward(0);
@@ -756,14 +762,16 @@ class KernelBuilder {
             int oid = it->second;
             std::string s = n.sub == IEM_OP_SIN ? nm : "v" + std::to_string(oid);
             std::string c = n.sub == IEM_OP_SIN ? "v" + std::to_string(oid) : nm;
-            os << "  double " << s << ", " << c << "; sincos(v" << n.a << ", &" << s << ", &" << c << ");\n";
+            if (opt_.ablate & 2) os << "  double " << s << " = v" << n.a << " * 0.5, " << c << " = v" << n.a << " * 0.25;\n";
+            else os << "  double " << s << ", " << c << "; sincos(v" << n.a << ", &" << s << ", &" << c << ");\n";
             done[oid] = 1;
             break;
           }
         }
         const char *f = fn_name(n.sub);
         if (!f) throw std::runtime_error("codegen: no device function for opcode " + std::to_string(n.sub));
-        os << "  const double " << nm << " = " << f << "(v" << n.a << ");\n";
+        if (opt_.ablate & 2) os << "  const double " << nm << " = v" << n.a << " * 0.75;\n";
+        else os << "  const double " << nm << " = " << f << "(v" << n.a << ");\n";
         break;
       }
       case VBIN: {
@@ -801,11 +809,58 @@ class KernelBuilder {
     int max_ns = 1;
     for (auto &o : outs_) if (kind_ == KK_JAC || kind_ == KK_HESS) max_ns = std::max<int>(max_ns, (int)o.vals.size());
     bool use_lds = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 1;
+    bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 2;
 
     // stores/outputs first into `tail` so that every ip() they need is registered before the struct is printed
     std::ostringstream tail;
     if (kind_ == KK_OBJ) tail << "  double acc = 0.0;\n";
-    for (auto &o : outs_) {
+    // Emission order: cheapest outputs first (greedy on the incremental cost of the DAG
+    // nodes still to be computed).  Blocks of one launch start in lockstep, so a kernel that
+    // computes everything before its first store leaves HBM idle for the whole prologue of
+    // the first round; emitting the templates with constant/affine partials first lets the
+    // store stream start while the transcendental-heavy templates are still being computed.
+    std::vector<int> order;
+    if (opt_.reorder && (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS)) {
+      std::vector<char> sim = done;
+      std::vector<char> taken(outs_.size(), 0);
+      for (size_t step = 0; step < outs_.size(); ++step) {
+        long best_cost = -1;
+        int best = -1;
+        for (size_t oi = 0; oi < outs_.size(); ++oi) {
+          if (taken[oi]) continue;
+          long c = 0;
+          std::vector<int> st(outs_[oi].vals.begin(), outs_[oi].vals.end());
+          std::vector<int> seen;
+          while (!st.empty()) {
+            int id = st.back(); st.pop_back();
+            if (sim[id]) continue;
+            sim[id] = 2; seen.push_back(id);
+            const VNode &n = v_[id];
+            if (n.op == VUN) { c += (n.sub == IEM_OP_NEG || n.sub == U_SGN) ? 1 : 40; st.push_back(n.a); }
+            else if (n.op == VBIN) { c += n.sub == IEM_OP_DIV ? 12 : n.sub == IEM_OP_POW ? 80 : 1; st.push_back(n.a); st.push_back(n.b); }
+            else if (n.op == VSEL) { c += 1; st.push_back(n.a); st.push_back(n.b); }
+            else if (n.op == VLD) c += 4;
+          }
+          for (int id : seen) sim[id] = 0;
+          if (best < 0 || c < best_cost) { best = (int)oi; best_cost = c; }
+        }
+        taken[best] = 1;
+        order.push_back(best);
+        std::vector<int> st(outs_[best].vals.begin(), outs_[best].vals.end());
+        while (!st.empty()) {
+          int id = st.back(); st.pop_back();
+          if (sim[id]) continue;
+          sim[id] = 1;
+          const VNode &n = v_[id];
+          if (n.op == VUN) st.push_back(n.a);
+          else if (n.op == VBIN || n.op == VSEL) { st.push_back(n.a); st.push_back(n.b); }
+        }
+      }
+    } else {
+      for (size_t oi = 0; oi < outs_.size(); ++oi) order.push_back((int)oi);
+    }
+    for (int oi : order) {
+      auto &o = outs_[oi];
       const Template &t = m_.tpl[o.tpl];
       tail << "  // template " << o.tpl << " (" << (t.kind == IEM_T_OBJ ? "objective" : "constraint") << ", " << o.vals.size() << " value(s))\n";
       for (int v : o.vals) emit_val(v, tail, done, live);
@@ -824,7 +879,24 @@ class KernelBuilder {
           tail << "  { const double r[" << ns << "] = {";
           for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
           tail << "};\n";
-          if (use_lds && !scalar_tpl) tail << "    iem_store_rows<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r, lds_wave); }\n";
+          if (opt_.store_mode == 2 && !scalar_tpl) {
+            // block-uniform position of lane 0 / slot 0 and the valid lane interval of this workgroup
+            const IdxVal &pv = idx_[o.pos_idx];
+            AffQ pb = pv.aff;
+            std::ostringstream gb;
+            bool any = false;
+            for (int d = 1; d < g_.nd; ++d) {
+              if (o.qlo[d] > 0) { gb << (any ? " && " : "") << "q" << d << " >= " << coefstr(o.qlo[d]); any = true; }
+              if (o.qhi[d] < g_.ext[d]) { gb << (any ? " && " : "") << "q" << d << " < " << ip(o.qhi[d]); any = true; }
+            }
+            int64_t k0 = pb.k[0];
+            pb.k[0] = 0;
+            tail << "    const long long pb = " << aff_str(pb) << " + " << coefstr(k0) << " * qb0;\n";
+            tail << "    const int v0 = iem_clamp256(" << coefstr(o.qlo[0]) << " - qb0);\n";
+            tail << "    const int v1 = " << (any ? "(" + gb.str() + ") ? " : "") << "iem_clamp256(" << ip(std::min(o.qhi[0], g_.ext[0])) << " - qb0)"
+                 << (any ? " : v0" : "") << ";\n";
+            tail << "    iem_store_block<" << ns << ">(OUT, pb, v0, v1, r, lds_blk); }\n";
+          } else if (use_lds && !scalar_tpl) tail << "    iem_store_rows<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r, lds_wave); }\n";
           else tail << "    iem_store_rows_direct<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r); }\n";
           break;
         }
@@ -899,7 +971,8 @@ class KernelBuilder {
     size_t nfa = std::max<size_t>(1, fav_.size()), nia = std::max<size_t>(1, iav_.size());
     os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; double* out; double w;\n"
        << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
-    os << "extern \"C\" __global__ __launch_bounds__(IEM_BLOCK) void " << name_ << "(const Args_" << name_ << " A) {\n";
+    os << "extern \"C\" __global__ __launch_bounds__(IEM_BLOCK" << (opt_.min_waves > 0 ? ", " + std::to_string(opt_.min_waves) : std::string())
+       << ") void " << name_ << "(const Args_" << name_ << " A) {\n";
     os << "  const double* __restrict__ X = A.x; const double* __restrict__ TH = A.th; const double* __restrict__ Y = A.y;\n";
     os << "  double* __restrict__ OUT = A.out;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
@@ -907,6 +980,11 @@ class KernelBuilder {
     if (use_lds) {
       os << "  __shared__ double lds_all[" << (IEM_BLOCK_WAVES * 64 * max_ns) << "];\n";
       os << "  double* lds_wave = lds_all + iem_wave() * " << (64 * max_ns) << ";\n";
+      kd.lds_bytes = IEM_BLOCK_WAVES * 64 * max_ns * 8;
+    }
+    if (use_blk) {
+      os << "  __shared__ double lds_blk[" << (IEM_BLOCK_WAVES * 64 * max_ns) << "];\n";
+      os << "  const long long qb0 = (long long)blockIdx.x * IEM_BLOCK;\n";
       kd.lds_bytes = IEM_BLOCK_WAVES * 64 * max_ns * 8;
     }
     if (kind_ == KK_OBJ) os << "  __shared__ double lds4[4];\n";
@@ -1155,7 +1233,7 @@ Program generate(const Model &m, const Options &opt) {
   }
   P.n_partials = partial_off;
   P.source = src.str();
-  P.key = fnv1a64(P.source + (opt.store_mode ? "|lds" : "|direct"));
+  P.key = fnv1a64(P.source);
   return P;
 }
 

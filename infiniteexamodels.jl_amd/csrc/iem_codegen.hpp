@@ -27,7 +27,12 @@ struct KernelDesc {
 };
 
 struct Options {
-  int store_mode = 1;  // 0 direct strided stores, 1 LDS-transposed coalesced stores
+  int store_mode = 2;  // 0 direct strided stores, 1 wave-level LDS-transposed stores, 2 block-cooperative 128-B-aligned stores
+  int reorder = 1;     // 1: emit cheap templates first so the store stream starts early
+  int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
+  int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels
+  int nt_stores = 1;   // 1: non-temporal stores for the streamed COO outputs
+  int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)
 };
 
 struct Program {

@@ -36,13 +36,26 @@ __device__ __forceinline__ void iem_wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// streaming store of an output element: the COO buffers are written once per call and
+// never re-read by the evaluator, so IEM_NT=1 marks them non-temporal.
+#ifndef IEM_NT
+#define IEM_NT 0
+#endif
+__device__ __forceinline__ void iem_stg(double *p, double v) {
+#if IEM_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // Direct form: lane writes its NS slots at stride NS (kept for A/B measurement).
 template <int NS>
 __device__ __forceinline__ void iem_store_rows_direct(double *__restrict__ out, long long pos0, bool valid,
                                                       const double (&v)[NS]) {
   if (valid) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) out[pos0 + s] = v[s];
+    for (int s = 0; s < NS; ++s) iem_stg(out + pos0 + s, v[s]);
   }
 }
 
@@ -54,19 +67,65 @@ __device__ __forceinline__ void iem_store_rows(double *__restrict__ out, long lo
   const int lane = iem_lane();
   const unsigned long long m = __ballot(valid);
   if (m == 0ull) return;  // wave-uniform
+#if defined(IEM_ABLATE) && IEM_ABLATE == 1
+  {  // timing experiment only (WRONG layout): coalesced stores without the LDS transpose
+    const long long b0 = __shfl(pos0, __ffsll((long long)m) - 1, IEM_WAVE);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) if (valid) iem_stg(out + b0 + s * IEM_WAVE + lane, v[s]);
+    return;
+  }
+#endif
 #pragma unroll
   for (int s = 0; s < NS; ++s) lds_wave[lane * NS + s] = v[s];
   const int first = __ffsll((long long)m) - 1;
   // position of (virtual) lane 0, slot 0 — wave-uniform
   const long long base = __shfl(pos0, first, IEM_WAVE) - (long long)first * NS;
   iem_wave_lds_sync();
+  double *__restrict__ dst = out + base + lane;
+  if (m == ~0ull) {  // full wave (the common case): NS unpredicated 512-byte stores
 #pragma unroll
-  for (int j = 0; j < NS; ++j) {
-    const int e = j * IEM_WAVE + lane;  // element of the wave's contiguous block
-    const int src = e / NS;             // lane that produced it (NS is a compile-time constant)
-    if ((m >> src) & 1ull) out[base + e] = lds_wave[e];
+    for (int j = 0; j < NS; ++j) iem_stg(dst + j * IEM_WAVE, lds_wave[j * IEM_WAVE + lane]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int e = j * IEM_WAVE + lane;  // element of the wave's contiguous block
+      const int src = e / NS;             // lane that produced it (NS is a compile-time constant)
+      if ((m >> src) & 1ull) iem_stg(dst + j * IEM_WAVE, lds_wave[e]);
+    }
   }
   iem_wave_lds_sync();
+}
+
+// Block-cooperative, 128-byte-ALIGNED form (store_mode 2).
+//
+// The COO offsets are ExaModels' running counters (o1 = 9, 209, ...), so a wave's own
+// block  [o + NS*64*w, o + NS*64*(w+1))  starts at an arbitrary 8-byte phase: every 512-byte
+// wave store would straddle an extra cache line (measured: 4.5 vs 5.6 TB/s for the same
+// bytes, tools/membw2.hip).  Here the 4 waves of a workgroup stage their 256 items and
+// re-cut the workgroup's contiguous block at 128-byte boundaries of the OUTPUT address:
+//   head  (< 16 elements up to the first boundary)   one partial store
+//   body  every wave store is 512 bytes, 128-byte aligned
+// v0/v1 = first / one-past-last valid lane of the workgroup (template guards are ranges
+// in q0, so validity is an interval); P0 = position of lane 0's slot 0 (block-uniform).
+__device__ __forceinline__ int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_BLOCK ? IEM_BLOCK : (int)v); }
+
+template <int NS>
+__device__ __forceinline__ void iem_store_block(double *__restrict__ out, long long P0, int v0, int v1,
+                                                const double (&v)[NS], double *__restrict__ lds_blk) {
+  const int t = (int)threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) lds_blk[t * NS + s] = v[s];
+  __syncthreads();
+  const int e0 = v0 * NS, e1 = v1 * NS;  // valid element interval of the workgroup's block
+  const int head = (int)((16 - ((P0 + e0) & 15)) & 15);
+  double *__restrict__ dst = out + P0;
+  if (t < head && e0 + t < e1) iem_stg(dst + e0 + t, lds_blk[e0 + t]);
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int e = e0 + head + t + j * IEM_BLOCK;
+    if (e < e1) iem_stg(dst + e, lds_blk[e]);
+  }
+  __syncthreads();
 }
 
 // ---- reductions -------------------------------------------------------------

@@ -15,6 +15,7 @@ KERNEL_DIR = os.path.join(_HERE, "kernels")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 _lib = None
+DEFAULT_STORE_MODE = 2
 
 
 class IemError(RuntimeError):
@@ -136,8 +137,10 @@ def precompile(blob: bytes, arch: str = "gfx950", force: bool = False) -> str:
     hip = os.path.join(KERNEL_DIR, f"iem_{key:016x}.hip")
     with open(hip, "w") as f:
         f.write(src)
-    cmd = [os.path.join(ROCM, "bin", "hipcc"), "--genco", f"--offload-arch={arch}", "-O3", "-ffp-contract=off",
-           "-std=c++17", "-o", out + ".tmp", hip]
+    first = src.split("\n", 1)[0]
+    assert first.startswith("// iem-flags:"), first
+    flags = first[len("// iem-flags:"):].split()
+    cmd = [os.path.join(ROCM, "bin", "hipcc"), "--genco", f"--offload-arch={arch}", *flags, "-o", out + ".tmp", hip]
     subprocess.check_call(cmd)
     os.replace(out + ".tmp", out)
     return out

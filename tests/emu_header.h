@@ -29,6 +29,12 @@ template <int NS>
 inline void iem_store_rows(double *out, long long pos0, bool valid, const double (&v)[NS], double *) {
   iem_store_rows_direct<NS>(out, pos0, valid, v);
 }
+inline int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_BLOCK ? IEM_BLOCK : (int)v); }
+template <int NS>
+inline void iem_store_block(double *out, long long P0, int v0, int v1, const double (&v)[NS], double *) {
+  const int t = (int)threadIdx.x;
+  if (t >= v0 && t < v1) for (int s = 0; s < NS; ++s) out[P0 + (long long)t * NS + s] = v[s];
+}
 inline void iem_block_partial(double v, double *partials, long long slot, double *) { partials[slot] += v; }
 inline void iem_grad_wave_uniform(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }
 inline void iem_grad_atomic(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }

@@ -79,26 +79,35 @@ def test_all_entry_points_match_oracle(name, torch_cuda):
     gm.close()
 
 
-def test_store_modes_agree(torch_cuda):
-    """LDS-transposed block stores and direct strided stores write identical bytes."""
+@pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "irregular", "test_problem_1"])
+def test_store_modes_agree(name, torch_cuda):
+    """Direct strided stores (0), wave-level LDS-transposed stores (1) and the
+    block-cooperative 128-byte-aligned stores (2) write identical bytes."""
     torch = torch_cuda
     from infiniteexamodels.jl_amd import lib as iemlib
     from infiniteexamodels.jl_amd.model import ExaModel
-    core = cases.build_core("quadrotor_1000")
+    from pyoracle import OracleModel
+    core = cases.build_core(name)
     blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om, 3)
     out = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             iemlib.set_option("store_mode", mode)
             gm = ExaModel(core, device=0, blob=blob)
-            x = torch.tensor(gm.meta.x0 + 0.1 * np.random.default_rng(3).standard_normal(gm.meta.nvar), device="cuda")
-            y = torch.tensor(np.random.default_rng(4).standard_normal(gm.meta.ncon), device="cuda")
-            out[mode] = (gm.jac_coord(x).cpu().numpy(), gm.hess_coord(x, y).cpu().numpy())
+            xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+            jv = torch.full((om.nnzj,), float("nan"), device="cuda", dtype=torch.float64)
+            hv = torch.full((om.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
+            out[mode] = (gm.jac_coord(xd, jv).cpu().numpy(), gm.hess_coord(xd, yd, hv).cpu().numpy())
             gm.close()
     finally:
-        iemlib.set_option("store_mode", 1)
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1])
+        iemlib.set_option("store_mode", iemlib.DEFAULT_STORE_MODE)
+    for mode in (1, 2):
+        assert np.array_equal(out[0][0], out[mode][0]), f"jac differs in store_mode {mode}"
+        assert np.array_equal(out[0][1], out[mode][1]), f"hess differs in store_mode {mode}"
+    _close(out[2][0], om.jac_coord(x), "jac")
+    _close(out[2][1], om.hess_coord(x, y, 1.0), "hess")
 
 
 def test_set_parameter_updates_theta(torch_cuda):
