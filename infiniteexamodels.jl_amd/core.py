@@ -84,7 +84,7 @@ class Objective:
 
 class _Template:
     __slots__ = ("kind", "items", "nodes", "root", "ifields", "ffields", "idx", "lcon", "ucon",
-                 "o0", "expr")
+                 "o0", "expr", "tag")
 
 
 class ExaCore:
@@ -179,6 +179,7 @@ class ExaCore:
             expr = Null(expr)
         t = _Template()
         t.kind, t.items, t.expr = kind, items, expr
+        t.tag = ("tpl", len(self.templates))   # the transcriber overwrites it with a model-level tag
         t.nodes, t.ifields, t.ffields, t.idx = [], [], [], []
         if_ids: Dict[str, int] = {}
         ff_ids: Dict[str, int] = {}

@@ -1,6 +1,231 @@
-"""Support-axis sharding for multi-GPU runs (one process per GPU) — see DESIGN.md §6."""
+"""Support-axis sharding for multi-GPU runs — one process per GPU.
+
+The reference is single-process, single-device; its SIMD templates, however, are
+embarrassingly parallel over items: every item of a template owns its constraint row and
+its COO slots, so ``cons!``, ``jac_coord!`` and ``hess_coord!`` of a support block need no
+communication, and only the scalar objective and the gradient entries of replicated
+(finite / first-stage) variables need a sum across ranks.
+
+A shard is the SAME model statement transcribed over a window of one infinite
+parameter's supports:
+
+* rank ``r`` owns the contiguous support block ``[a_r, b_r)`` of the sharded parameter;
+  its window additionally holds ``halo`` supports before ``a_r`` (1 for the backward
+  finite-difference rows, ``transform.jl:535-557``) so stencil neighbours are local;
+* templates that iterate over the sharded parameter are cut to the owned supports
+  (:func:`owned`), measure coefficients come from the GLOBAL grid, templates that do not
+  involve the sharded parameter (point constraints, first-stage rows, finite objective
+  terms) live on rank 0 only; finite variables are replicated;
+* :class:`ShardMaps` gives the local→global maps of variables, constraint rows and COO
+  positions used by the tests (and by a consumer that wants the assembled arrays).
+
+Host-side collectives (``torch.distributed``: RCCL on GPUs, gloo in the CPU tests) are
+confined to :func:`allreduce_obj_grad`.
+"""
 from __future__ import annotations
 
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
 
-def quadrotor_shard(S_global: int, rank: int, world: int):
-    raise NotImplementedError("filled in below in this round")
+import numpy as np
+
+from . import transcribe
+from .core import ExaCore, T_CON, T_OBJ
+from .infinite import InfiniteModel, _round_sig
+
+
+@dataclass
+class ShardSpec:
+    """Attached to an :class:`InfiniteModel` as ``model.shard``; read by :mod:`transcribe`."""
+    group_index: int            # 1-based index of the sharded parameter group
+    rank: int
+    world: int
+    own_lo: int                 # local index of the first owned support (= halo actually present)
+    own_n: int                  # number of owned supports
+    global_lo: int              # global index of the first LOCAL support (window start)
+    n_global: int
+    coeffs: Optional[np.ndarray] = None   # measure coefficients of the LOCAL supports from the global grid
+
+
+def partition(n: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous near-equal blocks ``[a_r, b_r)``."""
+    base, rem = divmod(n, world)
+    out, a = [], 0
+    for r in range(world):
+        b = a + base + (1 if r < rem else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+def trapezoid_weights(s: np.ndarray) -> np.ndarray:
+    d = np.diff(s)
+    c = np.zeros_like(s)
+    c[:-1] += d / 2
+    c[1:] += d / 2
+    return c
+
+
+def window(supports: np.ndarray, rank: int, world: int, halo: int, measure: str = "trapezoid"):
+    """Local support window of ``rank`` and its :class:`ShardSpec` fields."""
+    n = len(supports)
+    a, b = partition(n, world)[rank]
+    h = min(halo, a)
+    if measure == "trapezoid":
+        cg = trapezoid_weights(supports)
+    else:
+        cg = np.full(n, 1.0 / n)
+    return supports[a - h:b], dict(own_lo=h, own_n=b - a, global_lo=a - h, n_global=n, coeffs=cg[a - h:b].copy())
+
+
+def quadrotor_shard(S_global: int, rank: int, world: int, backend=None):
+    """Time-sharded quadrotor (``examples/quadrotor.jl``): returns ``(core, owned supports)``."""
+    from . import workloads
+    t_g = _round_sig(np.linspace(0.0, 60.0, S_global))
+    local, f = window(t_g, rank, world, halo=1)
+    im = workloads.quadrotor(supports=local, backend=backend)
+    im.shard = ShardSpec(group_index=1, rank=rank, world=world, **f)
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(im, data)
+    core._shard_data = data
+    core._shard_spec = im.shard
+    return core, f["own_n"]
+
+
+def farmer_shard(num_scenarios: int, rank: int, world: int, seed: int = 42, backend=None):
+    """Scenario-sharded two-stage farmer (``examples/2stage_example.jl``)."""
+    from . import workloads
+    supp = workloads.farmer_supports(num_scenarios, seed)
+    a, b = partition(num_scenarios, world)[rank]
+    im = workloads.farmer(supports=supp[a:b], backend=backend)
+    im.shard = ShardSpec(group_index=1, rank=rank, world=world, own_lo=0, own_n=b - a, global_lo=a,
+                         n_global=num_scenarios, coeffs=np.full(b - a, 1.0 / num_scenarios))
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(im, data)
+    core._shard_data = data
+    core._shard_spec = im.shard
+    return core, b - a
+
+
+def pandemic_shard(num_supports: int, num_scenarios: int, rank: int, world: int, backend=None):
+    """ξ-sharded pandemic SIR (``ESCAPE34/pandemic.jl``): t-stencils stay local, ``u(t)`` and
+    the objective ∫u dt are replicated / rank-0 only."""
+    from . import workloads
+    xi_g = _round_sig(np.linspace(0.1, 0.6, num_scenarios))
+    a, b = partition(num_scenarios, world)[rank]
+    im = workloads.pandemic(num_supports, xi_supports=xi_g[a:b], backend=backend)
+    im.shard = ShardSpec(group_index=2, rank=rank, world=world, own_lo=0, own_n=b - a, global_lo=a,
+                         n_global=num_scenarios, coeffs=None)
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(im, data)
+    core._shard_data = data
+    core._shard_spec = im.shard
+    return core, b - a
+
+
+# ---------------------------------------------------------------------------
+# local → global maps
+# ---------------------------------------------------------------------------
+class ShardMaps:
+    """Index maps between a shard's ExaCore and the global model's ExaCore.
+
+    Both cores must come from the same model statement (same template tags)."""
+
+    def __init__(self, local: ExaCore, glob: ExaCore, spec: ShardSpec, local_data, global_data):
+        self.spec = spec
+        self._glob_templates = list(glob.templates)
+        g = spec.group_index
+        # variables -----------------------------------------------------------------
+        self.var_map = np.full(local.nvar, -1, dtype=np.int64)   # 0-based local -> 0-based global
+        self.var_owned = np.zeros(local.nvar, dtype=bool)
+        self.replicated = np.zeros(local.nvar, dtype=bool)   # finite / non-sharded variables held by every rank
+        lv = list(local_data.finvar_slabs) + list(local_data.infvar_slabs)
+        gv = list(global_data.finvar_slabs) + list(global_data.infvar_slabs)
+        assert len(lv) == len(gv)
+        for (lvar, lgroups), (gvar, ggroups) in zip(lv, gv):
+            assert lgroups == ggroups
+            if g not in lgroups:
+                idx = np.arange(lvar.length)
+                self.var_map[lvar.offset + idx] = gvar.offset + idx
+                self.var_owned[lvar.offset + idx] = spec.rank == 0
+                self.replicated[lvar.offset + idx] = True
+                continue
+            ax = lgroups.index(g)
+            lshape, gshape = lvar.size, gvar.size
+            lidx = np.indices(lshape).reshape(len(lshape), -1)
+            gidx = lidx.copy()
+            gidx[ax] += spec.global_lo
+            lflat = np.ravel_multi_index(tuple(lidx), lshape, order="F")
+            gflat = np.ravel_multi_index(tuple(gidx), gshape, order="F")
+            self.var_map[lvar.offset + lflat] = gvar.offset + gflat
+            self.var_owned[lvar.offset + lflat] = lidx[ax] >= spec.own_lo
+        assert (self.var_map >= 0).all()
+        # templates -------------------------------------------------------------------
+        gt = {t.tag: t for t in glob.templates}
+        self.row_map = np.full(local.ncon, -1, dtype=np.int64)
+        self.pairs = []   # (local template, global template, global item ordinal per local item)
+        for t in local.templates:
+            G = gt[t.tag]
+            kmap = self._item_map(t, G, spec)
+            self.pairs.append((t, G, kmap))
+            if t.kind == T_CON:
+                self.row_map[t.o0 + np.arange(len(t.items))] = G.o0 + kmap
+        assert (self.row_map >= 0).all()
+
+    @staticmethod
+    def _item_map(t, G, spec) -> np.ndarray:
+        """global item ordinal of each local item, via the templates' group-index columns."""
+        alias = f"group_idx{spec.group_index}"
+        n = len(t.items)
+        if alias not in t.items.fields:
+            return np.arange(n, dtype=np.int64)
+        # every item is identified by its tuple of integer fields; shift the sharded one
+        names = [k for k, f in t.items.fields.items() if f.kind == "int"]
+        key_l = np.stack([t.items.column(k) + (spec.global_lo if k == alias else 0) for k in names], axis=1)
+        key_g = np.stack([G.items.column(k) for k in names], axis=1)
+        lookup = {tuple(r): i for i, r in enumerate(key_g.tolist())}
+        return np.array([lookup[tuple(r)] for r in key_l.tolist()], dtype=np.int64)
+
+    def jac_positions(self, local_info, global_info):
+        """global COO position of every local Jacobian entry.
+        ``*_info(i)`` → dict with o1/o1step for template i (``ExaModel.template_info``)."""
+        return self._positions(local_info, global_info, "o1", "o1step", cons_only=True)
+
+    def hess_positions(self, local_info, global_info):
+        return self._positions(local_info, global_info, "o2", "o2step", cons_only=False)
+
+    def _positions(self, linfo, ginfo, okey, skey, cons_only):
+        out = []
+        gl_index = {id(G): i for i, G in enumerate(self._glob_templates)}
+        for li, (t, G, kmap) in enumerate(self.pairs):
+            if cons_only and t.kind != T_CON:
+                continue
+            a, b = linfo(li), ginfo(gl_index[id(G)])
+            step = a[skey]
+            assert step == b[skey]
+            if step == 0:
+                continue
+            pos = b[okey] + step * kmap[:, None] + np.arange(step)[None, :]
+            out.append((a[okey], pos.reshape(-1)))
+        res = np.concatenate([p for _, p in sorted(out, key=lambda z: z[0])]) if out else np.zeros(0, np.int64)
+        return res
+
+    def bind(self, glob: ExaCore):
+        self._glob_templates = list(glob.templates)
+        return self
+
+
+def allreduce_obj_grad(obj_local: float, grad_local, shared_idx, dist=None):
+    """The only data-path collective: sum the scalar objective and the gradient entries of
+    replicated variables in ONE small buffer (8·(1+len(shared_idx)) bytes)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    buf = torch.empty(1 + len(shared_idx), dtype=torch.float64, device=grad_local.device)
+    buf[0] = obj_local
+    if len(shared_idx):
+        buf[1:] = grad_local[shared_idx]
+    dist.all_reduce(buf)
+    if len(shared_idx):
+        grad_local[shared_idx] = buf[1:]
+    return float(buf[0].item()), grad_local

@@ -54,6 +54,11 @@ class ExaMappingData:
         self.semivar_info: Dict[VariableRef, tuple] = {}
         self.has_internal_supps: List[bool] = []
         self.support_labels: List[list] = []
+        # (Variable, group indices) in creation order — used by the sharding maps
+        self.finvar_slabs: List[tuple] = []
+        self.infvar_slabs: List[tuple] = []
+        self.obj_terms = 0
+        self.model = None
 
 
 def _supp_key(values) -> tuple:
@@ -126,6 +131,7 @@ def _add_finite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel)
         lb, ub, start = _get_variable_bounds_and_start(vref.info)
         new_var = core.add_var(1, start=start, lvar=lb, uvar=ub)
         data.finvar_mappings[vref] = new_var[1]
+        data.finvar_slabs.append((new_var, []))
 
 
 def _add_infinite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
@@ -134,6 +140,7 @@ def _add_infinite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteMode
         dims = tuple(len(data.base_itrs[g - 1]) for g in group_idxs)
         lb, ub, start = _get_variable_bounds_and_start(vref.info, m, group_idxs, dims)
         data.infvar_mappings[vref] = core.add_var(*dims, start=start, lvar=lb, uvar=ub)
+        data.infvar_slabs.append((data.infvar_mappings[vref], list(group_idxs)))
 
 
 def _add_parameter_functions(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
@@ -196,7 +203,12 @@ def _process_point_var(vref: PointVariableRef, data: ExaMappingData) -> N.Var:
 
 def _add_point_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
     for vref in m.point_variables:
-        pt = _process_point_var(vref, data)
+        try:
+            pt = _process_point_var(vref, data)
+        except KeyError:
+            if _shard(m) is not None:
+                continue   # the point lies outside this rank's support window
+            raise
         data.finvar_mappings[vref] = pt
         _update_bounds_and_start(core, vref.info, pt)
 
@@ -273,6 +285,46 @@ def _finalize_expr(expr):
     return N.Null(expr) if is_number(expr) else expr
 
 
+# sharding hooks (shard.py) -----------------------------------------------------------
+def _shard(m: InfiniteModel):
+    return getattr(m, "shard", None)
+
+
+def owned(g: int, data: ExaMappingData, m: InfiniteModel) -> Items:
+    """Base iterator of group ``g`` cut to the supports this rank owns."""
+    sp = _shard(m)
+    itr = data.base_itrs[g - 1]
+    if sp is not None and g == sp.group_index:
+        return itr.select(sp.own_lo, sp.own_n)
+    return itr
+
+
+def _rank0_only(group_idxs, m: InfiniteModel) -> bool:
+    """Templates that do not involve the sharded parameter live on rank 0 only."""
+    sp = _shard(m)
+    return sp is not None and sp.group_index not in group_idxs and sp.rank != 0
+
+
+def _emit_here(expr, group_idxs, data: ExaMappingData, m: InfiniteModel) -> bool:
+    """Does this rank own the template?  Templates over the sharded parameter: every rank
+    (cut to its supports).  Templates that do not iterate over it: the rank that owns the
+    supports of their point variables (``x(0) == 0`` → the rank holding t = 0), else rank 0."""
+    sp = _shard(m)
+    if sp is None or sp.group_index in group_idxs:
+        return True
+    owners = set()
+    for v in all_expression_variables(expr):
+        if isinstance(v, PointVariableRef) and sp.group_index in v.ivref.group_idxs:
+            supp = [a for a, p in zip(v.values, v.ivref.prefs) if p.group.index == sp.group_index]
+            i = data.support_to_index.get((sp.group_index, _supp_key(supp)))
+            owners.add(i is not None and sp.own_lo <= i - 1 < sp.own_lo + sp.own_n)
+    if owners:
+        if len(owners) > 1:
+            raise NotImplementedError("a finite template couples point variables owned by different ranks")
+        return owners.pop()
+    return sp.rank == 0
+
+
 # 8 ---------------------------------------------------------------------------------
 def _product_itr(itrs: List[Items]) -> Items:
     out = itrs[0]
@@ -292,6 +344,13 @@ def _restriction_mask(restriction, itr: Items, data: ExaMappingData) -> np.ndarr
     return np.array([bool(restriction.func(*[float(c[k]) for c in cols])) for k in range(len(itr))])
 
 
+def id_index(lst, obj) -> int:
+    for i, o in enumerate(lst):
+        if o is obj:
+            return i
+    raise ValueError("object not in list")
+
+
 def _add_constraints(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
     for cref in m.constraints:
         expr = cref.func
@@ -299,17 +358,20 @@ def _add_constraints(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> N
             warnings.warn("Constrained measures can lead to poor performance with ExaModels.")
             raise NotImplementedError("constrained measures (expand_measures) are not built yet")
         group_idxs = parameter_group_int_indices(expr)
+        if not _emit_here(expr, group_idxs, data, m):
+            continue
         if not group_idxs:
             itr = Items.single()
         elif len(group_idxs) == 1:
-            itr = data.base_itrs[group_idxs[0] - 1]
+            itr = owned(group_idxs[0], data, m)
         else:
-            itr = _product_itr([data.base_itrs[g - 1] for g in group_idxs])
+            itr = _product_itr([owned(g, data, m) for g in group_idxs])
         if cref.restriction is not None:
             itr = itr.filter(_restriction_mask(cref.restriction, itr, data))
         data_src = N.DataSource()
         em_expr = _finalize_expr(_exafy(expr, data_src, data))
         cref.mapping = core.add_con(em_expr, itr, lcon=cref.lb, ucon=cref.ub)
+        core.templates[-1].tag = ("con", m.constraints.index(cref) if False else id_index(m.constraints, cref))
         data.constraint_mappings[cref] = cref.mapping
 
 
@@ -376,8 +438,18 @@ def _add_derivative_approximations(core: ExaCore, data: ExaMappingData, m: Infin
         pref_itr = srt_itr.take(idxs)
         for a, col in zip(aliases, arg_cols):
             pref_itr = pref_itr.with_float(a, col)
+        sp = _shard(m)
+        if sp is not None and sp.group_index == pref_group:
+            # the window carries the stencil halo, so every local row of a backward difference
+            # belongs to an owned support
+            if method[0] != "fd_backward":
+                raise NotImplementedError("sharding along a parameter supports backward differences only")
+            keep = idxs >= sp.own_lo
+            assert keep.all(), "halo does not cover the stencil"
+        if _rank0_only(group_idxs, m):
+            continue
         if len(group_idxs) > 1:
-            itr = _product_itr([pref_itr if g == pref_group else data.base_itrs[g - 1] for g in group_idxs])
+            itr = _product_itr([pref_itr if g == pref_group else owned(g, data, m) for g in group_idxs])
         else:
             itr = pref_itr
         data_src = N.DataSource()
@@ -385,6 +457,7 @@ def _add_derivative_approximations(core: ExaCore, data: ExaMappingData, m: Infin
             dref, vref, pref, data_src[data.group_alias[pref_group - 1]], data_src, data, method,
             [data_src[a] for a in aliases])
         core.add_con(em_expr, itr)
+        core.templates[-1].tag = ("deriv", id_index(m.derivatives, dref))
 
 
 # 10 --------------------------------------------------------------------------------
@@ -396,8 +469,14 @@ def _add_collocation_restrictions(core: ExaCore, data: ExaMappingData, m: Infini
 
 # 11 --------------------------------------------------------------------------------
 def _add_generic_objective_term(core: ExaCore, expr, data: ExaMappingData):
+    data.obj_terms += 1
+    sp = _shard(data.model) if data.model is not None else None
+    if sp is not None and sp.rank != 0:
+        return None   # finite objective terms are counted once (rank 0)
     em_expr = _finalize_expr(_exafy(expr, {}, data))
-    return core.add_obj(em_expr, Items.single())
+    out = core.add_obj(em_expr, Items.single())
+    core.templates[-1].tag = ("obj", data.obj_terms)
+    return out
 
 
 def _measure_data(mref: MeasureRef):
@@ -419,8 +498,12 @@ def _make_measure_itr(mref: MeasureRef, data: ExaMappingData) -> Items:
     supps, coeffs = _measure_data(mref)
     g = mref.prefs[0].group
     assert len(mref.prefs) == len(g.prefs)  # no partially measured dependent parameters (:628)
-    alias = data.group_alias[g.index - 1]
     itr = data.base_itrs[g.index - 1]      # measure supports == group supports, in order
+    sp = _shard(data.model) if data.model is not None else None
+    if sp is not None and sp.group_index == g.index:
+        if sp.coeffs is not None:
+            coeffs = sp.coeffs             # weights of the local supports on the GLOBAL grid
+        return itr.with_float("c", coeffs).select(sp.own_lo, sp.own_n)
     return itr.with_float("c", coeffs)
 
 
@@ -472,9 +555,14 @@ def _process_measure_sum(vref: MeasureRef, data: ExaMappingData, prev_itr: Optio
 def _add_objective_aff_term(core: ExaCore, coef, vref: VariableRef, data: ExaMappingData) -> None:
     if isinstance(vref, MeasureRef):
         mexpr, itr = _process_measure_sum(vref, data)
+        data.obj_terms += 1
+        sp = _shard(data.model) if data.model is not None else None
+        if sp is not None and sp.rank != 0 and f"group_idx{sp.group_index}" not in itr.fields:
+            return   # a measure that does not run over the sharded parameter: rank 0 only
         data_src = N.DataSource()
         em_expr = data_src.c * _exafy(coef * mexpr, data_src, data)
         core.add_obj(_finalize_expr(em_expr), itr)
+        core.templates[-1].tag = ("obj", data.obj_terms)
     else:
         _add_generic_objective_term(core, coef * vref, data)
 
@@ -486,7 +574,11 @@ def _add_objective(core: ExaCore, expr, data: ExaMappingData, m: InfiniteModel) 
         for coef, vref in expr.linear_terms():
             _add_objective_aff_term(core, coef, vref, data)
         if expr.constant != 0.0:
-            core.add_obj(N.Null(expr.constant))
+            data.obj_terms += 1
+            sp = _shard(m)
+            if sp is None or sp.rank == 0:
+                core.add_obj(N.Null(expr.constant))
+                core.templates[-1].tag = ("obj", data.obj_terms)
     elif isinstance(expr, QuadExpr):
         for coef, v1, v2 in expr.quad_terms():
             if isinstance(v1, MeasureRef) and isinstance(v2, MeasureRef):
@@ -506,6 +598,7 @@ def _add_objective(core: ExaCore, expr, data: ExaMappingData, m: InfiniteModel) 
 
 def build_exa_core(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> ExaCore:
     """``build_exa_core!`` (transform.jl:771-796)."""
+    data.model = m
     _build_base_iterators(data, m)
     _add_finite_parameters(core, data, m)
     _add_finite_variables(core, data, m)

@@ -12,12 +12,15 @@ from . import infinite as io
 from .infinite import InfiniteModel
 
 
-def quadrotor(num_supports: int = 100, backend=None) -> InfiniteModel:
+def quadrotor(num_supports: int = 100, backend=None, supports=None) -> InfiniteModel:
     """``/root/reference/examples/quadrotor.jl:6-77`` — 9 states, 4 controls, T = 60,
     backward finite differences (InfiniteOpt default)."""
     n, p, T = 9, 4, 60.0
     im = InfiniteModel(backend)
-    t = im.infinite_parameter("t", 0.0, T, num_supports=num_supports)           # :19
+    if supports is not None:   # explicit support window (shard.py)
+        t = im.infinite_parameter("t", 0.0, T, supports=supports)
+    else:
+        t = im.infinite_parameter("t", 0.0, T, num_supports=num_supports)       # :19
     d1 = im.parameter_function("d1", lambda t: np.sin(2 * np.pi * t / T), t)        # :21
     d3 = im.parameter_function("d3", lambda t: 2 * np.sin(4 * np.pi * t / T), t)    # :22
     d5 = im.parameter_function("d5", lambda t: 2 * (t / T), t)                      # :23
@@ -44,7 +47,7 @@ def quadrotor(num_supports: int = 100, backend=None) -> InfiniteModel:
     return im
 
 
-def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None) -> InfiniteModel:
+def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None, xi_supports=None) -> InfiniteModel:
     """``/root/reference/ESCAPE34/pandemic.jl:4-34`` — SIR optimal control.
     ξ supports are synthetic (equispaced in [0.1, 0.6]) instead of Julia-RNG
     ``Uniform(0.1, 0.6)`` draws (``:16``)."""
@@ -52,7 +55,8 @@ def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None) -> I
     extra_ts = [0.001, 0.002, 0.004, 0.008, 0.02, 0.04, 0.08, 0.2, 0.4, 0.8]         # :11
     im = InfiniteModel(backend)
     t = im.infinite_parameter("t", 0.0, 200.0, num_supports=num_supports)            # :15
-    xi = im.infinite_parameter("ξ", supports=np.linspace(0.1, 0.6, num_scenarios))   # :16
+    xi = im.infinite_parameter("ξ", supports=(xi_supports if xi_supports is not None
+                                              else np.linspace(0.1, 0.6, num_scenarios)))   # :16
     im.add_supports(t, extra_ts)                                                     # :17
     s = im.variable("s", t, xi, lb=0)                                                # :18-21
     e = im.variable("e", t, xi, lb=0)
@@ -73,7 +77,13 @@ def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None) -> I
     return im
 
 
-def farmer(num_scenarios: int = 1000, seed: int = 42, backend=None) -> InfiniteModel:
+def farmer_supports(num_scenarios: int, seed: int = 42) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return np.column_stack([rng.uniform(0, 5, num_scenarios), rng.uniform(0, 5, num_scenarios),
+                            rng.uniform(10, 30, num_scenarios)])
+
+
+def farmer(num_scenarios: int = 1000, seed: int = 42, backend=None, supports=None) -> InfiniteModel:
     """``/root/reference/examples/2stage_example.jl:7-37`` — two-stage stochastic farmer.
     ξ supports: seeded numpy uniforms on the ranges of ``Ξ`` (``:15``)."""
     alpha = [150, 230, 260]
@@ -81,9 +91,7 @@ def farmer(num_scenarios: int = 1000, seed: int = 42, backend=None) -> InfiniteM
     lam = [170, 150, 36]
     dem = [200, 240, 0]
     xbar, wbar3, ybar3 = 500, 6000, 0
-    rng = np.random.default_rng(seed)
-    supp = np.column_stack([rng.uniform(0, 5, num_scenarios), rng.uniform(0, 5, num_scenarios),
-                            rng.uniform(10, 30, num_scenarios)])
+    supp = supports if supports is not None else farmer_supports(num_scenarios, seed)
     im = InfiniteModel(backend)
     xi = im.dependent_parameters(["ξ[1]", "ξ[2]", "ξ[3]"], supp)                      # :21
     x = [im.variable(f"x[{c + 1}]", lb=0, ub=xbar) for c in range(3)]                # :23
