@@ -1,0 +1,167 @@
+"""Host mirror of src/transform.jl against the reference's own structural assertions
+(/root/reference/test/transcription.jl, test/ipopt.jl:183-186, test/solve.jl:190-204)."""
+import numpy as np
+import pytest
+
+import cases
+from infiniteexamodels.jl_amd import infinite as io
+from infiniteexamodels.jl_amd import transcribe
+from infiniteexamodels.jl_amd.core import ExaCore, T_CON, T_OBJ
+from infiniteexamodels.jl_amd.infinite import DomainRestriction, InfiniteModel
+from infiniteexamodels.jl_amd.nodes import Var
+
+
+def test_mapping_initializers():
+    """test/transcription.jl:1-89 — variable blocks, function-valued bounds, semi-infinite
+    and point overrides."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    x = m.infinite_parameter("x", -1, 1, num_supports=5)   # 3 supports + collocation nodes in the reference
+    y = m.variable("y", t, lb=np.cos, ub=1)
+    q = m.variable("q", t, x, fix=42)
+    w = m.variable("w", x, lb=2, ub=np.sin, start=np.cos)
+    y0, y1 = y(0), y(1)
+    y0.info.start = 0.5
+    y1.info.lb, y1.info.ub = float("nan"), 0.8      # delete_lower_bound + set_upper_bound
+    q0, q1 = q(0, x), q(1, x)
+    q0.info.start = 10
+    q1.info.fix = 5
+    d1 = m.deriv(y, t)
+    z = m.variable("z", start=10)
+    c, data = ExaCore(), transcribe.ExaMappingData()
+    transcribe._build_base_iterators(data, m)
+    assert len(data.base_itrs) == 2
+    transcribe._add_finite_variables(c, data, m)
+    v = data.finvar_mappings[z]
+    assert v == Var(1) and c.x0[0] == 10 and c.lvar[0] == -np.inf and c.uvar[0] == np.inf   # :29-36
+    transcribe._add_infinite_variables(c, data, m)
+    yv = data.infvar_mappings[y]
+    assert yv.length == 5
+    np.testing.assert_array_equal(c.lvar[yv.offset:yv.offset + 5], np.cos(np.linspace(0, 1, 5)))   # :45
+    np.testing.assert_array_equal(c.uvar[yv.offset:yv.offset + 5], np.ones(5))
+    qv = data.infvar_mappings[q]
+    assert qv.length == 25
+    assert (c.lvar[qv.offset:qv.offset + 25] == 42).all() and (c.uvar[qv.offset:qv.offset + 25] == 42).all()
+    wv = data.infvar_mappings[w]
+    np.testing.assert_array_equal(c.lvar[wv.offset:wv.offset + 5], np.full(5, 2.0))
+    np.testing.assert_array_equal(c.uvar[wv.offset:wv.offset + 5], np.sin(np.linspace(-1, 1, 5)))     # :57
+    np.testing.assert_array_equal(c.x0[wv.offset:wv.offset + 5], np.cos(np.linspace(-1, 1, 5)))
+    assert data.infvar_mappings[d1].length == 5
+    transcribe._add_semi_infinite_variables(c, data, m)
+    assert len(data.semivar_info) == 2
+    assert c.x0[qv[1, 2].i - 1] == 10                                     # :72
+    assert c.lvar[qv[5, 3].i - 1] == 5 and c.uvar[qv[5, 4].i - 1] == 5    # :74-75
+    assert c.x0[qv[5, 2].i - 1] == 0
+    transcribe._add_point_variables(c, data, m)
+    assert len(data.finvar_mappings) == 3
+    p0 = data.finvar_mappings[y0]
+    assert c.x0[p0.i - 1] == 0.5 and c.lvar[p0.i - 1] == np.cos(0)        # :82-83
+    p1 = data.finvar_mappings[y1]
+    assert c.lvar[p1.i - 1] == -np.inf and c.uvar[p1.i - 1] == 0.8        # :86-87
+
+
+def test_finite_parameters_go_to_theta():
+    """test/transcription.jl:91-127."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    x = m.finite_parameter("x", 42)
+    ys = [m.finite_parameter(f"y[{i}]", v) for i, v in enumerate([20, 30])]
+    v = m.variable("v", t, lb=0, ub=100)
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(m, data)
+    assert len(data.param_mappings) == 3 and core.npar == 3
+    assert core.theta[data.param_mappings[x].offset] == 42
+    assert [core.theta[data.param_mappings[p].offset] for p in ys] == [20, 30]
+
+
+def test_parameter_functions_column_major():
+    """test/transcription.jl:129-175: θ holds pf values, first parameter fastest."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    s = m.infinite_parameter("s", 2, 3, num_supports=5)
+    v = m.variable("v", t, lb=0, ub=100)
+    pf = m.parameter_function("pf", np.sin, t)
+    pf2 = m.parameter_function("pf2", lambda t, s: np.cos(t) * s, t, s)
+    m.constraint(v + pf <= 100)
+    m.constraint(v * 2 + pf * pf2 <= 100)
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(m, data)
+    p1, p2 = data.param_mappings[pf], data.param_mappings[pf2]
+    assert p1.length == 5 and p2.length == 25 and core.npar == 30
+    tv, sv = np.array([0., .25, .5, .75, 1.]), np.array([2, 2.25, 2.5, 2.75, 3])
+    np.testing.assert_array_equal(core.theta[p1.offset:p1.offset + 5], np.sin(tv))                      # :151
+    np.testing.assert_array_equal(core.theta[p2.offset:p2.offset + 25],
+                                  np.array([np.cos(a) * b for b in sv for a in tv]))                    # :164
+
+
+def test_theta_literal_vector_of_solve_jl():
+    """test/solve.jl:190-191 — the θ of pf2(t,s) = sin(t)·s + 0.2 on 3×3 supports, digit for digit."""
+    m, (pf1, pf2) = cases.pfun()
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(m, data)
+    p1, p2 = data.param_mappings[pf1], data.param_mappings[pf2]
+    expected = [0.2, 1.158851077208406, 1.882941969615793, 0.2, 1.3985638465105075, 2.3036774620197416,
+                0.2, 1.638276615812609, 2.7244129544236895]
+    np.testing.assert_array_equal(core.theta[p1.offset:p1.offset + 3], np.sin([0.0, 0.5, 1.0]))
+    np.testing.assert_array_equal(core.theta[p2.offset:p2.offset + 9], expected)
+
+
+def test_domain_restriction_item_count():
+    """test/transcription.jl:211-218."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=10)
+    y = m.variable("y", t)
+    m.constraint(y ** 2 >= 2, restriction=DomainRestriction(lambda s: s >= 0.5, t))
+    core = transcribe.exa_core(m)
+    con = [tp for tp in core.templates if tp.kind == T_CON]
+    assert len(con[0].items) == int((t.supports >= 0.5).sum())
+
+
+def test_warmstart_problem_sizes_and_starts():
+    """test/ipopt.jl:183-186: x0 == [10, 0, …] (length 51), y0 == zeros(70)."""
+    core = transcribe.exa_core(cases.ode_5x5())
+    expected = np.zeros(51)
+    expected[0] = 10.0
+    np.testing.assert_array_equal(core.x0, expected)
+    assert core.ncon == 70
+
+
+def test_objective_heuristics_accept_and_warn():
+    """test/transcription.jl:177-209: nested measures with movable terms build one template;
+    the 'not so good' forms take the (unbuilt) expansion fallback with the reference's warning."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=3)
+    x1 = m.infinite_parameter("x1", -1, 1, num_supports=5)
+    x2 = m.infinite_parameter("x2", -1, 1, num_supports=5)
+    y = m.variable("y", t, x1, x2)
+    q = m.variable("q", t)
+    z = m.variable("z")
+    x1_int = m.integral(y ** 2, x1)
+    ok = [m.integral(m.integral(x1_int, x2), t),
+          m.integral(m.integral(x1_int, x2) + 2 * q ** 2, t),
+          m.integral(m.integral(x1_int, x2) * io.sin(q), t),
+          m.integral(m.integral(x1_int, x2) + 2 * q, t),
+          m.integral(m.integral(x1_int, x2) + io.sin(q), t)]
+    for obj in ok:
+        m.objective("min", obj)
+        core = transcribe.exa_core(m)
+        objs = [tp for tp in core.templates if tp.kind == T_OBJ]
+        assert len(objs) == 1 and len(objs[0].items) == 3 * 5 * 5
+    bad = [m.integral(m.integral(x1_int ** 2, x2), t), m.integral(m.integral(io.sin(x1_int), x2), t)]
+    for obj in bad:
+        m.objective("min", obj)
+        with pytest.warns(UserWarning, match="Unable to convert objective measures"):
+            with pytest.raises(NotImplementedError):
+                transcribe.exa_core(m)
+
+
+def test_build_order_matches_build_exa_core():
+    """transform.jl:777-794: user constraints → derivative approximations → objective."""
+    core = cases.build_core("quadrotor_5")
+    tags = [t.tag[0] for t in core.templates]
+    assert tags == ["con"] * 18 + ["deriv"] * 9 + ["obj"]
+    # product iterators run first-group-fastest (transform.jl:443-445)
+    core = cases.build_core("pandemic_20x3")
+    ode = core.templates[4]
+    cols = ode.items.column("group_idx1"), ode.items.column("group_idx2")
+    assert list(cols[0][:4]) == [1, 2, 3, 4] and list(cols[1][:4]) == [1, 1, 1, 1]
