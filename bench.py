@@ -164,6 +164,17 @@ def main():
         ms_dom = ms_hess if dom == "hess" else ms_jac
         achieved = alg / (ms_dom * 1e-3) / 1e9
         pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process
+        # (they need rocprofv3 passes of their own): taken from the committed profile of the
+        # same command and size (tools/profile_gpu.sh → profiles/), null otherwise.
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "r01_rocprof_quadrotor_1e6.json")
+        if os.path.exists(prof) and S_local == 1_000_000 and world == 1:
+            try:
+                traffic = json.load(open(prof))["pmc"][kd["name"]]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_rocprof_quadrotor_1e6.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            except Exception:
+                traffic = None
         line = {
             "metric": "jac_coord!+hess_coord! evals/sec, quadrotor 1e6 supports; % HBM roofline",
             "value": value, "unit": "jac+hess pairs/s (1e6-support quadrotor equivalent)",
@@ -175,7 +186,7 @@ def main():
                        "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
                        "store_mode": args.store_mode, "parallelism": f"support-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes": alg, "kernel_ms": ms_dom,
                          "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
                          "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Config 3 of BASELINE.json: pandemic SIR (ESCAPE34/pandemic.jl), full NLPModels evaluation
+loop — obj, grad!, cons!, jac_coord!, hess_coord! in solver order — on one MI355X.
+
+  python tools/eval_loop.py [--nt 4990] [--nxi 100] [--iters 100] [--workload pandemic|farmer|quadrotor]
+
+Prints one JSON line with per-call device times (HIP events around each call on the launch
+stream) and the achieved HBM rate from the generator's algorithmic byte counts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+from infiniteexamodels.jl_amd import transcribe, workloads
+from infiniteexamodels.jl_amd.model import ExaModel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="pandemic")
+    ap.add_argument("--nt", type=int, default=4990)     # + 10 extra supports = 5000
+    ap.add_argument("--nxi", type=int, default=100)
+    ap.add_argument("--supports", type=int, default=100_000)
+    ap.add_argument("--iters", type=int, default=100)
+    args = ap.parse_args()
+    t0 = time.perf_counter()
+    if args.workload == "pandemic":
+        im = workloads.pandemic(args.nt, args.nxi)
+        desc = f"pandemic SIR, Nt={args.nt + 10} x Nxi={args.nxi} = {(args.nt + 10) * args.nxi} supports"
+    elif args.workload == "farmer":
+        im = workloads.farmer(args.supports)
+        desc = f"two-stage farmer, {args.supports} scenarios"
+    else:
+        im = workloads.quadrotor(args.supports)
+        desc = f"quadrotor, {args.supports} supports"
+    core = transcribe.exa_core(im)
+    gm = ExaModel(core, device=0)
+    t_build = time.perf_counter() - t0
+    rng = np.random.default_rng(0)
+    x = torch.tensor(np.abs(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)) + 0.05, device="cuda")
+    y = torch.tensor(np.random.default_rng(1).standard_normal(gm.meta.ncon), device="cuda")
+    g = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    c = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
+    jv = torch.empty(gm.meta.nnzj, dtype=torch.float64, device="cuda")
+    hv = torch.empty(gm.meta.nnzh, dtype=torch.float64, device="cuda")
+    calls = {
+        "obj": lambda: gm.obj(x), "grad": lambda: gm.grad(x, g), "cons": lambda: gm.cons(x, c),
+        "jac_coord": lambda: gm.jac_coord(x, jv), "hess_coord": lambda: gm.hess_coord(x, y, hv, obj_weight=1.0),
+    }
+    for f in calls.values():
+        for _ in range(5):
+            f()
+    torch.cuda.synchronize()
+    ms = {}
+    for name, f in calls.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms[name] = e0.elapsed_time(e1) / args.iters
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        for f in calls.values():
+            f()
+    torch.cuda.synchronize()
+    loop_ms = (time.perf_counter() - t0) / args.iters * 1e3
+    kinds = {"obj": "obj", "grad": "grad", "cons": "cons", "jac_coord": "jac", "hess_coord": "hess"}
+    bytes_ = {k: sum(kk["alg_bytes_read"] + kk["alg_bytes_written"] for kk in gm.kernels() if kk["kind"] == v)
+              for k, v in kinds.items()}
+    out = {
+        "workload": desc, "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
+        "n_kernels": gm.meta.n_kernels, "build_s": t_build, "loop_ms": loop_ms, "loops_per_s": 1e3 / loop_ms,
+        "ms": ms, "alg_bytes": bytes_,
+        "GBps": {k: (bytes_[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else None) for k in ms},
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
