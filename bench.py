@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--nt", type=int, default=1)
     ap.add_argument("--fma", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
+    ap.add_argument("--emulate-shard", default="", help="R/N: time shard R of an N-way sharded run on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     args = ap.parse_args()
@@ -94,13 +95,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # under torchrun (RANK set) the process group is always created — also at world 1, so the
+    # RCCL path of this script can be rehearsed on a one-GPU box
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
     iemlib.build_library()
     iemlib.set_option("store_mode", args.store_mode)
     iemlib.set_option("nt_stores", args.nt)
@@ -113,7 +121,10 @@ def main():
         S_global, S_local = args.supports * world, args.supports
     else:
         S_global, S_local = args.supports, None
-    if world == 1:
+    if args.emulate_shard:     # build shard R of N on this one GPU (no communication): "R/N"
+        er, ew = (int(v) for v in args.emulate_shard.split("/"))
+        core, S_local = shard.quadrotor_shard(args.supports * ew if args.scaling == "weak" else args.supports, er, ew)
+    elif world == 1:
         core = transcribe.exa_core(workloads.quadrotor(S_global))
         S_local = S_global
     else:
@@ -132,17 +143,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -194,8 +203,8 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        barrier()
         dist.destroy_process_group()
 
 
