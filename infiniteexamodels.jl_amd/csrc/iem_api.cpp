@@ -290,6 +290,7 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "lds_slots") == 0) { g_opt.lds_slots = (int)value; return IEM_OK; }
   if (std::strcmp(name, "reorder") == 0) { g_opt.reorder = (int)value; return IEM_OK; }
   if (std::strcmp(name, "min_waves") == 0) { g_opt.min_waves = (int)value; return IEM_OK; }
   if (std::strcmp(name, "fp_contract") == 0) { g_opt.fp_contract = (int)value; return IEM_OK; }

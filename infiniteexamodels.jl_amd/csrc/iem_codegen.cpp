@@ -859,6 +859,17 @@ class KernelBuilder {
     } else {
       for (size_t oi = 0; oi < outs_.size(); ++oi) order.push_back((int)oi);
     }
+    int batch_slots = 0;
+    const int lds_budget = std::max(opt_.lds_slots, max_ns);
+    std::vector<std::string> pending_flush;
+    auto flush_batch = [&]() {
+      if (pending_flush.empty()) return;
+      tail << "  __syncthreads();\n";
+      for (auto &f : pending_flush) tail << f;
+      tail << "  __syncthreads();\n";
+      pending_flush.clear();
+      batch_slots = 0;
+    };
     for (int oi : order) {
       auto &o = outs_[oi];
       const Template &t = m_.tpl[o.tpl];
@@ -876,14 +887,18 @@ class KernelBuilder {
         case KK_HESS: {
           int ns = (int)o.vals.size();
           bool scalar_tpl = std::find(g_.scalars.begin(), g_.scalars.end(), o.tpl) != g_.scalars.end();
-          tail << "  { const double r[" << ns << "] = {";
-          for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
-          tail << "};\n";
           if (opt_.store_mode == 2 && !scalar_tpl) {
+            // stage now, flush with the rest of the batch (one barrier pair per batch)
+            if (batch_slots + ns > lds_budget) flush_batch();
+            std::string rn = "r" + std::to_string(oi);
+            tail << "  const double " << rn << "[" << ns << "] = {";
+            for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
+            tail << "};\n";
+            tail << "  iem_stage<" << ns << ">(" << rn << ", lds_blk + " << (batch_slots * 256) << ");\n";
             // block-uniform position of lane 0 / slot 0 and the valid lane interval of this workgroup
             const IdxVal &pv = idx_[o.pos_idx];
             AffQ pb = pv.aff;
-            std::ostringstream gb;
+            std::ostringstream gb, fl;
             bool any = false;
             for (int d = 1; d < g_.nd; ++d) {
               if (o.qlo[d] > 0) { gb << (any ? " && " : "") << "q" << d << " >= " << coefstr(o.qlo[d]); any = true; }
@@ -891,11 +906,19 @@ class KernelBuilder {
             }
             int64_t k0 = pb.k[0];
             pb.k[0] = 0;
-            tail << "    const long long pb = " << aff_str(pb) << " + " << coefstr(k0) << " * qb0;\n";
-            tail << "    const int v0 = iem_clamp256(" << coefstr(o.qlo[0]) << " - qb0);\n";
-            tail << "    const int v1 = " << (any ? "(" + gb.str() + ") ? " : "") << "iem_clamp256(" << ip(std::min(o.qhi[0], g_.ext[0])) << " - qb0)"
-                 << (any ? " : v0" : "") << ";\n";
-            tail << "    iem_store_block<" << ns << ">(OUT, pb, v0, v1, r, lds_blk); }\n";
+            fl << "  { const long long pb = " << aff_str(pb) << " + " << coefstr(k0) << " * qb0;\n";
+            fl << "    const int v0 = iem_clamp256(" << coefstr(o.qlo[0]) << " - qb0);\n";
+            fl << "    const int v1 = " << (any ? "(" + gb.str() + ") ? " : "") << "iem_clamp256(" << ip(std::min(o.qhi[0], g_.ext[0])) << " - qb0)"
+               << (any ? " : v0" : "") << ";\n";
+            fl << "    iem_flush<" << ns << ">(OUT, pb, v0, v1, lds_blk + " << (batch_slots * 256) << "); }\n";
+            pending_flush.push_back(fl.str());
+            batch_slots += ns;
+            break;
+          }
+          tail << "  { const double r[" << ns << "] = {";
+          for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
+          tail << "};\n";
+          if (false) {
           } else if (use_lds && !scalar_tpl) tail << "    iem_store_rows<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r, lds_wave); }\n";
           else tail << "    iem_store_rows_direct<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r); }\n";
           break;
@@ -910,6 +933,7 @@ class KernelBuilder {
           break;
       }
     }
+    flush_batch();
     if (kind_ == KK_OBJ)
       tail << "  iem_block_partial(acc, OUT, A.ip[" << ip_index(kd.partial_off) << "] + (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * (long long)blockIdx.z), lds4);\n";
 
@@ -983,9 +1007,10 @@ class KernelBuilder {
       kd.lds_bytes = IEM_BLOCK_WAVES * 64 * max_ns * 8;
     }
     if (use_blk) {
-      os << "  __shared__ double lds_blk[" << (IEM_BLOCK_WAVES * 64 * max_ns) << "];\n";
+      const int budget = std::max(opt_.lds_slots, max_ns);
+      os << "  __shared__ double lds_blk[" << (IEM_BLOCK_WAVES * 64 * budget) << "];\n";
       os << "  const long long qb0 = (long long)blockIdx.x * IEM_BLOCK;\n";
-      kd.lds_bytes = IEM_BLOCK_WAVES * 64 * max_ns * 8;
+      kd.lds_bytes = IEM_BLOCK_WAVES * 64 * budget * 8;
     }
     if (kind_ == KK_OBJ) os << "  __shared__ double lds4[4];\n";
     os << head.str() << tail.str() << "}\n\n";

@@ -109,22 +109,39 @@ __device__ __forceinline__ void iem_store_rows(double *__restrict__ out, long lo
 // in q0, so validity is an interval); P0 = position of lane 0's slot 0 (block-uniform).
 __device__ __forceinline__ int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_BLOCK ? IEM_BLOCK : (int)v); }
 
+// The two halves of the block store, so that several templates can share one barrier pair:
+//   iem_stage<NS>  lane writes its NS values item-major into its template's LDS region
+//   __syncthreads()
+//   iem_flush<NS>  the workgroup writes the region out, re-cut at 128-byte boundaries
+//   __syncthreads()   (before the regions are reused)
 template <int NS>
-__device__ __forceinline__ void iem_store_block(double *__restrict__ out, long long P0, int v0, int v1,
-                                                const double (&v)[NS], double *__restrict__ lds_blk) {
+__device__ __forceinline__ void iem_stage(const double (&v)[NS], double *__restrict__ lds_reg) {
   const int t = (int)threadIdx.x;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) lds_blk[t * NS + s] = v[s];
-  __syncthreads();
+  for (int s = 0; s < NS; ++s) lds_reg[t * NS + s] = v[s];
+}
+
+template <int NS>
+__device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0, int v0, int v1,
+                                          const double *__restrict__ lds_reg) {
+  const int t = (int)threadIdx.x;
   const int e0 = v0 * NS, e1 = v1 * NS;  // valid element interval of the workgroup's block
   const int head = (int)((16 - ((P0 + e0) & 15)) & 15);
   double *__restrict__ dst = out + P0;
-  if (t < head && e0 + t < e1) iem_stg(dst + e0 + t, lds_blk[e0 + t]);
+  if (t < head && e0 + t < e1) iem_stg(dst + e0 + t, lds_reg[e0 + t]);
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int e = e0 + head + t + j * IEM_BLOCK;
-    if (e < e1) iem_stg(dst + e, lds_blk[e]);
+    if (e < e1) iem_stg(dst + e, lds_reg[e]);
   }
+}
+
+template <int NS>
+__device__ __forceinline__ void iem_store_block(double *__restrict__ out, long long P0, int v0, int v1,
+                                                const double (&v)[NS], double *__restrict__ lds_blk) {
+  iem_stage<NS>(v, lds_blk);
+  __syncthreads();
+  iem_flush<NS>(out, P0, v0, v1, lds_blk);
   __syncthreads();
 }
 

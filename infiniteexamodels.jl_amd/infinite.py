@@ -355,6 +355,15 @@ class InfiniteModel:
         self._ready = False
         return c
 
+    def constraint_interval(self, func, lower: float, upper: float, restriction: DomainRestriction = None,
+                            name: str = "") -> ConstraintObject:
+        """``@constraint(m, lower <= func <= upper)`` → MOI.Interval (transform.jl:405-407)."""
+        spec = ConstraintSpec(func if not is_number(func) else AffExpr(constant=func), "==")
+        c = self.constraint(spec, restriction, name)
+        off = -c.lb   # constant moved to the right-hand side by constraint()
+        c.lb, c.ub = float(lower) - off, float(upper) - off
+        return c
+
     def objective(self, sense: str, expr):
         assert sense in ("min", "max")
         self.objective_sense, self.objective_function = sense, expr

@@ -107,6 +107,22 @@ def farmer_shard(num_scenarios: int, rank: int, world: int, seed: int = 42, back
     return core, b - a
 
 
+def opf_shard(num_scenarios: int, rank: int, world: int, seed: int = 0, backend=None):
+    """Scenario-sharded stochastic AC-OPF (``ESCAPE34/opf.jl``): the first-stage network lives on
+    rank 0, first-stage variables are replicated, ramping rows couple them to every scenario."""
+    from . import workloads
+    supp = workloads.opf_supports(num_scenarios, seed)
+    a, b = partition(num_scenarios, world)[rank]
+    im = workloads.opf(supports=supp[a:b], backend=backend)
+    im.shard = ShardSpec(group_index=1, rank=rank, world=world, own_lo=0, own_n=b - a, global_lo=a,
+                         n_global=num_scenarios, coeffs=None)
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(im, data)
+    core._shard_data = data
+    core._shard_spec = im.shard
+    return core, b - a
+
+
 def pandemic_shard(num_supports: int, num_scenarios: int, rank: int, world: int, backend=None):
     """ξ-sharded pandemic SIR (``ESCAPE34/pandemic.jl``): t-stencils stay local, ``u(t)`` and
     the objective ∫u dt are replicated / rank-0 only."""

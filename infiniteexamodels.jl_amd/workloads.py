@@ -105,3 +105,123 @@ def farmer(num_scenarios: int = 1000, seed: int = 42, backend=None, supports=Non
     im.constraint(w[2] <= wbar3)                                                     # :35
     im.constraint(y[2] <= ybar3)                                                     # :36
     return im
+
+
+# ---------------------------------------------------------------------------
+# stochastic AC-OPF (ESCAPE34/opf.jl)
+# ---------------------------------------------------------------------------
+# The reference downloads pglib_opf_case3_lmbd.m at run time (ESCAPE34/opf.jl:15-18) and reads
+# it through PowerModels; neither is available here, so a 3-bus / 3-generator / 3-branch network
+# of the same shape is embedded in per-unit (baseMVA 100).  Values are synthetic stand-ins in
+# the range of that case, NOT a copy of the pglib file.
+OPF_NETWORK = dict(
+    bus={1: dict(vmin=0.9, vmax=1.1, pd=1.10, qd=0.40, gs=0.0, bs=0.0),
+         2: dict(vmin=0.9, vmax=1.1, pd=1.10, qd=0.40, gs=0.0, bs=0.0),
+         3: dict(vmin=0.9, vmax=1.1, pd=0.95, qd=0.50, gs=0.0, bs=0.0)},
+    ref_buses=[1],
+    gen={1: dict(bus=1, pmin=0.0, pmax=20.0, qmin=-10.0, qmax=10.0, cost=(1100.0, 500.0, 0.0)),
+         2: dict(bus=2, pmin=0.0, pmax=20.0, qmin=-10.0, qmax=10.0, cost=(850.0, 120.0, 0.0)),
+         3: dict(bus=3, pmin=0.0, pmax=0.0, qmin=-10.0, qmax=10.0, cost=(0.0, 0.0, 0.0))},
+    branch={1: dict(f_bus=1, t_bus=3, r=0.065, x=0.620, b_c=0.450, rate_a=90.0, angmin=-0.5236, angmax=0.5236),
+            2: dict(f_bus=3, t_bus=2, r=0.025, x=0.750, b_c=0.700, rate_a=0.5, angmin=-0.5236, angmax=0.5236),
+            3: dict(f_bus=1, t_bus=2, r=0.042, x=0.900, b_c=0.300, rate_a=90.0, angmin=-0.5236, angmax=0.5236)},
+)
+
+
+def opf_supports(num_supports: int, seed: int = 0, net=OPF_NETWORK) -> np.ndarray:
+    """Load perturbations θ ~ N(0, (0.1·[Pd; Qd])²) (opf.jl:46-52, :112), seeded numpy draws."""
+    bus = net["bus"]
+    std = 0.1 * np.array([bus[i]["pd"] for i in sorted(bus)] + [bus[i]["qd"] for i in sorted(bus)])
+    return np.random.default_rng(seed).standard_normal((num_supports, len(std))) * std
+
+
+def opf(num_supports: int = 100, seed: int = 0, backend=None, supports=None, net=OPF_NETWORK) -> InfiniteModel:
+    """``/root/reference/ESCAPE34/opf.jl:36-285`` — two-stage stochastic AC-OPF: first-stage
+    (finite) dispatch, per-scenario recourse network coupled through ramping rows.  Julia ``Dict``
+    iteration order of buses/generators is replaced by sorted keys."""
+    bus, gen, brs = net["bus"], net["gen"], net["branch"]
+    nbus = len(bus)
+    branch = []
+    for l in sorted(brs):
+        br = brs[l]
+        den = br["r"] ** 2 + br["x"] ** 2
+        g, b = br["r"] / den, -br["x"] / den              # PowerModels.calc_branch_y
+        tr, ti = 1.0, 0.0                                  # calc_branch_t (tap 1, shift 0)
+        branch.append(dict(f_bus=br["f_bus"], t_bus=br["t_bus"], f_idx=(l, br["f_bus"], br["t_bus"]),
+                           t_idx=(l, br["t_bus"], br["f_bus"]), g=g, b=b, tr=tr, ti=ti, ttm=tr ** 2 + ti ** 2,
+                           g_fr=0.0, b_fr=br["b_c"] / 2, g_to=0.0, b_to=br["b_c"] / 2,
+                           angmin=br["angmin"], angmax=br["angmax"], rate_a=br["rate_a"]))
+    arcs = [b["f_idx"] for b in branch] + [b["t_idx"] for b in branch]
+    bus_arcs = {i: [a for a in arcs if a[1] == i] for i in bus}
+    bus_gens = {i: [k for k in sorted(gen) if gen[k]["bus"] == i] for i in bus}
+    cos, sin = io.cos, io.sin
+
+    im = InfiniteModel(backend)
+    # first stage variables (opf.jl:83-109)
+    va0 = {i: im.variable(f"va0[{i}]") for i in sorted(bus)}
+    vm0 = {i: im.variable(f"vm0[{i}]", lb=bus[i]["vmin"], ub=bus[i]["vmax"], start=1.0) for i in sorted(bus)}
+    pg0 = {k: im.variable(f"pg0[{k}]", lb=gen[k]["pmin"], ub=gen[k]["pmax"]) for k in sorted(gen)}
+    qg0 = {k: im.variable(f"qg0[{k}]", lb=gen[k]["qmin"], ub=gen[k]["qmax"]) for k in sorted(gen)}
+    p0 = {a: im.variable(f"p0{a}", lb=-brs[a[0]]["rate_a"], ub=brs[a[0]]["rate_a"]) for a in arcs}
+    q0 = {a: im.variable(f"q0{a}", lb=-brs[a[0]]["rate_a"], ub=brs[a[0]]["rate_a"]) for a in arcs}
+    # second stage (opf.jl:112-140)
+    supp = supports if supports is not None else opf_supports(num_supports, seed, net)
+    th = im.dependent_parameters([f"θ[{i + 1}]" for i in range(2 * nbus)], supp)
+    va = {i: im.variable(f"va[{i}]", *th) for i in sorted(bus)}
+    vm = {i: im.variable(f"vm[{i}]", *th, lb=bus[i]["vmin"], ub=bus[i]["vmax"], start=1.0) for i in sorted(bus)}
+    pg = {k: im.variable(f"pg[{k}]", *th, lb=gen[k]["pmin"], ub=gen[k]["pmax"]) for k in sorted(gen)}
+    qg = {k: im.variable(f"qg[{k}]", *th, lb=gen[k]["qmin"], ub=gen[k]["qmax"]) for k in sorted(gen)}
+    p = {a: im.variable(f"p{a}", *th, lb=-brs[a[0]]["rate_a"], ub=brs[a[0]]["rate_a"]) for a in arcs}
+    q = {a: im.variable(f"q{a}", *th, lb=-brs[a[0]]["rate_a"], ub=brs[a[0]]["rate_a"]) for a in arcs}
+
+    im.objective("min", sum(gen[k]["cost"][0] * pg0[k] ** 2 + gen[k]["cost"][1] * pg0[k] + gen[k]["cost"][2]
+                            for k in sorted(gen)))                                  # :142-146
+
+    def network(VA, VM, PG, QG, P, Q, load_p, load_q):
+        for i in net["ref_buses"]:
+            im.constraint(VA[i] == 0)                                               # :149 / :213
+        for br in branch:                                                           # :150-157
+            f, t = br["f_bus"], br["t_bus"]
+            im.constraint(P[br["f_idx"]] ==
+                          (br["g"] + br["g_fr"]) / br["ttm"] * VM[f] ** 2 +
+                          (-br["g"] * br["tr"] + br["b"] * br["ti"]) / br["ttm"] * (VM[f] * VM[t] * cos(VA[f] - VA[t])) +
+                          (-br["b"] * br["tr"] - br["g"] * br["ti"]) / br["ttm"] * (VM[f] * VM[t] * sin(VA[f] - VA[t])))
+        for br in branch:                                                           # :158-165
+            f, t = br["f_bus"], br["t_bus"]
+            im.constraint(Q[br["f_idx"]] ==
+                          -(br["b"] + br["b_fr"]) / br["ttm"] * VM[f] ** 2 -
+                          (-br["b"] * br["tr"] - br["g"] * br["ti"]) / br["ttm"] * (VM[f] * VM[t] * cos(VA[f] - VA[t])) +
+                          (-br["g"] * br["tr"] + br["b"] * br["ti"]) / br["ttm"] * (VM[f] * VM[t] * sin(VA[f] - VA[t])))
+        for br in branch:                                                           # :168-175
+            f, t = br["f_bus"], br["t_bus"]
+            im.constraint(P[br["t_idx"]] ==
+                          (br["g"] + br["g_to"]) * VM[t] ** 2 +
+                          (-br["g"] * br["tr"] - br["b"] * br["ti"]) / br["ttm"] * (VM[t] * VM[f] * cos(VA[t] - VA[f])) +
+                          (-br["b"] * br["tr"] + br["g"] * br["ti"]) / br["ttm"] * (VM[t] * VM[f] * sin(VA[t] - VA[f])))
+        for br in branch:                                                           # :176-183
+            f, t = br["f_bus"], br["t_bus"]
+            im.constraint(Q[br["t_idx"]] ==
+                          -(br["b"] + br["b_to"]) * VM[t] ** 2 -
+                          (-br["b"] * br["tr"] + br["g"] * br["ti"]) / br["ttm"] * (VM[t] * VM[f] * cos(VA[t] - VA[f])) +
+                          (-br["g"] * br["tr"] - br["b"] * br["ti"]) / br["ttm"] * (VM[t] * VM[f] * sin(VA[t] - VA[f])))
+        for br in branch:                                                           # :186 / :250
+            im.constraint_interval(VA[br["f_bus"]] - VA[br["t_bus"]], br["angmin"], br["angmax"])
+        for br in branch:                                                           # :189-190
+            im.constraint(P[br["f_idx"]] ** 2 + Q[br["f_idx"]] ** 2 <= br["rate_a"])
+        for br in branch:
+            im.constraint(P[br["t_idx"]] ** 2 + Q[br["t_idx"]] ** 2 <= br["rate_a"])
+        for i in sorted(bus):                                                       # :193-210 / :257-278
+            im.constraint(sum(P[a] for a in bus_arcs[i]) ==
+                          load_p(i) + sum(PG[g] for g in bus_gens[i]) - bus[i]["pd"] - bus[i]["gs"] * VM[i] ** 2)
+            im.constraint(sum(Q[a] for a in bus_arcs[i]) ==
+                          load_q(i) + sum(QG[g] for g in bus_gens[i]) - bus[i]["qd"] + bus[i]["bs"] * VM[i] ** 2)
+
+    network(va0, vm0, pg0, qg0, p0, q0, lambda i: 0.0, lambda i: 0.0)
+    network(va, vm, pg, qg, p, q, lambda i: th[i - 1], lambda i: th[nbus + i - 1])
+    for k in sorted(gen):                                                           # :282-283
+        d = 0.1 * (gen[k]["pmax"] - gen[k]["pmin"])
+        im.constraint_interval(pg0[k] - pg[k], -d, d)
+    for k in sorted(gen):
+        d = 0.1 * (gen[k]["qmax"] - gen[k]["qmin"])
+        im.constraint_interval(qg0[k] - qg[k], -d, d)
+    return im

@@ -760,21 +760,24 @@ void orc_jac_structure(const orc_model *m, int64_t *rows, int64_t *cols, int bas
 }
 
 void orc_jac_coord(const orc_model *m, const double *x, double *vals) {
-  memset(vals, 0, sizeof(double) * m->nnzj); /* ExaModels: fill!(jac, 0) then += */
-  for (int64_t i = 0; i < m->n_tpl; ++i) {
-    const otpl *t = &m->tpl[i];
-    if (t->kind != IEM_T_CON) continue;
+  /* ExaModels: fill!(jac, 0), then one serial "+=" loop per template.  The OpenMP variant
+   * (cpu_baseline "all cores") keeps one parallel region per call; items are independent. */
 #pragma omp parallel num_threads(g_threads)
-    {
-      scratch *s = scratch_new(m);
+  {
+    scratch *s = scratch_new(m);
 #pragma omp for schedule(static)
+    for (int64_t j = 0; j < m->nnzj; ++j) vals[j] = 0.0;
+    for (int64_t i = 0; i < m->n_tpl; ++i) {
+      const otpl *t = &m->tpl[i];
+      if (t->kind != IEM_T_CON) continue;
+#pragma omp for schedule(static) nowait
       for (int64_t k = 0; k < t->n_items; ++k) {
         forward(m, t, k, x, s, 1);
         rctx c = {t, s, NULL, vals + t->o1 + (int64_t)t->o1step * k};
         grpass(&c, t->root, 0, 1.0);
       }
-      scratch_free(s);
     }
+    scratch_free(s);
   }
 }
 
@@ -798,21 +801,22 @@ void orc_hess_structure(const orc_model *m, int64_t *rows, int64_t *cols, int ba
 
 /* Hessian of  obj_weight*f(x) + sum_k y_k c_k(x)  (NLPModels hess_coord!(m, x, y, vals; obj_weight)) */
 void orc_hess_coord(const orc_model *m, const double *x, const double *y, double obj_weight, double *vals) {
-  memset(vals, 0, sizeof(double) * m->nnzh);
-  for (int64_t i = 0; i < m->n_tpl; ++i) {
-    const otpl *t = &m->tpl[i];
-    if (t->o2step == 0) continue;
 #pragma omp parallel num_threads(g_threads)
-    {
-      scratch *s = scratch_new(m);
+  {
+    scratch *s = scratch_new(m);
 #pragma omp for schedule(static)
+    for (int64_t j = 0; j < m->nnzh; ++j) vals[j] = 0.0;
+    for (int64_t i = 0; i < m->n_tpl; ++i) {
+      const otpl *t = &m->tpl[i];
+      if (t->o2step == 0) continue;
+#pragma omp for schedule(static) nowait
       for (int64_t k = 0; k < t->n_items; ++k) {
         forward(m, t, k, x, s, 2);
         hctx c = {t, s, vals + t->o2 + (int64_t)t->o2step * k};
         double adj = t->kind == IEM_T_OBJ ? obj_weight : y[t->o0 + k];
         hrpass0(&c, t->root, 0, adj, 0.0);
       }
-      scratch_free(s);
     }
+    scratch_free(s);
   }
 }

@@ -110,6 +110,8 @@ def small_cases():
         "pandemic_300x7": lambda: workloads.pandemic(300, 7),
         "farmer_5": lambda: workloads.farmer(5),
         "farmer_1000": lambda: workloads.farmer(1000),
+        "opf_7": lambda: workloads.opf(7),
+        "opf_600": lambda: workloads.opf(600),
         "ode_5x5": ode_5x5,
         "test_problem_1": test_problem_1,
         "rosenbrock": lambda: rosenbrock()[0],
@@ -123,7 +125,7 @@ def eval_point_for(name, om, seed=0):
     """Seeded evaluation point kept inside every operator's domain."""
     rng = np.random.default_rng(seed)
     x = om.x0 + 0.1 * rng.standard_normal(om.nvar)
-    if name.startswith("quadrotor"):
+    if name.startswith("quadrotor") or name.startswith("opf"):
         pass
     elif name == "operator_zoo":
         n = om.nvar // 2

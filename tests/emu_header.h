@@ -35,6 +35,18 @@ inline void iem_store_block(double *out, long long P0, int v0, int v1, const dou
   const int t = (int)threadIdx.x;
   if (t >= v0 && t < v1) for (int s = 0; s < NS; ++s) out[P0 + (long long)t * NS + s] = v[s];
 }
+// split form: one lane at a time, the lane reads back its own staged values
+template <int NS>
+inline void iem_stage(const double (&v)[NS], double *lds_reg) {
+  const int t = (int)threadIdx.x;
+  for (int s = 0; s < NS; ++s) lds_reg[t * NS + s] = v[s];
+}
+template <int NS>
+inline void iem_flush(double *out, long long P0, int v0, int v1, const double *lds_reg) {
+  const int t = (int)threadIdx.x;
+  if (t >= v0 && t < v1) for (int s = 0; s < NS; ++s) out[P0 + (long long)t * NS + s] = lds_reg[t * NS + s];
+}
+inline void __syncthreads() {}
 inline void iem_block_partial(double v, double *partials, long long slot, double *) { partials[slot] += v; }
 inline void iem_grad_wave_uniform(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }
 inline void iem_grad_atomic(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }

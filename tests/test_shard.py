@@ -21,6 +21,8 @@ def _global(name, size):
         core = transcribe.exa_core(workloads.quadrotor(size), data)
     elif name == "farmer":
         core = transcribe.exa_core(workloads.farmer(size), data)
+    elif name == "opf":
+        core = transcribe.exa_core(workloads.opf(size), data)
     else:
         core = transcribe.exa_core(workloads.pandemic(size[0], size[1]), data)
     return core, data
@@ -31,6 +33,8 @@ def _shard(name, size, r, world):
         core, _ = shard.quadrotor_shard(size, r, world)
     elif name == "farmer":
         core, _ = shard.farmer_shard(size, r, world)
+    elif name == "opf":
+        core, _ = shard.opf_shard(size, r, world)
     else:
         core, _ = shard.pandemic_shard(size[0], size[1], r, world)
     return core
@@ -38,14 +42,14 @@ def _shard(name, size, r, world):
 
 def _point(om, name, seed=0):
     x = om.x0 + 0.1 * np.random.default_rng(seed).standard_normal(om.nvar)
-    if name != "quadrotor":
+    if name not in ("quadrotor", "opf"):
         x = np.abs(x) + 0.05
     y = np.random.default_rng(seed + 1).standard_normal(om.ncon)
     return x, y
 
 
 @pytest.mark.parametrize("name,size,world", [("quadrotor", 37, 3), ("quadrotor", 64, 2), ("quadrotor", 11, 8),
-                                             ("farmer", 23, 4), ("pandemic", (9, 7), 3)])
+                                             ("farmer", 23, 4), ("pandemic", (9, 7), 3), ("opf", 13, 8)])
 def test_shards_reassemble_to_global(name, size, world, built):
     gcore, gdata = _global(name, size)
     G = OracleModel(gcore.to_blob())

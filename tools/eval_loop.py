@@ -36,6 +36,9 @@ def main():
     if args.workload == "pandemic":
         im = workloads.pandemic(args.nt, args.nxi)
         desc = f"pandemic SIR, Nt={args.nt + 10} x Nxi={args.nxi} = {(args.nt + 10) * args.nxi} supports"
+    elif args.workload == "opf":
+        im = workloads.opf(args.supports)
+        desc = f"stochastic AC-OPF (3-bus synthetic network), {args.supports} scenarios"
     elif args.workload == "farmer":
         im = workloads.farmer(args.supports)
         desc = f"two-stage farmer, {args.supports} scenarios"
@@ -46,7 +49,8 @@ def main():
     gm = ExaModel(core, device=0)
     t_build = time.perf_counter() - t0
     rng = np.random.default_rng(0)
-    x = torch.tensor(np.abs(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)) + 0.05, device="cuda")
+    x0 = gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)
+    x = torch.tensor(x0 if args.workload in ("opf", "quadrotor") else np.abs(x0) + 0.05, device="cuda")
     y = torch.tensor(np.random.default_rng(1).standard_normal(gm.meta.ncon), device="cuda")
     g = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
     c = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
