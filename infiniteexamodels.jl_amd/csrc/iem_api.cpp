@@ -102,7 +102,7 @@ struct iem_model {
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
-  hipFunction_t fn_reduce = nullptr;
+  hipFunction_t fn_reduce = nullptr, fn_struct = nullptr;
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *h_obj = nullptr;  // pinned
   std::map<int, void *> d_arrays;  // model array id -> device copy
@@ -191,6 +191,7 @@ int compile_or_load(iem_model *m) {
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));
   HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_reduce_partials"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   return IEM_OK;
 }
 
@@ -244,6 +245,90 @@ struct ItemIdx {
     }
   }
 };
+
+// host mirrors of the device structs in iem_device.h
+struct IdxDescH {
+  long long c, k[3];
+  int ng, garr[3];
+  long long gcoef[3], gbase[3], gstep[3][3];
+};
+struct StructArgsH {
+  long long *rows, *cols;
+  const IdxDescH *ia, *ib;
+  const long long *const *iarrs;
+  long long dims0, dims1, n_items, o, o0, base;
+  int nslots;
+};
+
+IdxDescH make_idx_desc(const iem::Template &t, int idx_id, const std::map<int, int> &iarr_slot) {
+  IdxDescH d;
+  std::memset(&d, 0, sizeof d);
+  const iem::IdxExpr &ix = t.idx[idx_id];
+  d.c = ix.c0;
+  for (int j = 0; j < ix.nterms; ++j) {
+    const iem::FieldDesc &f = t.ifields[ix.field[j]];
+    if (f.mode == IEM_F_AFFINE) {
+      d.c += ix.coef[j] * f.base;
+      for (int dd = 0; dd < 3; ++dd) d.k[dd] += ix.coef[j] * f.step[dd];
+    } else {
+      int g = d.ng++;
+      d.garr[g] = iarr_slot.at(f.arr);
+      d.gcoef[g] = ix.coef[j];
+      d.gbase[g] = f.base;
+      for (int dd = 0; dd < 3; ++dd) d.gstep[g][dd] = f.step[dd];
+    }
+  }
+  return d;
+}
+
+int structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base, bool hess) {
+  // int64 columns referenced by index expressions → device table
+  std::map<int, int> slot;
+  std::vector<const long long *> ptrs;
+  for (const iem::Template &t : m->model.tpl)
+    for (const iem::FieldDesc &f : t.ifields)
+      if (f.mode == IEM_F_GATHER && !slot.count(f.arr)) {
+        int rc = upload_array(m, f.arr, true);
+        if (rc) return rc;
+        slot[f.arr] = (int)ptrs.size();
+        ptrs.push_back((const long long *)m->d_arrays[f.arr]);
+      }
+  const long long **d_ptrs = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_ptrs, std::max<size_t>(ptrs.size(), 1) * 8));
+  if (!ptrs.empty()) HIP_TRY(hipMemcpy(d_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice));
+  std::vector<void *> to_free{(void *)d_ptrs};
+  int rc = IEM_OK;
+  for (const iem::Template &t : m->model.tpl) {
+    int ns = hess ? t.o2step : t.o1step;
+    if (ns == 0 || (!hess && t.kind != IEM_T_CON)) continue;
+    std::vector<IdxDescH> a(ns), b(ns);
+    for (int s = 0; s < ns; ++s) {
+      a[s] = make_idx_desc(t, hess ? t.slot2_i[s] : t.slot1_idx[s], slot);
+      if (hess) b[s] = make_idx_desc(t, t.slot2_j[s], slot);
+    }
+    IdxDescH *da = nullptr, *db = nullptr;
+    HIP_TRY(hipMalloc((void **)&da, sizeof(IdxDescH) * ns));
+    to_free.push_back(da);
+    HIP_TRY(hipMemcpy(da, a.data(), sizeof(IdxDescH) * ns, hipMemcpyHostToDevice));
+    if (hess) {
+      HIP_TRY(hipMalloc((void **)&db, sizeof(IdxDescH) * ns));
+      to_free.push_back(db);
+      HIP_TRY(hipMemcpy(db, b.data(), sizeof(IdxDescH) * ns, hipMemcpyHostToDevice));
+    }
+    StructArgsH A{(long long *)d_rows, (long long *)d_cols, da, db, d_ptrs, t.dims[0], t.dims[1], t.n_items,
+                  hess ? t.o2 : t.o1, t.o0, base, ns};
+    size_t sz = sizeof A;
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    long long total = t.n_items * ns;
+    hipError_t e = hipModuleLaunchKernel(m->fn_struct, (unsigned)((total + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg);
+    if (e != hipSuccess) { rc = fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e)); break; }
+  }
+  hipError_t e = hipStreamSynchronize(m->stream);
+  for (void *p : to_free) hipFree(p);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e));
+  return IEM_OK;
+}
 
 void jac_structure_host(const iem::Model &m, int64_t *rows, int64_t *cols, int base) {
   for (const iem::Template &t : m.tpl) {
@@ -528,21 +613,13 @@ int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base)
 }
 
 int iem_jac_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
-  if (!m) return fail(IEM_E_ARG, "null handle");
-  std::vector<int64_t> r((size_t)m->model.nnzj), c((size_t)m->model.nnzj);
-  jac_structure_host(m->model, r.data(), c.data(), base);
-  HIP_TRY(hipMemcpy(d_rows, r.data(), r.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_cols, c.data(), c.size() * 8, hipMemcpyHostToDevice));
-  return IEM_OK;
+  if (!m || ((!d_rows || !d_cols) && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
+  return structure_device(m, d_rows, d_cols, base, false);
 }
 
 int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
-  if (!m) return fail(IEM_E_ARG, "null handle");
-  std::vector<int64_t> r((size_t)m->model.nnzh), c((size_t)m->model.nnzh);
-  hess_structure_host(m->model, r.data(), c.data(), base);
-  HIP_TRY(hipMemcpy(d_rows, r.data(), r.size() * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_cols, c.data(), c.size() * 8, hipMemcpyHostToDevice));
-  return IEM_OK;
+  if (!m || ((!d_rows || !d_cols) && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  return structure_device(m, d_rows, d_cols, base, true);
 }
 
 int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess, int iters,

@@ -28,7 +28,7 @@ struct KernelDesc {
 
 struct Options {
   int store_mode = 2;  // 0 direct strided stores, 1 wave-level LDS-transposed stores, 2 block-cooperative 128-B-aligned stores
-  int lds_slots = 12;  // store_mode 2: values per lane staged per barrier pair (LDS = 2 KB x this per workgroup)
+  int lds_slots = 24;  // store_mode 2: values per lane staged per barrier pair (LDS = 2 KB x this per workgroup)
   int reorder = 1;     // 1: emit cheap templates first so the store stream starts early
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
   int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels

@@ -187,10 +187,45 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_reduce_partials(cons
   if (threadIdx.x == 0) out[0] = lds[0];
 }
 
-// structure fill helpers (int64, one-off)
-extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_fill_i64(long long *__restrict__ p, long long n, long long v) {
-  const long long i = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;
-  if (i < n) p[i] = v;
+// ---- jac_structure! / hess_structure! on the device -----------------------------------------
+// One launch per template: thread e handles COO element e of the template's block
+// (item k = e / nslots, slot s = e % nslots), so rows/cols are written as two coalesced
+// int64 streams.  An index expression is  c + sum_d k[d]*k_d + sum_j gcoef[j]*IA[garr[j]][gbase[j] + sum_d gstep[j][d]*k_d]
+// (1-based variable index); Hessian entries are emitted lower-triangular (row >= col).
+struct IemIdxDesc {
+  long long c, k[3];
+  int ng, garr[3];
+  long long gcoef[3], gbase[3], gstep[3][3];
+};
+struct IemStructArgs {
+  long long *rows, *cols;
+  const IemIdxDesc *ia, *ib;       // per slot; ib == nullptr for the Jacobian
+  const long long *const *iarrs;   // device int64 columns
+  long long dims0, dims1, n_items, o, o0, base;
+  int nslots;
+};
+__device__ __forceinline__ long long iem_eval_idx(const IemIdxDesc &d, const long long *const *iarrs, long long k0,
+                                                 long long k1, long long k2) {
+  long long v = d.c + d.k[0] * k0 + d.k[1] * k1 + d.k[2] * k2;
+  for (int j = 0; j < d.ng; ++j)
+    v += d.gcoef[j] * iarrs[d.garr[j]][d.gbase[j] + d.gstep[j][0] * k0 + d.gstep[j][1] * k1 + d.gstep[j][2] * k2];
+  return v;
+}
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_structure_kernel(const IemStructArgs A) {
+  const long long e = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;
+  if (e >= A.n_items * A.nslots) return;
+  const long long k = e / A.nslots;
+  const int s = (int)(e - k * A.nslots);
+  const long long k0 = k % A.dims0, k1 = (k / A.dims0) % A.dims1, k2 = k / (A.dims0 * A.dims1);
+  const long long a = iem_eval_idx(A.ia[s], A.iarrs, k0, k1, k2);
+  if (A.ib == nullptr) {
+    A.rows[A.o + e] = A.o0 + k + A.base;
+    A.cols[A.o + e] = a - 1 + A.base;
+  } else {
+    const long long b = iem_eval_idx(A.ib[s], A.iarrs, k0, k1, k2);
+    A.rows[A.o + e] = (a >= b ? a : b) - 1 + A.base;
+    A.cols[A.o + e] = (a >= b ? b : a) - 1 + A.base;
+  }
 }
 
 #endif  // IEM_DEVICE_H

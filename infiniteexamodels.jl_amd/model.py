@@ -184,6 +184,23 @@ class ExaModel:
         _lib.check(self._L.iem_hess_structure(self._h, r.ctypes.data, c.ctypes.data, base))
         return r[:self.meta.nnzh], c[:self.meta.nnzh]
 
+    def jac_structure_device(self, base: int = 0):
+        """Structure generated on the device (int64 tensors), for GPU-resident solvers."""
+        t = self._torch
+        r = t.empty(self.meta.nnzj, dtype=t.int64, device=self.device)
+        c = t.empty(self.meta.nnzj, dtype=t.int64, device=self.device)
+        self._sync_stream()
+        _lib.check(self._L.iem_jac_structure_device(self._h, _ptr(r), _ptr(c), base))
+        return r, c
+
+    def hess_structure_device(self, base: int = 0):
+        t = self._torch
+        r = t.empty(self.meta.nnzh, dtype=t.int64, device=self.device)
+        c = t.empty(self.meta.nnzh, dtype=t.int64, device=self.device)
+        self._sync_stream()
+        _lib.check(self._L.iem_hess_structure_device(self._h, _ptr(r), _ptr(c), base))
+        return r, c
+
     def synchronize(self):
         _lib.check(self._L.iem_synchronize(self._h))
 

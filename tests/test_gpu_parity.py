@@ -55,6 +55,13 @@ def test_all_entry_points_match_oracle(name, torch_cuda):
         r, c = gm.hess_structure(base)
         ro, co = om.hess_structure(base)
         assert np.array_equal(r, ro) and np.array_equal(c, co)
+    for base in (0, 1):   # device-generated structure == host structure == oracle
+        r, c = gm.jac_structure_device(base)
+        ro, co = om.jac_structure(base)
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
+        r, c = gm.hess_structure_device(base)
+        ro, co = om.hess_structure(base)
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
     np.testing.assert_array_equal(gm.meta.x0, om.x0)
     np.testing.assert_array_equal(gm.meta.lvar, om.lvar)
     np.testing.assert_array_equal(gm.meta.uvar, om.uvar)
