@@ -109,7 +109,10 @@ def main():
     def barrier():
         if use_dist:
             dist.barrier(device_ids=[local_rank])
-    iemlib.build_library()
+    if not os.path.exists(iemlib.LIB_PATH):   # the prebuilt in-tree library is the normal case; never let N ranks run make at once
+        if rank == 0:
+            iemlib.build_library()
+        barrier()
     iemlib.set_option("store_mode", args.store_mode)
     iemlib.set_option("nt_stores", args.nt)
     iemlib.set_option("fp_contract", args.fma)

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,7 @@ std::string full_source(const iem::Program &p) {
   s += "// iem-flags: -O3 " + contract_flag() + " -std=c++17\n";
   s += "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += std::string("#define IEM_NT ") + (g_opt.nt_stores ? "1" : "0") + "\n";
+  s += "#define IEM_TILE " + std::to_string(g_opt.block) + "\n";
   if (g_opt.ablate) s += "#define IEM_ABLATE " + std::to_string(g_opt.ablate & 1) + "  // timing experiment, results are wrong\n";
   s += kDeviceHeader;
   s += "\n";
@@ -179,11 +181,13 @@ int compile_or_load(iem_model *m) {
     hiprtcDestroyProgram(&prog);
     m->jit = true;
     mkdir(dir.c_str(), 0755);
-    std::ofstream f(path + ".tmp", std::ios::binary);
+    // several ranks may compile the same key at once: private temp name, atomic rename
+    const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
+    std::ofstream f(tmp, std::ios::binary);
     if (f) {
       f.write(code.data(), (std::streamsize)code.size());
       f.close();
-      std::rename((path + ".tmp").c_str(), path.c_str());
+      if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
     }
   }
   HIP_TRY(hipModuleLoadData(&m->mod, code.data()));
@@ -211,7 +215,7 @@ int launch(iem_model *m, size_t k, const double *x, const double *y, double *out
   if (kd.ia.empty()) buf.push_back(0);
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], 256, 1, 1, 0,
+  HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
                                 m->stream, nullptr, cfg));
   return IEM_OK;
 }
@@ -375,6 +379,11 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "block") == 0) {
+    if (value < 64 || value > 1024 || value % 64) return fail(IEM_E_ARG, "block must be a multiple of 64 in 64..1024");
+    g_opt.block = (int)value;
+    return IEM_OK;
+  }
   if (std::strcmp(name, "lds_slots") == 0) { g_opt.lds_slots = (int)value; return IEM_OK; }
   if (std::strcmp(name, "reorder") == 0) { g_opt.reorder = (int)value; return IEM_OK; }
   if (std::strcmp(name, "min_waves") == 0) { g_opt.min_waves = (int)value; return IEM_OK; }
@@ -409,7 +418,7 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     os << "partials " << p.n_partials << "\n";
     for (const iem::KernelDesc &kd : p.kernels) {
       os << "kernel " << kd.name << " kind " << kd.kind << " grid " << kd.grid[0] << " " << kd.grid[1] << " " << kd.grid[2]
-         << " lds " << kd.lds_bytes << " rbytes " << kd.alg_bytes_read << " wbytes " << kd.alg_bytes_written << "\n";
+         << " lds " << kd.lds_bytes << " rbytes " << kd.alg_bytes_read << " wbytes " << kd.alg_bytes_written << " block " << kd.block << "\n";
       os << "ip " << kd.ip.size(); for (int64_t v : kd.ip) os << " " << v; os << "\n";
       os << "dp " << kd.dp.size(); for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); os << " " << b; } os << "\n";
       os << "fa " << kd.fa.size(); for (int v : kd.fa) os << " " << v; os << "\n";

@@ -860,7 +860,7 @@ class KernelBuilder {
       for (size_t oi = 0; oi < outs_.size(); ++oi) order.push_back((int)oi);
     }
     int batch_slots = 0;
-    const int lds_budget = std::max(opt_.lds_slots, max_ns);
+    const int lds_budget = stage_budget(max_ns);
     std::vector<std::string> pending_flush;
     auto flush_batch = [&]() {
       if (pending_flush.empty()) return;
@@ -894,7 +894,7 @@ class KernelBuilder {
             tail << "  const double " << rn << "[" << ns << "] = {";
             for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
             tail << "};\n";
-            tail << "  iem_stage<" << ns << ">(" << rn << ", lds_blk + " << (batch_slots * 256) << ");\n";
+            tail << "  iem_stage<" << ns << ">(" << rn << ", lds_blk + " << (batch_slots * opt_.block) << ");\n";
             // block-uniform position of lane 0 / slot 0 and the valid lane interval of this workgroup
             const IdxVal &pv = idx_[o.pos_idx];
             AffQ pb = pv.aff;
@@ -910,7 +910,7 @@ class KernelBuilder {
             fl << "    const int v0 = iem_clamp256(" << coefstr(o.qlo[0]) << " - qb0);\n";
             fl << "    const int v1 = " << (any ? "(" + gb.str() + ") ? " : "") << "iem_clamp256(" << ip(std::min(o.qhi[0], g_.ext[0])) << " - qb0)"
                << (any ? " : v0" : "") << ";\n";
-            fl << "    iem_flush<" << ns << ">(OUT, pb, v0, v1, lds_blk + " << (batch_slots * 256) << "); }\n";
+            fl << "    iem_flush<" << ns << ">(OUT, pb, v0, v1, lds_blk + " << (batch_slots * opt_.block) << "); }\n";
             pending_flush.push_back(fl.str());
             batch_slots += ns;
             break;
@@ -939,7 +939,7 @@ class KernelBuilder {
 
     // head: coordinates, guards, integer loads, index values, loads
     std::ostringstream head;
-    head << "  const long long q0 = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;\n";
+    head << "  const long long q0 = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
     head << "  const long long q1 = blockIdx.y, q2 = blockIdx.z;\n";
     head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
     for (size_t gi = 0; gi < guards_.size(); ++gi) head << "  const bool g" << gi << " = " << guards_[gi] << ";\n";
@@ -995,27 +995,36 @@ class KernelBuilder {
     size_t nfa = std::max<size_t>(1, fav_.size()), nia = std::max<size_t>(1, iav_.size());
     os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; double* out; double w;\n"
        << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
-    os << "extern \"C\" __global__ __launch_bounds__(IEM_BLOCK" << (opt_.min_waves > 0 ? ", " + std::to_string(opt_.min_waves) : std::string())
+    os << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt_.min_waves > 0 ? ", " + std::to_string(opt_.min_waves) : std::string())
        << ") void " << name_ << "(const Args_" << name_ << " A) {\n";
     os << "  const double* __restrict__ X = A.x; const double* __restrict__ TH = A.th; const double* __restrict__ Y = A.y;\n";
     os << "  double* __restrict__ OUT = A.out;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
     if (use_lds) {
-      os << "  __shared__ double lds_all[" << (IEM_BLOCK_WAVES * 64 * max_ns) << "];\n";
+      os << "  __shared__ double lds_all[" << (opt_.block * max_ns) << "];\n";
       os << "  double* lds_wave = lds_all + iem_wave() * " << (64 * max_ns) << ";\n";
-      kd.lds_bytes = IEM_BLOCK_WAVES * 64 * max_ns * 8;
+      kd.lds_bytes = opt_.block * max_ns * 8;
     }
     if (use_blk) {
-      const int budget = std::max(opt_.lds_slots, max_ns);
-      os << "  __shared__ double lds_blk[" << (IEM_BLOCK_WAVES * 64 * budget) << "];\n";
-      os << "  const long long qb0 = (long long)blockIdx.x * IEM_BLOCK;\n";
-      kd.lds_bytes = IEM_BLOCK_WAVES * 64 * budget * 8;
+      const int budget = stage_budget(max_ns);
+      os << "  __shared__ double lds_blk[" << (opt_.block * budget) << "];\n";
+      os << "  const long long qb0 = (long long)blockIdx.x * IEM_TILE;\n";
+      kd.lds_bytes = opt_.block * budget * 8;
     }
-    if (kind_ == KK_OBJ) os << "  __shared__ double lds4[4];\n";
+    if (kind_ == KK_OBJ) os << "  __shared__ double lds4[IEM_TILE / 64];\n";
     os << head.str() << tail.str() << "}\n\n";
     kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
     return os.str();
+  }
+
+  // values per lane staged per barrier pair: `lds_slots` is quoted for 256-thread workgroups
+  // (2 KB of LDS per slot) and scaled so the LDS per workgroup stays the same for other sizes
+  int stage_budget(int max_ns) const {
+    int b = std::max(1, opt_.lds_slots * 256 / opt_.block);
+    b = std::max(b, max_ns);
+    if ((long long)b * opt_.block * 8 > 160 * 1024) throw std::runtime_error("template needs more LDS than a CU has at this workgroup size");
+    return b;
   }
 
   int ip_index(int64_t v) {
@@ -1197,7 +1206,8 @@ Program generate(const Model &m, const Options &opt) {
       KernelDesc kd;
       kd.name = name;
       kd.kind = kind;
-      kd.grid[0] = (g.ext[0] + 255) / 256; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
+      kd.block = opt.block;
+      kd.grid[0] = (g.ext[0] + opt.block - 1) / opt.block; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
       kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
       if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
       if (kind == KK_GRAD) {

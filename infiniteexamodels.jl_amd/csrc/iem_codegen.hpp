@@ -20,6 +20,7 @@ struct KernelDesc {
   std::vector<int> fa;      // const double* fa[]  (model array ids, uploaded as f64)
   std::vector<int> ia;      // const long long* ia[] (model array ids, uploaded as i64)
   int lds_bytes = 0;
+  int block = 256;          // threads per workgroup of this kernel
   int64_t partial_off = 0;  // KK_OBJ: first partial slot written by this kernel
   int64_t n_blocks = 1;
   // bookkeeping for the roofline line
@@ -28,6 +29,7 @@ struct KernelDesc {
 
 struct Options {
   int store_mode = 2;  // 0 direct strided stores, 1 wave-level LDS-transposed stores, 2 block-cooperative 128-B-aligned stores
+  int block = 512;     // workgroup size of the fused kernels (multiple of 64); 512 halves the partial cache lines at block seams
   int lds_slots = 24;  // store_mode 2: values per lane staged per barrier pair (LDS = 2 KB x this per workgroup)
   int reorder = 1;     // 1: emit cheap templates first so the store stream starts early
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals

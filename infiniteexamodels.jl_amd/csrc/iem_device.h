@@ -22,7 +22,10 @@
 #ifndef IEM_DEVICE_H
 #define IEM_DEVICE_H
 
-#define IEM_BLOCK 256
+#define IEM_BLOCK 256   // helper kernels (reduction, structure)
+#ifndef IEM_TILE
+#define IEM_TILE 256    // workgroup size of the generated fused kernels (set by the generator)
+#endif
 #define IEM_WAVE 64
 
 __device__ __forceinline__ int iem_lane() { return (int)(threadIdx.x & (IEM_WAVE - 1)); }
@@ -107,7 +110,7 @@ __device__ __forceinline__ void iem_store_rows(double *__restrict__ out, long lo
 //   body  every wave store is 512 bytes, 128-byte aligned
 // v0/v1 = first / one-past-last valid lane of the workgroup (template guards are ranges
 // in q0, so validity is an interval); P0 = position of lane 0's slot 0 (block-uniform).
-__device__ __forceinline__ int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_BLOCK ? IEM_BLOCK : (int)v); }
+__device__ __forceinline__ int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_TILE ? IEM_TILE : (int)v); }
 
 // The two halves of the block store, so that several templates can share one barrier pair:
 //   iem_stage<NS>  lane writes its NS values item-major into its template's LDS region
@@ -131,7 +134,7 @@ __device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0
   if (t < head && e0 + t < e1) iem_stg(dst + e0 + t, lds_reg[e0 + t]);
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
-    const int e = e0 + head + t + j * IEM_BLOCK;
+    const int e = e0 + head + t + j * IEM_TILE;
     if (e < e1) iem_stg(dst + e, lds_reg[e]);
   }
 }
@@ -158,7 +161,12 @@ __device__ __forceinline__ void iem_block_partial(double v, double *__restrict__
   v = iem_wave_sum(v);
   if (iem_lane() == 0) lds4[iem_wave()] = v;
   __syncthreads();
-  if (threadIdx.x == 0) partials[slot] = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+  if (threadIdx.x == 0) {
+    double acc = lds4[0];
+#pragma unroll
+    for (int w = 1; w < IEM_TILE / IEM_WAVE; ++w) acc += lds4[w];
+    partials[slot] = acc;
+  }
 }
 
 // gradient entry shared by every lane of the wave (index does not depend on q0)

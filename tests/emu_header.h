@@ -7,6 +7,9 @@
 #include <cstdint>
 
 #define IEM_BLOCK 256
+#ifndef IEM_TILE
+#define IEM_TILE 256
+#endif
 #define IEM_WAVE 64
 #define __global__
 #define __device__
@@ -29,7 +32,7 @@ template <int NS>
 inline void iem_store_rows(double *out, long long pos0, bool valid, const double (&v)[NS], double *) {
   iem_store_rows_direct<NS>(out, pos0, valid, v);
 }
-inline int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_BLOCK ? IEM_BLOCK : (int)v); }
+inline int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_TILE ? IEM_TILE : (int)v); }
 template <int NS>
 inline void iem_store_block(double *out, long long P0, int v0, int v1, const double (&v)[NS], double *) {
   const int t = (int)threadIdx.x;
