@@ -180,3 +180,39 @@ def test_quadrotor_1e5_properties(torch_cuda):
     ro, co = om.hess_structure()
     assert np.array_equal(r, ro) and np.array_equal(c, co)
     gm.close()
+
+
+def test_quadrotor_1e6_headline_size(torch_cuda):
+    """The headline size of BASELINE.json (10^6 supports): the GPU result is compared with
+    the oracle over the WHOLE problem (the C oracle, all host threads, needs a few seconds)
+    plus a checksum-of-blocks property: per-template sums of the COO block equal the oracle's."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    S = 1_000_000
+    core = transcribe.exa_core(workloads.quadrotor(S))
+    blob = core.to_blob()
+    gm = ExaModel(core, device=0, blob=blob)
+    om = OracleModel(blob)
+    del blob
+    om.set_threads(min(om.max_threads(), 32))
+    x = gm.meta.x0 + 0.1 * np.random.default_rng(0).standard_normal(gm.meta.nvar)
+    x[7 * S:8 * S] = np.clip(x[7 * S:8 * S], -1.2, 1.2)
+    y = np.random.default_rng(1).standard_normal(gm.meta.ncon)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    j = gm.jac_coord(xd).cpu().numpy()
+    jo = om.jac_coord(x)
+    _close(j, jo, "jac_coord 1e6")
+    h = gm.hess_coord(xd, yd, obj_weight=1.0).cpu().numpy()
+    ho = om.hess_coord(x, y, 1.0)
+    _close(h, ho, "hess_coord 1e6")
+    for i in range(om.n_templates):
+        t = om.template_info(i)
+        if t["o2step"]:
+            a, b = t["o2"], t["o2"] + t["n_items"] * t["o2step"]
+            assert abs(h[a:b].sum() - ho[a:b].sum()) <= 1e-9 * max(1.0, np.abs(ho[a:b]).sum())
+    r, c = gm.jac_structure_device()
+    ro, co = om.jac_structure()
+    assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
+    gm.close()

@@ -1,0 +1,170 @@
+"""Randomised templates at the ExaCore level (the boundary a general IR import — SURVEY §8 f1 —
+would feed): random expression trees over the whole operator vocabulary, random index
+expressions (shifted, strided, multi-dimensional, gathered), shared finite variables, item
+data and θ.  For every seed:   oracle ≡ torch autograd   and   generated kernels (host
+emulation) ≡ oracle.  On the GPU the same models run through the C-ABI."""
+import numpy as np
+import pytest
+
+from infiniteexamodels.jl_amd import DataSource, ExaCore, Items, FUNCS
+from helpers import TorchModel, coo_to_dense, lower_to_full
+from pyoracle import OracleModel
+
+SAFE_UNARY = ["sin", "cos", "tanh", "atan", "exp", "abs2", "sinh", "cosh", "sech", "sqrt1p", "log1p2", "inv1p2",
+              "cbrt1p", "neg", "abs", "acot1p", "sind", "cosd", "atand", "exp2", "log2p", "log10p", "asin_s", "acos_s",
+              "atanh_s"]
+
+
+def _unary(rng, x):
+    name = SAFE_UNARY[rng.integers(len(SAFE_UNARY))]
+    F = FUNCS
+    if name == "neg":
+        return -x
+    if name == "sqrt1p":
+        return F["sqrt"](F["abs2"](x) + 1.5)
+    if name == "log1p2":
+        return F["log1p"](F["abs2"](x))
+    if name == "inv1p2":
+        return F["inv"](F["abs2"](x) + 2.0)
+    if name == "cbrt1p":
+        return F["cbrt"](F["abs2"](x) + 1.0)
+    if name == "acot1p":
+        return F["acot"](F["abs2"](x) + 1.0)
+    if name == "log2p":
+        return F["log2"](F["abs2"](x) + 1.25)
+    if name == "log10p":
+        return F["log10"](F["abs2"](x) + 1.25)
+    if name in ("asin_s", "acos_s", "atanh_s"):
+        return F[name[:-2]](0.5 * F["tanh"](x))
+    return F[name](x)
+
+
+def _tree(rng, leaves, depth):
+    if depth == 0 or rng.random() < 0.2:
+        leaf = leaves[rng.integers(len(leaves))]
+        return leaf() if callable(leaf) else leaf
+    r = rng.random()
+    if r < 0.35:
+        return _unary(rng, _tree(rng, leaves, depth - 1))
+    a, b = _tree(rng, leaves, depth - 1), _tree(rng, leaves, depth - 1)
+    op = rng.integers(8)
+    if op == 0:
+        return a + b
+    if op == 1:
+        return a - b
+    if op == 2:
+        return a * b
+    if op == 3:
+        return a / (FUNCS["abs2"](b) + 1.0)
+    if op == 4:
+        return (FUNCS["abs2"](a) + 0.5) ** float(rng.choice([2.0, 1.5, -1.0, 3.0]))
+    if op == 5:
+        return (FUNCS["abs2"](a) + 0.5) ** (0.5 * FUNCS["tanh"](b))      # variable ^ variable
+    if op == 6:
+        return float(rng.choice([2.0, 0.5, 3.0])) ** FUNCS["tanh"](a)     # real ^ variable
+    return float(rng.normal()) * a + float(rng.normal())
+
+
+def random_core(seed: int) -> ExaCore:
+    rng = np.random.default_rng(seed)
+    n1 = int(rng.integers(5, 70))
+    n2 = int(rng.integers(2, 6))
+    core = ExaCore()
+    z = core.add_var(1, start=0.3)                        # finite variable shared by every item
+    a = core.add_var(n1, start=rng.normal(size=n1) * 0.3)
+    b = core.add_var(n1, n2, start=rng.normal(size=(n1, n2)) * 0.3)
+    th = core.add_par(rng.normal(size=n1))
+    th2 = core.add_par(rng.normal(size=(n1, n2)))
+    ds = DataSource()
+    sup1 = np.linspace(0.0, 1.0, n1)
+    g1 = Items.from_supports("i", n1, {"t": sup1}, group_id=1)
+    g2 = Items.from_supports("j", n2, {"s": np.linspace(2.0, 3.0, n2)}, group_id=2)
+    g12 = g1.product(g2)
+    inner = g1.select(1, n1 - 2).with_float("h", rng.random(n1 - 2) + 0.5)     # i = 2..n1-1
+    # an irregular iterator (explicit int64 column)
+    pick = np.sort(rng.choice(n1, size=max(2, n1 // 3), replace=False))
+    irr = Items.from_records([dict(i=int(k) + 1, w=float(rng.normal())) for k in pick])
+    leaves1 = [lambda: a[ds.i], lambda: z[1], lambda: th[ds.i], lambda: ds.t, lambda: float(rng.normal())]
+    leaves_in = leaves1 + [lambda: a[ds.i - 1], lambda: a[ds.i + 1], lambda: ds.h]
+    leaves12 = [lambda: b[ds.i, ds.j], lambda: a[ds.i], lambda: z[1], lambda: th2[ds.i, ds.j], lambda: ds.s,
+                lambda: b[ds.i, 1], lambda: float(rng.normal())]
+    leaves_irr = [lambda: a[ds.i], lambda: ds.w, lambda: z[1], lambda: b[ds.i, 2]]
+    for _ in range(int(rng.integers(1, 4))):
+        core.add_con(_tree(rng, leaves1, 3), g1, lcon=-1.0, ucon=np.inf)
+    for _ in range(int(rng.integers(1, 3))):
+        core.add_con(_tree(rng, leaves_in, 3), inner)
+    for _ in range(int(rng.integers(1, 3))):
+        core.add_con(_tree(rng, leaves12, 3), g12, lcon=rng.normal(size=n1 * n2), ucon=np.inf)
+    core.add_con(_tree(rng, leaves_irr, 2), irr)
+    core.add_con(_tree(rng, [lambda: z[1], lambda: a[3], lambda: b[2, 2]], 2))                 # single item
+    core.add_obj(ds.c * _tree(rng, leaves1, 3), g1.with_float("c", rng.random(n1)))
+    core.add_obj(_tree(rng, leaves12, 2), g12)
+    core.add_obj(_tree(rng, [lambda: z[1], lambda: a[1]], 2))
+    core.add_obj(1.75)                                                                        # Null constant
+    return core
+
+
+SEEDS = list(range(16))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_model_oracle_vs_autograd_vs_generated(seed, built):
+    from emu import EmulatedModel
+    core = random_core(seed)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    rng = np.random.default_rng(1000 + seed)
+    x = om.x0 + 0.2 * rng.standard_normal(om.nvar)
+    y = rng.standard_normal(om.ncon)
+    f, c, g, J, H = TorchModel(core).dense(x, y, 0.6)
+    assert np.isfinite(H).all() and np.isfinite(J).all()
+    scale = max(1.0, np.abs(H).max())
+    assert abs(om.obj(x) - f) <= 1e-11 * max(1.0, abs(f))
+    np.testing.assert_allclose(om.cons(x), c, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(om.grad(x), g, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(g).max()))
+    r, cc = om.jac_structure()
+    np.testing.assert_allclose(coo_to_dense(r, cc, om.jac_coord(x), (om.ncon, om.nvar)), J, rtol=1e-10,
+                               atol=1e-10 * max(1.0, np.abs(J).max()))
+    r, cc = om.hess_structure()
+    assert (r >= cc).all()
+    Ho = lower_to_full(coo_to_dense(r, cc, om.hess_coord(x, y, 0.6), (om.nvar, om.nvar)))
+    np.testing.assert_allclose(Ho, H, rtol=1e-9, atol=1e-9 * scale)
+    em = EmulatedModel(core, blob)
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max())) if len(b) else 0.0
+
+    assert abs(em.obj(x) - om.obj(x)) <= 1e-12 * max(1.0, abs(om.obj(x)))
+    assert rel(em.cons(x), om.cons(x)) <= 1e-13
+    assert rel(em.grad(x), om.grad(x)) <= 1e-12
+    assert rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-13
+    assert rel(em.hess_coord(x, y, 0.6, om.nnzh), om.hess_coord(x, y, 0.6)) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_model_gpu(seed, built):
+    import torch
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from test_gpu_parity import _close
+    core = random_core(seed)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    gm = ExaModel(core, device=0, blob=blob)
+    rng = np.random.default_rng(1000 + seed)
+    x = om.x0 + 0.2 * rng.standard_normal(om.nvar)
+    y = rng.standard_normal(om.ncon)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    for base in (0, 1):
+        r, c = gm.jac_structure_device(base)
+        ro, co = om.jac_structure(base)
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
+        r, c = gm.hess_structure_device(base)
+        ro, co = om.hess_structure(base)
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
+    assert abs(gm.obj(xd) - om.obj(x)) <= 1e-10 * max(1.0, abs(om.obj(x)))
+    _close(gm.cons(xd).cpu().numpy(), om.cons(x), "cons")
+    _close(gm.grad(xd).cpu().numpy(), om.grad(x), "grad")
+    _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac")
+    _close(gm.hess_coord(xd, yd, obj_weight=0.6).cpu().numpy(), om.hess_coord(x, y, 0.6), "hess")
+    gm.close()
