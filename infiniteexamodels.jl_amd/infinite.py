@@ -86,6 +86,14 @@ class ParameterFunctionRef(VariableRef):
     def group_idxs(self) -> List[int]:
         return _group_idxs(self.prefs)
 
+    def __call__(self, *args):
+        """``pf(0.5, s)`` — a parameter function restricted to some parameter values."""
+        if len(args) != len(self.prefs):
+            raise ValueError("wrong number of arguments")
+        if all(is_number(a) for a in args):
+            return float(self.func(*args))
+        return self.model._semi(self, list(args))
+
 
 class VarInfo:
     def __init__(self, lb=None, ub=None, fix=None, start=None):

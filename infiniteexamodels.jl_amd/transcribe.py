@@ -285,6 +285,49 @@ def _finalize_expr(expr):
     return N.Null(expr) if is_number(expr) else expr
 
 
+# expand_measures fallback ----------------------------------------------------------------
+def _reduce_ref(v, fixed: Dict[VariableRef, float]):
+    """Restrict one reference to parameter values ``fixed`` (pref → value): what InfiniteOpt's
+    measure expansion does with ``make_point_variable_ref`` / ``make_semi_infinite_variable_ref``."""
+    if isinstance(v, InfiniteParameterRef):
+        return fixed.get(v, v)
+    if isinstance(v, (InfiniteVariableRef, ParameterFunctionRef)):
+        if not any(p in fixed for p in v.prefs):
+            return v
+        args = [fixed.get(p, p) for p in v.prefs]
+        if isinstance(v, ParameterFunctionRef) and all(is_number(a) for a in args):
+            return float(v.func(*args))
+        return v(*args)
+    if isinstance(v, SemiInfiniteVariableRef):
+        if not any((not is_number(a)) and a in fixed for a in v.args):
+            return v
+        args = [a if is_number(a) else fixed.get(a, a) for a in v.args]
+        if isinstance(v.ivref, ParameterFunctionRef) and all(is_number(a) for a in args):
+            return float(v.ivref.func(*args))
+        return v.ivref(*args)
+    return v
+
+
+def expand_measures(expr, m: InfiniteModel):
+    """``InfiniteOpt.expand_measures`` [EXT]: every measure becomes the explicit weighted sum of
+    its integrand at the measure's supports (the reference's slow fallback, transform.jl:435,
+    :719, :758)."""
+    def expand_one(mref: MeasureRef):
+        supps, coeffs = _measure_data(mref)
+        inner = expand_measures(mref.func, m)
+        total = None
+        for k in range(len(coeffs)):
+            fixed = {p: float(supps[k, c]) for c, p in enumerate(mref.prefs)}
+            term = map_expression(lambda v: _reduce_ref(v, fixed), inner) if not is_number(inner) else inner
+            term = coeffs[k] * term
+            total = term if total is None else total + term
+        return total if total is not None else 0.0
+
+    if is_number(expr):
+        return expr
+    return map_expression(lambda v: expand_one(v) if isinstance(v, MeasureRef) else v, expr)
+
+
 # sharding hooks (shard.py) -----------------------------------------------------------
 def _shard(m: InfiniteModel):
     return getattr(m, "shard", None)
@@ -356,7 +399,7 @@ def _add_constraints(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> N
         expr = cref.func
         if any(isinstance(v, MeasureRef) for v in all_expression_variables(expr)):
             warnings.warn("Constrained measures can lead to poor performance with ExaModels.")
-            raise NotImplementedError("constrained measures (expand_measures) are not built yet")
+            expr = expand_measures(expr, m)
         group_idxs = parameter_group_int_indices(expr)
         if not _emit_here(expr, group_idxs, data, m):
             continue
@@ -549,7 +592,7 @@ def _process_measure_sum(vref: MeasureRef, data: ExaMappingData, prev_itr: Optio
         inner_mexpr, new_itr = _process_measure_sum(mref, data, itr)
         return map_expression(lambda v: inner_mexpr if v is mref else v, mexpr), new_itr
     warnings.warn(_ObjMeasureExpansionWarn)
-    raise NotImplementedError("expand_measures fallback is not built yet")
+    return expand_measures(mexpr, data.model), itr
 
 
 def _add_objective_aff_term(core: ExaCore, coef, vref: VariableRef, data: ExaMappingData) -> None:
@@ -583,7 +626,7 @@ def _add_objective(core: ExaCore, expr, data: ExaMappingData, m: InfiniteModel) 
         for coef, v1, v2 in expr.quad_terms():
             if isinstance(v1, MeasureRef) and isinstance(v2, MeasureRef):
                 warnings.warn(_ObjMeasureExpansionWarn)
-                raise NotImplementedError("expand_measures fallback is not built yet")
+                _add_generic_objective_term(core, expand_measures(coef * v1 * v2, m), data)
             elif isinstance(v1, MeasureRef):
                 _add_objective_aff_term(core, coef * v2, v1, data)
             else:
@@ -592,8 +635,7 @@ def _add_objective(core: ExaCore, expr, data: ExaMappingData, m: InfiniteModel) 
     else:
         if any(isinstance(v, MeasureRef) for v in all_expression_variables(expr)):
             warnings.warn(_ObjMeasureExpansionWarn)
-            raise NotImplementedError("expand_measures fallback is not built yet")
-        _add_generic_objective_term(core, expr, data)
+        _add_generic_objective_term(core, expand_measures(expr, m), data)
 
 
 def build_exa_core(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> ExaCore:

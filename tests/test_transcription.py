@@ -128,7 +128,7 @@ def test_warmstart_problem_sizes_and_starts():
 
 def test_objective_heuristics_accept_and_warn():
     """test/transcription.jl:177-209: nested measures with movable terms build one template;
-    the 'not so good' forms take the (unbuilt) expansion fallback with the reference's warning."""
+    the 'not so good' forms take the expand_measures fallback with the reference's warning."""
     m = InfiniteModel()
     t = m.infinite_parameter("t", 0, 1, num_supports=3)
     x1 = m.infinite_parameter("x1", -1, 1, num_supports=5)
@@ -147,12 +147,47 @@ def test_objective_heuristics_accept_and_warn():
         core = transcribe.exa_core(m)
         objs = [tp for tp in core.templates if tp.kind == T_OBJ]
         assert len(objs) == 1 and len(objs[0].items) == 3 * 5 * 5
-    bad = [m.integral(m.integral(x1_int ** 2, x2), t), m.integral(m.integral(io.sin(x1_int), x2), t)]
+    bad = [m.integral(m.integral(x1_int ** 2, x2), t), m.integral(m.integral(io.sin(x1_int), x2), t),
+           m.integral(m.integral(x1_int * x1_int ** 2.3, x2), t),
+           m.integral(m.integral(x1_int + m.integral(io.sin(y), x1), x2), t)]
     for obj in bad:
         m.objective("min", obj)
         with pytest.warns(UserWarning, match="Unable to convert objective measures"):
-            with pytest.raises(NotImplementedError):
-                transcribe.exa_core(m)
+            core = transcribe.exa_core(m)                       # test/transcription.jl:205-208: still an ExaModel
+        assert sum(tp.kind == T_OBJ for tp in core.templates) >= 1
+
+
+def test_expand_measures_matches_explicit_quadrature(built):
+    """Constrained measures and the objective fallback (transform.jl:433-435, 708-720) against
+    a hand-written trapezoid sum."""
+    from pyoracle import OracleModel
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=3)
+    x1 = m.infinite_parameter("x1", -1, 1, num_supports=4)
+    y = m.variable("y", t, x1)
+    q = m.variable("q", t)
+    z = m.variable("z")
+    m.objective("min", m.integral(io.sin(m.integral(y ** 2, x1)) + 0.3 * q, t) + z ** 2)
+    with pytest.warns(UserWarning, match="Constrained measures"):
+        m.constraint(m.integral(y, x1) + q <= 3.0)
+        m.constraint(m.integral(m.integral(y * q, x1), t) == 1.0)
+        core = transcribe.exa_core(m)
+    om = OracleModel(core.to_blob())
+    x = np.random.default_rng(0).normal(size=om.nvar)
+
+    def trap(s):
+        d = np.diff(s)
+        c = np.zeros_like(s)
+        c[:-1] += d / 2
+        c[1:] += d / 2
+        return c
+
+    ct, cx = trap(np.linspace(0, 1, 3)), trap(np.linspace(-1, 1, 4))
+    Y, Q, zz = x[1:13].reshape(4, 3).T, x[13:16], x[0]
+    obj = sum(ct[i] * (np.sin(cx @ Y[i] ** 2) + 0.3 * Q[i]) for i in range(3)) + zz ** 2
+    assert abs(om.obj(x) - obj) < 1e-12
+    np.testing.assert_allclose(om.cons(x)[:3], [cx @ Y[i] + Q[i] for i in range(3)], rtol=1e-12, atol=1e-13)
+    assert abs(om.cons(x)[3] - sum(ct[i] * (cx @ Y[i]) * Q[i] for i in range(3))) < 1e-13
 
 
 def test_build_order_matches_build_exa_core():
