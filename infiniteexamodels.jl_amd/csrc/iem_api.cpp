@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +112,7 @@ struct iem_model {
   std::vector<double> theta_host;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool jit = false;
+  std::vector<std::pair<int64_t, int64_t>> grad_zero;  // [lo, hi) ranges of g the kernels do not overwrite
 };
 
 namespace {
@@ -469,6 +471,16 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
     for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return bail(rc);
     for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return bail(rc);
   }
+  {  // complement of the fully-overwritten gradient ranges
+    auto cov = m->prog.grad_covered;
+    std::sort(cov.begin(), cov.end());
+    int64_t pos = 0;
+    for (auto &c : cov) {
+      if (c.first > pos) m->grad_zero.emplace_back(pos, c.first);
+      pos = std::max(pos, c.second + 1);
+    }
+    if (pos < M.nvar) m->grad_zero.emplace_back(pos, M.nvar);
+  }
   if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) return bail(fail(IEM_E_HIP, "hipEventCreate"));
   *out = m;
   return IEM_OK;
@@ -590,7 +602,8 @@ int iem_obj(iem_model *m, const double *d_x, double *h_out) {
 
 int iem_grad(iem_model *m, const double *d_x, double *d_g) {
   if (!m || !d_x || !d_g) return fail(IEM_E_ARG, "null argument");
-  HIP_TRY(hipMemsetAsync(d_g, 0, (size_t)m->model.nvar * 8, m->stream));
+  for (auto &z : m->grad_zero)   // zero only what the kernels do not overwrite completely
+    HIP_TRY(hipMemsetAsync(d_g + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
   return launch_kind(m, iem::KK_GRAD, d_x, nullptr, d_g, 0.0);
 }
 

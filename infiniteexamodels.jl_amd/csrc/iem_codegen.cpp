@@ -809,7 +809,7 @@ class KernelBuilder {
     int max_ns = 1;
     for (auto &o : outs_) if (kind_ == KK_JAC || kind_ == KK_HESS) max_ns = std::max<int>(max_ns, (int)o.vals.size());
     bool use_lds = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 1;
-    bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 2;
+    bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS) && opt_.store_mode == 2;
 
     // stores/outputs first into `tail` so that every ip() they need is registered before the struct is printed
     std::ostringstream tail;
@@ -878,15 +878,15 @@ class KernelBuilder {
       std::string g = "g" + std::to_string(o.guard);
       switch (kind_) {
         case KK_CONS:
-          tail << "  if (" << g << ") OUT[i" << o.pos_idx << "] = v" << o.vals[0] << ";\n";
-          break;
-        case KK_OBJ:
-          tail << "  acc += " << g << " ? v" << o.vals[0] << " : 0.0;\n";
-          break;
+          if (!(opt_.store_mode == 2 && !o.scalar)) {
+            tail << "  if (" << g << ") OUT[i" << o.pos_idx << "] = v" << o.vals[0] << ";\n";
+            break;
+          }
+          [[fallthrough]];   // store_mode 2: rows go out through the aligned block store (1 value per lane)
         case KK_JAC:
         case KK_HESS: {
           int ns = (int)o.vals.size();
-          bool scalar_tpl = std::find(g_.scalars.begin(), g_.scalars.end(), o.tpl) != g_.scalars.end();
+          bool scalar_tpl = o.scalar;
           if (opt_.store_mode == 2 && !scalar_tpl) {
             // stage now, flush with the rest of the batch (one barrier pair per batch)
             if (batch_slots + ns > lds_budget) flush_batch();
@@ -923,6 +923,9 @@ class KernelBuilder {
           else tail << "    iem_store_rows_direct<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r); }\n";
           break;
         }
+        case KK_OBJ:
+          tail << "  acc += " << g << " ? v" << o.vals[0] << " : 0.0;\n";
+          break;
         case KK_GRAD:
           for (size_t s = 0; s < o.vals.size(); ++s) {
             int mode = o.grad_mode[s];
@@ -1190,7 +1193,7 @@ Program generate(const Model &m, const Options &opt) {
   static const char *kname[] = {"cons", "jac", "hess", "obj", "grad"};
 
   // gradient slot classification needs a global view of every objective slot's index range
-  struct GSlot { int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; };
+  struct GSlot { int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; int64_t count = 0; };
   std::vector<GSlot> gslots;
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
@@ -1234,6 +1237,7 @@ Program generate(const Model &m, const Options &opt) {
                 }
               }
               gs.lo = lo; gs.hi = hi; gs.injective = inj;
+              gs.count = scalar ? 1 : t.n_items;
               gs.uniform0 = !scalar && iv.aff.k[0] == 0 && t.dims[0] > 1;
             } else {
               gs.lo = INT64_MIN; gs.hi = INT64_MAX;
@@ -1258,6 +1262,9 @@ Program generate(const Model &m, const Options &opt) {
         if (!(b.hi < a.lo || b.lo > a.hi)) clash = true;
       }
       if (!clash) mode = 0;
+      // a slot whose items tile its index range without gaps fully overwrites that range:
+      // iem_grad need not zero it first
+      if (mode == 0 && a.hi - a.lo + 1 == a.count) P.grad_covered.emplace_back(a.lo, a.hi);
     }
     if (mode == 2 && a.pure && a.uniform0) mode = 1;
     builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "iem_model.hpp"
@@ -43,6 +44,8 @@ struct Program {
   uint64_t key = 0;
   std::vector<KernelDesc> kernels;
   int64_t n_partials = 0;
+  // 0-based index ranges [lo, hi] of g that the gradient kernels overwrite completely
+  std::vector<std::pair<int64_t, int64_t>> grad_covered;
 };
 
 Program generate(const Model &m, const Options &opt);

@@ -75,9 +75,11 @@ def test_all_entry_points_match_oracle(name, torch_cuda):
         f = gm.obj(xd)
         fo = om.obj(x)
         assert abs(f - fo) <= RTOL * max(1.0, abs(fo)), (f, fo)
-        _close(gm.cons(xd).cpu().numpy(), om.cons(x), "cons")
-        _close(gm.grad(xd).cpu().numpy(), om.grad(x), "grad")
         # outputs must be fully overwritten: poison the buffers first
+        cv = torch.full((om.ncon,), float("nan"), device="cuda", dtype=torch.float64)
+        gv = torch.full((om.nvar,), float("nan"), device="cuda", dtype=torch.float64)
+        _close(gm.cons(xd, cv).cpu().numpy(), om.cons(x), "cons")
+        _close(gm.grad(xd, gv).cpu().numpy(), om.grad(x), "grad")
         jv = torch.full((om.nnzj,), float("nan"), device="cuda", dtype=torch.float64)
         hv = torch.full((om.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
         _close(gm.jac_coord(xd, jv).cpu().numpy(), om.jac_coord(x), "jac_coord")

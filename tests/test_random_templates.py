@@ -163,8 +163,11 @@ def test_random_model_gpu(seed, built):
         ro, co = om.hess_structure(base)
         assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
     assert abs(gm.obj(xd) - om.obj(x)) <= 1e-10 * max(1.0, abs(om.obj(x)))
-    _close(gm.cons(xd).cpu().numpy(), om.cons(x), "cons")
-    _close(gm.grad(xd).cpu().numpy(), om.grad(x), "grad")
+    nan = float("nan")
+    cv = torch.full((om.ncon,), nan, device="cuda", dtype=torch.float64)
+    gv = torch.full((om.nvar,), nan, device="cuda", dtype=torch.float64)
+    _close(gm.cons(xd, cv).cpu().numpy(), om.cons(x), "cons")
+    _close(gm.grad(xd, gv).cpu().numpy(), om.grad(x), "grad")
     _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac")
     _close(gm.hess_coord(xd, yd, obj_weight=0.6).cpu().numpy(), om.hess_coord(x, y, 0.6), "hess")
     gm.close()
