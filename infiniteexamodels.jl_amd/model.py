@@ -130,6 +130,15 @@ class ExaModel:
         self.counters.neval_obj += 1
         return float(out.value)
 
+    def obj_device(self, x, out=None):
+        """Asynchronous ``obj``: the scalar stays on the device (graph-capturable)."""
+        self._chk(x, self.meta.nvar, "x")
+        out = out if out is not None else self._new(1)
+        self._sync_stream()
+        _lib.check(self._L.iem_obj_device(self._h, _ptr(x), _ptr(out)))
+        self.counters.neval_obj += 1
+        return out
+
     def grad(self, x, g=None):
         """``grad!(m, x, g)``."""
         self._chk(x, self.meta.nvar, "x")

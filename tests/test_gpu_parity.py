@@ -218,3 +218,47 @@ def test_quadrotor_1e6_headline_size(torch_cuda):
     ro, co = om.jac_structure()
     assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
     gm.close()
+
+
+def test_eval_loop_is_graph_capturable(torch_cuda):
+    """The five-call evaluation loop captured into a HIP graph (torch.cuda.graph) and replayed
+    on new inputs gives the same results as eager calls: no allocation / synchronisation
+    hides in the launch path."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    core = cases.build_core("pandemic_300x7")
+    blob = core.to_blob()
+    gm = ExaModel(core, device=0, blob=blob)
+    om = OracleModel(blob)
+    x0, y0 = cases.eval_point_for("pandemic_300x7", om, 0)
+    x1, y1 = cases.eval_point_for("pandemic_300x7", om, 5)
+    xd, yd = torch.tensor(x0, device="cuda"), torch.tensor(y0, device="cuda")
+    f = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g = torch.empty(om.nvar, dtype=torch.float64, device="cuda")
+    c = torch.empty(om.ncon, dtype=torch.float64, device="cuda")
+    jv = torch.empty(om.nnzj, dtype=torch.float64, device="cuda")
+    hv = torch.empty(om.nnzh, dtype=torch.float64, device="cuda")
+
+    def loop():
+        gm.obj_device(xd, f); gm.grad(xd, g); gm.cons(xd, c); gm.jac_coord(xd, jv); gm.hess_coord(xd, yd, hv, obj_weight=0.4)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        loop()                      # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loop()
+    xd.copy_(torch.tensor(x1)); yd.copy_(torch.tensor(y1))
+    for out in (f, g, c, jv, hv):
+        out.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert abs(f.item() - om.obj(x1)) <= 1e-10 * max(1.0, abs(om.obj(x1)))
+    _close(g.cpu().numpy(), om.grad(x1), "grad (graph)")
+    _close(c.cpu().numpy(), om.cons(x1), "cons (graph)")
+    _close(jv.cpu().numpy(), om.jac_coord(x1), "jac (graph)")
+    _close(hv.cpu().numpy(), om.hess_coord(x1, y1, 0.4), "hess (graph)")
+    gm.close()

@@ -79,12 +79,35 @@ def main():
             f()
     torch.cuda.synchronize()
     loop_ms = (time.perf_counter() - t0) / args.iters * 1e3
+    # the same loop captured in a HIP graph (obj kept on the device)
+    fdev = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def dev_loop():
+        gm.obj_device(x, fdev); gm.grad(x, g); gm.cons(x, c); gm.jac_coord(x, jv); gm.hess_coord(x, y, hv, obj_weight=1.0)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dev_loop()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dev_loop()
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        graph.replay()
+    torch.cuda.synchronize()
+    graph_ms = (time.perf_counter() - t0) / args.iters * 1e3
     kinds = {"obj": "obj", "grad": "grad", "cons": "cons", "jac_coord": "jac", "hess_coord": "hess"}
     bytes_ = {k: sum(kk["alg_bytes_read"] + kk["alg_bytes_written"] for kk in gm.kernels() if kk["kind"] == v)
               for k, v in kinds.items()}
     out = {
         "workload": desc, "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
         "n_kernels": gm.meta.n_kernels, "build_s": t_build, "loop_ms": loop_ms, "loops_per_s": 1e3 / loop_ms,
+        "graph_loop_ms": graph_ms, "graph_loops_per_s": 1e3 / graph_ms,
         "ms": ms, "alg_bytes": bytes_,
         "GBps": {k: (bytes_[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else None) for k in ms},
     }
