@@ -806,8 +806,11 @@ class KernelBuilder {
     for (auto &o : outs_) { if (o.pos_idx >= 0) need_idx.insert(o.pos_idx); for (int g : o.grad_idx) need_idx.insert(g); }
     for (auto &pr : sels_) { need_idx.insert(pr.first); need_idx.insert(pr.second); }
 
+    // templates with more slots than LDS can stage (huge nonlinear rows) keep the direct form
+    const int ns_cap = std::max(1, (opt_.store_mode == 1 ? 96 * 1024 / (8 * 64 * (opt_.block / 64)) : 96 * 1024 / (8 * opt_.block)));
     int max_ns = 1;
-    for (auto &o : outs_) if (kind_ == KK_JAC || kind_ == KK_HESS) max_ns = std::max<int>(max_ns, (int)o.vals.size());
+    for (auto &o : outs_)
+      if ((kind_ == KK_JAC || kind_ == KK_HESS) && (int)o.vals.size() <= ns_cap) max_ns = std::max<int>(max_ns, (int)o.vals.size());
     bool use_lds = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 1;
     bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS) && opt_.store_mode == 2;
 
@@ -887,6 +890,7 @@ class KernelBuilder {
         case KK_HESS: {
           int ns = (int)o.vals.size();
           bool scalar_tpl = o.scalar;
+          if (ns > ns_cap) scalar_tpl = true;   // direct strided stores for this template
           if (opt_.store_mode == 2 && !scalar_tpl) {
             // stage now, flush with the rest of the batch (one barrier pair per batch)
             if (batch_slots + ns > lds_budget) flush_batch();
@@ -1026,7 +1030,7 @@ class KernelBuilder {
   int stage_budget(int max_ns) const {
     int b = std::max(1, opt_.lds_slots * 256 / opt_.block);
     b = std::max(b, max_ns);
-    if ((long long)b * opt_.block * 8 > 160 * 1024) throw std::runtime_error("template needs more LDS than a CU has at this workgroup size");
+    if ((long long)b * opt_.block * 8 > 160 * 1024) throw std::runtime_error("internal: LDS staging budget exceeds a CU");
     return b;
   }
 

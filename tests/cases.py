@@ -118,6 +118,7 @@ def small_cases():
         "pfun": lambda: pfun()[0],
         "operator_zoo": operator_zoo,
         "irregular": irregular,
+        "wide_rows": None,
     }
 
 
@@ -137,4 +138,24 @@ def eval_point_for(name, om, seed=0):
 
 
 def build_core(name):
+    if name == "wide_rows":
+        return wide_rows()
     return transcribe.exa_core(small_cases()[name]())
+
+
+def wide_rows():
+    """One constraint with 14 variables multiplied pairwise-nonlinearly: > 100 Hessian slots per
+    item, more than the LDS staging budget — exercises the direct-store fallback."""
+    from infiniteexamodels.jl_amd import DataSource, ExaCore, Items, FUNCS
+    core = ExaCore()
+    n = 300
+    vs = [core.add_var(n, start=0.1 * (k + 1)) for k in range(14)]
+    ds = DataSource()
+    it = Items.from_supports("i", n, {"t": np.linspace(0, 1, n)}, group_id=1)
+    prod = vs[0][ds.i]
+    for v in vs[1:]:
+        prod = prod * FUNCS["cos"](v[ds.i]) + v[ds.i]
+    core.add_con(FUNCS["sin"](prod), it)
+    core.add_con(vs[0][ds.i] * vs[1][ds.i], it)
+    core.add_obj(FUNCS["abs2"](vs[2][ds.i]), it)
+    return core
