@@ -105,6 +105,14 @@ int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base)
 int iem_jac_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base);
 int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base);
 
+/* COO -> CSR value assembly with duplicate summation (the step that follows
+ * jac_coord!/hess_coord! in every solver iteration).  `d_perm` lists the COO positions sorted
+ * by (row, col); `d_seg[i] .. d_seg[i+1]` delimits the duplicates of CSR nonzero i (n_csr + 1
+ * entries).  The plan is built once from the structure (csr.py); this call is per iteration,
+ * deterministic (fixed summation order, no atomics). */
+int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int64_t *d_perm, const double *d_coo,
+                   double *d_csr);
+
 /* ---- kernel generation (no device needed) ---------------------------------------
  * The evaluator of a model is specialised HIP source generated from its templates
  * and compiled for gfx950 (offline into a code-object cache, or by hiprtc on a cache

@@ -105,7 +105,7 @@ struct iem_model {
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
-  hipFunction_t fn_reduce = nullptr, fn_struct = nullptr;
+  hipFunction_t fn_reduce = nullptr, fn_struct = nullptr, fn_csr = nullptr;
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *h_obj = nullptr;  // pinned
   std::map<int, void *> d_arrays;  // model array id -> device copy
@@ -198,6 +198,7 @@ int compile_or_load(iem_model *m) {
     HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));
   HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_reduce_partials"));
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
   return IEM_OK;
 }
 
@@ -642,6 +643,16 @@ int iem_jac_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int
 int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
   if (!m || ((!d_rows || !d_cols) && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
   return structure_device(m, d_rows, d_cols, base, true);
+}
+
+int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int64_t *d_perm, const double *d_coo,
+                   double *d_csr) {
+  if (!m || n_csr < 0 || (n_csr && (!d_seg || !d_perm || !d_coo || !d_csr))) return fail(IEM_E_ARG, "bad argument");
+  if (n_csr == 0) return IEM_OK;
+  long long n = n_csr;
+  void *args[] = {(void *)&d_seg, (void *)&d_perm, (void *)&d_coo, (void *)&d_csr, (void *)&n};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_csr, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
+  return IEM_OK;
 }
 
 int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess, int iters,

@@ -236,4 +236,18 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_structure_kernel(con
   }
 }
 
+// ---- COO -> CSR value assembly (the step right after jac_coord!/hess_coord! in a solver) -----
+// One thread per CSR nonzero: sums its (few) COO duplicates in a fixed order — deterministic,
+// no atomics.  seg/perm come from a one-off plan (sort of the COO positions by (row, col)).
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum(const long long *__restrict__ seg,
+                                                                          const long long *__restrict__ perm,
+                                                                          const double *__restrict__ coo,
+                                                                          double *__restrict__ csr, long long n) {
+  const long long i = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (long long k = seg[i]; k < seg[i + 1]; ++k) acc += coo[perm[k]];
+  csr[i] = acc;
+}
+
 #endif  // IEM_DEVICE_H

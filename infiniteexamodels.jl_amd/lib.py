@@ -41,7 +41,7 @@ class KernelInfo(C.Structure):
 SYMBOLS = ["iem_create", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_emit_source", "iem_emit_launch_plan", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_last_error", "iem_version"]
 
 
@@ -83,6 +83,7 @@ def lib():
     L.iem_hess_coord.argtypes = [vp, vp, vp, dbl, vp]
     for f in ("iem_jac_structure", "iem_hess_structure", "iem_jac_structure_device", "iem_hess_structure_device"):
         getattr(L, f).argtypes = [vp, vp, vp, i32]
+    L.iem_csr_values.argtypes = [vp, i64, vp, vp, vp, vp]
     L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     L.iem_emit_source.restype = i32
     L.iem_free.argtypes = [vp]
