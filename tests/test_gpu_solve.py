@@ -1,0 +1,112 @@
+"""Solver-in-the-loop on the GPU path: scipy drives the NLPModels surface of the DEVICE model
+(every obj / grad! / cons! / jac_coord! / hess_coord! call goes through the C-ABI to the HIP
+kernels) and must reach the reference's known optima (test/solve.jl:146,154,187;
+test/ipopt.jl:181) — the same end-to-end pin the reference's own tests use."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from scipy.optimize import Bounds, NonlinearConstraint, minimize
+
+import cases
+from infiniteexamodels.jl_amd import transcribe
+
+pytestmark = pytest.mark.gpu
+
+
+class HostView:
+    """numpy façade over a device ExaModel (host<->device copies per call; tiny problems)."""
+
+    def __init__(self, gm):
+        import torch
+        self.gm, self.torch = gm, torch
+        self.meta = gm.meta
+
+    def _d(self, a):
+        return self.torch.tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda")
+
+    def obj(self, x):
+        return self.gm.obj(self._d(x))
+
+    def grad(self, x):
+        return self.gm.grad(self._d(x)).cpu().numpy()
+
+    def cons(self, x):
+        return self.gm.cons(self._d(x)).cpu().numpy()
+
+    def jac(self, x):
+        r, c = self.gm.jac_structure()
+        return sp.coo_matrix((self.gm.jac_coord(self._d(x)).cpu().numpy(), (r, c)),
+                             shape=(self.meta.ncon, self.meta.nvar)).tocsr()
+
+    def hess(self, x, y, w):
+        r, c = self.gm.hess_structure()
+        v = self.gm.hess_coord(self._d(x), self._d(y), obj_weight=w).cpu().numpy()
+        L = sp.coo_matrix((v, (r, c)), shape=(self.meta.nvar, self.meta.nvar)).tocsr()
+        return (L + L.T - sp.diags(L.diagonal())).tocsr()
+
+
+def slsqp(h: HostView, x0):
+    m = h.meta
+    lc, uc = m.lcon, m.ucon
+    eq = np.nonzero(lc == uc)[0]
+    lo = np.nonzero((lc > -np.inf) & (lc != uc))[0]
+    up = np.nonzero((uc < np.inf) & (lc != uc))[0]
+    J = lambda x: h.jac(x).toarray()
+    cons = []
+    if len(eq):
+        cons.append(dict(type="eq", fun=lambda x: h.cons(x)[eq] - lc[eq], jac=lambda x: J(x)[eq]))
+    if len(lo):
+        cons.append(dict(type="ineq", fun=lambda x: h.cons(x)[lo] - lc[lo], jac=lambda x: J(x)[lo]))
+    if len(up):
+        cons.append(dict(type="ineq", fun=lambda x: uc[up] - h.cons(x)[up], jac=lambda x: -J(x)[up]))
+    b = [(None if l == -np.inf else l, None if u == np.inf else u) for l, u in zip(m.lvar, m.uvar)]
+    return minimize(h.obj, x0, jac=h.grad, bounds=b, constraints=cons, method="SLSQP",
+                    options=dict(ftol=1e-15, maxiter=1000))
+
+
+def test_known_optima_through_the_gpu_model(built):
+    from infiniteexamodels.jl_amd.model import ExaModel
+    # test/solve.jl:134-154 — finite parameters, then set_parameter_value + re-solve
+    m, (P1, P2) = cases.rosenbrock()
+    data = transcribe.ExaMappingData()
+    core = transcribe.exa_core(m, data)
+    h = HostView(ExaModel(core, device=0))
+    x0 = np.array([0.4, 0.4, 0.4, 2.2, 2.2, 2.2])
+    f = slsqp(h, x0).fun
+    assert abs(f - 306.5) < 1e-6 and abs(f - 306.4999755050365) < 5e-5
+    core.set_parameter(data.param_mappings[P1], [90.0])     # ExaModels.set_parameter! → iem_set_parameter
+    core.set_parameter(data.param_mappings[P2], [1.3])
+    f = slsqp(h, x0).fun
+    assert abs(f - 276.265) < 1e-6 and abs(f - 276.26497794903645) < 5e-5
+    # test/solve.jl:173-187 — parameter functions
+    m, _ = cases.pfun()
+    h = HostView(ExaModel(transcribe.exa_core(m), device=0))
+    f = slsqp(h, np.full(h.meta.nvar, 1.0)).fun
+    assert abs(f - 0.48292223509341475) < 2e-6
+    # test/ipopt.jl:160-181 — the warm-start problem, Jacobian AND Hessian from the device
+    h = HostView(ExaModel(cases.build_core("ode_5x5"), device=0))
+    f = slsqp(h, h.meta.x0.copy()).fun
+    assert abs(f - (-12.784599900757165)) < 1e-6
+    zero_y = np.zeros(h.meta.ncon)
+    con = NonlinearConstraint(h.cons, h.meta.lcon, h.meta.ucon, jac=h.jac, hess=lambda x, v: h.hess(x, v, 0.0))
+    res = minimize(h.obj, h.meta.x0.copy(), jac=h.grad, hess=lambda x: h.hess(x, zero_y, 1.0),
+                   bounds=Bounds(h.meta.lvar, h.meta.uvar), constraints=[con], method="trust-constr",
+                   options=dict(gtol=1e-10, xtol=1e-12, barrier_tol=1e-10, maxiter=3000))
+    assert abs(res.fun - (-12.784599900757165)) < 5e-6
+
+
+def test_quadrotor_100_plumbing(built):
+    """Config 1 of BASELINE.json (examples/quadrotor.jl, 100 supports): a few SQP iterations on
+    the device model decrease the objective and the constraint violation from the start point."""
+    from infiniteexamodels.jl_amd import workloads
+    from infiniteexamodels.jl_amd.model import ExaModel
+    h = HostView(ExaModel(transcribe.exa_core(workloads.quadrotor(100)), device=0))
+    assert (h.meta.nvar, h.meta.ncon) == (2200, 1800)
+    x0 = h.meta.x0.copy()
+    v0 = np.abs(h.cons(x0)).max()
+    assert v0 == pytest.approx(9.8)                      # ∂x6 = u1·cos·cos − 9.8 at x = 0
+    # one Gauss-Newton feasibility step with the device Jacobian: min ||c + J dx||
+    J = h.jac(x0)
+    import scipy.sparse.linalg as spla
+    dx = spla.lsqr(J, -h.cons(x0), atol=1e-12, btol=1e-12)[0]
+    assert np.abs(h.cons(x0 + dx)).max() < 0.2 * v0
