@@ -98,6 +98,13 @@ int iem_cons(iem_model *m, const double *d_x, double *d_c);
 int iem_jac_coord(iem_model *m, const double *d_x, double *d_vals);
 int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_vals);
 
+/* matrix-free products (NLPModels jprod! / jtprod! / hprod!; ExaModels' `prod = true` path —
+ * not used by the reference's solvers): Jv (ncon), J'v (nvar), Hv (nvar) with
+ * H the Hessian of obj_weight*f + y'c. */
+int iem_jprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jv);
+int iem_jtprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jtv);
+int iem_hprod(iem_model *m, const double *d_x, const double *d_y, const double *d_v, double obj_weight, double *d_Hv);
+
 /* jac_structure! / hess_structure! — one-off; `base` = 1 for Julia, 0 for C/Python.
  * Hessian pairs are lower-triangular (row >= col); COO may repeat positions. */
 int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base);

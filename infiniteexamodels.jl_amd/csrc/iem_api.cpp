@@ -113,6 +113,7 @@ struct iem_model {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool jit = false;
   std::vector<std::pair<int64_t, int64_t>> grad_zero;  // [lo, hi) ranges of g the kernels do not overwrite
+  std::vector<std::pair<int64_t, int64_t>> zero_ranges[iem::KK_COUNT];
 };
 
 namespace {
@@ -202,11 +203,11 @@ int compile_or_load(iem_model *m) {
   return IEM_OK;
 }
 
-int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w) {
+int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
   const iem::KernelDesc &kd = m->prog.kernels[k];
   std::vector<uint64_t> buf;
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
-  push_ptr(x); push_ptr(m->d_theta); push_ptr(y); push_ptr(out);
+  push_ptr(x); push_ptr(m->d_theta); push_ptr(y); push_ptr(v); push_ptr(out);
   uint64_t wb; std::memcpy(&wb, &w, 8); buf.push_back(wb);
   for (int64_t v : kd.ip) buf.push_back((uint64_t)v);
   if (kd.ip.empty()) buf.push_back(0);
@@ -223,10 +224,10 @@ int launch(iem_model *m, size_t k, const double *x, const double *y, double *out
   return IEM_OK;
 }
 
-int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w) {
+int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     if (m->prog.kernels[k].kind == kind) {
-      int rc = launch(m, k, x, y, out, w);
+      int rc = launch(m, k, x, y, out, w, v);
       if (rc) return rc;
     }
   return IEM_OK;
@@ -472,16 +473,18 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
     for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return bail(rc);
     for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return bail(rc);
   }
-  {  // complement of the fully-overwritten gradient ranges
-    auto cov = m->prog.grad_covered;
+  for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) {
+    // complement of the ranges the scatter kernels of this kind overwrite completely
+    auto cov = m->prog.covered[kind];
     std::sort(cov.begin(), cov.end());
     int64_t pos = 0;
     for (auto &c : cov) {
-      if (c.first > pos) m->grad_zero.emplace_back(pos, c.first);
+      if (c.first > pos) m->zero_ranges[kind].emplace_back(pos, c.first);
       pos = std::max(pos, c.second + 1);
     }
-    if (pos < M.nvar) m->grad_zero.emplace_back(pos, M.nvar);
+    if (pos < M.nvar) m->zero_ranges[kind].emplace_back(pos, M.nvar);
   }
+  m->grad_zero = m->zero_ranges[iem::KK_GRAD];
   if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) return bail(fail(IEM_E_HIP, "hipEventCreate"));
   *out = m;
   return IEM_OK;
@@ -606,6 +609,28 @@ int iem_grad(iem_model *m, const double *d_x, double *d_g) {
   for (auto &z : m->grad_zero)   // zero only what the kernels do not overwrite completely
     HIP_TRY(hipMemsetAsync(d_g + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
   return launch_kind(m, iem::KK_GRAD, d_x, nullptr, d_g, 0.0);
+}
+
+/* NLPModels.jprod!(m, x, v, Jv) */
+int iem_jprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jv) {
+  if (!m || !d_x || !d_v || (!d_Jv && m->model.ncon)) return fail(IEM_E_ARG, "null argument");
+  return launch_kind(m, iem::KK_JPROD, d_x, nullptr, d_Jv, 0.0, d_v);
+}
+
+/* NLPModels.jtprod!(m, x, v, Jtv) */
+int iem_jtprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jtv) {
+  if (!m || !d_x || (!d_v && m->model.ncon) || !d_Jtv) return fail(IEM_E_ARG, "null argument");
+  for (auto &z : m->zero_ranges[iem::KK_JTPROD])
+    HIP_TRY(hipMemsetAsync(d_Jtv + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
+  return launch_kind(m, iem::KK_JTPROD, d_x, nullptr, d_Jtv, 0.0, d_v);
+}
+
+/* NLPModels.hprod!(m, x, y, v, Hv; obj_weight) */
+int iem_hprod(iem_model *m, const double *d_x, const double *d_y, const double *d_v, double obj_weight, double *d_Hv) {
+  if (!m || !d_x || (!d_y && m->model.ncon) || !d_v || !d_Hv) return fail(IEM_E_ARG, "null argument");
+  for (auto &z : m->zero_ranges[iem::KK_HPROD])
+    HIP_TRY(hipMemsetAsync(d_Hv + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
+  return launch_kind(m, iem::KK_HPROD, d_x, d_y, d_Hv, obj_weight, d_v);
 }
 
 int iem_cons(iem_model *m, const double *d_x, double *d_c) {

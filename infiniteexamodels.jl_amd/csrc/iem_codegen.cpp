@@ -593,6 +593,9 @@ class KernelBuilder {
       case KK_HESS: return t.o2step > 0;
       case KK_OBJ: return t.kind == IEM_T_OBJ;
       case KK_GRAD: return t.kind == IEM_T_OBJ && t.o1step > 0;
+      case KK_JPROD: return t.kind == IEM_T_CON;
+      case KK_JTPROD: return t.kind == IEM_T_CON && t.o1step > 0;
+      case KK_HPROD: return t.o2step > 0;
     }
     return false;
   }
@@ -643,6 +646,74 @@ class KernelBuilder {
               o.grad_mode.push_back(2);
               alg_w_ += t.n_items;
             }
+          }
+          break;
+        }
+        case KK_JPROD: {   // (J v)[row] = sum_slots dc/dx_slot * v[col(slot)]
+          tg.forward(1);
+          tg.slots1.assign(t.o1step, -1);
+          tg.gr(t.root, 0, C(1.0));
+          int acc = C(0.0);
+          for (int s = 0; s < t.o1step; ++s) {
+            int vv = load(4, 0, tg.pos0(t.slot1_idx[s]), G.guard);
+            acc = add(acc, mul(tg.slots1[s] < 0 ? C(0.0) : tg.slots1[s], vv));
+          }
+          IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
+          o.pos_idx = idxval(iv);
+          o.vals = {acc};
+          alg_w_ += t.n_items;
+          break;
+        }
+        case KK_JTPROD: {  // (J' v)[col] += dc/dx_slot * v[row]  == gradient of  v . c(x)
+          tg.forward(1);
+          tg.slots1.assign(t.o1step, -1);
+          IdxVal rv; rv.aff = klin_aff(t, G, 1, t.o0);
+          int seed = load(4, 0, idxval(rv), G.guard);
+          tg.gr(t.root, 0, seed);
+          o.vals = tg.slots1;
+          for (int s = 0; s < t.o1step; ++s) {
+            o.grad_idx.push_back(tg.pos0(t.slot1_idx[s]));
+            o.grad_mode.push_back(2);
+            alg_w_ += t.n_items;
+          }
+          break;
+        }
+        case KK_HPROD: {   // (H v): slot (a, b) with value h adds h*v[b] to row a and, if a != b, h*v[a] to row b
+          tg.forward(2);
+          tg.slots2.assign(t.o2step, -1);
+          int adj;
+          if (t.kind == IEM_T_OBJ) adj = mk(VW, 0, -1, -1, -1, 0);
+          else {
+            IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
+            adj = load(2, 0, idxval(iv), G.guard);
+          }
+          tg.hr0(t.root, 0, adj, C(0.0));
+          std::map<int, int> dest;   // destination IdxVal id (0-based position) -> accumulated DAG value
+          std::vector<int> dest_order;
+          auto contribute = [&](int pos_id, int val) {
+            auto it = dest.find(pos_id);
+            if (it == dest.end()) { dest.emplace(pos_id, val); dest_order.push_back(pos_id); }
+            else it->second = add(it->second, val);
+          };
+          for (int s = 0; s < t.o2step; ++s) {
+            int h = tg.slots2[s] < 0 ? C(0.0) : tg.slots2[s];
+            int ia = tg.idx1(t.slot2_i[s]), ib = tg.idx1(t.slot2_j[s]);
+            int pa = tg.pos0(t.slot2_i[s]), pb = tg.pos0(t.slot2_j[s]);
+            contribute(pa, mul(h, load(4, 0, pb, G.guard)));
+            if (ia != ib) {
+              int c2 = mul(h, load(4, 0, pa, G.guard));
+              const IdxVal &A = idx_[ia], &Bv = idx_[ib];
+              bool never = A.ind.empty() && Bv.ind.empty() && A.aff.k[0] == Bv.aff.k[0] && A.aff.k[1] == Bv.aff.k[1] &&
+                           A.aff.k[2] == Bv.aff.k[2] && A.aff.c != Bv.aff.c;
+              if (!never) c2 = mk(VSEL, sel_id(ia, ib), C(0.0), c2, -1, 0);
+              contribute(pb, c2);
+            }
+          }
+          for (int pid : dest_order) {
+            o.vals.push_back(dest[pid]);
+            o.grad_idx.push_back(pid);
+            o.grad_mode.push_back(2);
+            alg_w_ += t.n_items;
           }
           break;
         }
@@ -812,7 +883,7 @@ class KernelBuilder {
     for (auto &o : outs_)
       if ((kind_ == KK_JAC || kind_ == KK_HESS) && (int)o.vals.size() <= ns_cap) max_ns = std::max<int>(max_ns, (int)o.vals.size());
     bool use_lds = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 1;
-    bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS) && opt_.store_mode == 2;
+    bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD) && opt_.store_mode == 2;
 
     // stores/outputs first into `tail` so that every ip() they need is registered before the struct is printed
     std::ostringstream tail;
@@ -823,7 +894,7 @@ class KernelBuilder {
     // the first round; emitting the templates with constant/affine partials first lets the
     // store stream start while the transcendental-heavy templates are still being computed.
     std::vector<int> order;
-    if (opt_.reorder && (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS)) {
+    if (opt_.reorder && (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD)) {
       std::vector<char> sim = done;
       std::vector<char> taken(outs_.size(), 0);
       for (size_t step = 0; step < outs_.size(); ++step) {
@@ -880,6 +951,7 @@ class KernelBuilder {
       for (int v : o.vals) emit_val(v, tail, done, live);
       std::string g = "g" + std::to_string(o.guard);
       switch (kind_) {
+        case KK_JPROD:
         case KK_CONS:
           if (!(opt_.store_mode == 2 && !o.scalar)) {
             tail << "  if (" << g << ") OUT[i" << o.pos_idx << "] = v" << o.vals[0] << ";\n";
@@ -930,6 +1002,8 @@ class KernelBuilder {
         case KK_OBJ:
           tail << "  acc += " << g << " ? v" << o.vals[0] << " : 0.0;\n";
           break;
+        case KK_JTPROD:
+        case KK_HPROD:
         case KK_GRAD:
           for (size_t s = 0; s < o.vals.size(); ++s) {
             int mode = o.grad_mode[s];
@@ -965,7 +1039,7 @@ class KernelBuilder {
       bool used = false;
       for (size_t v = 0; v < v_.size(); ++v) if (v_[v].op == VLD && v_[v].sub == (int)i && live[v]) { used = true; break; }
       if (!used) continue;
-      std::string arr = l.arr == 0 ? "X" : l.arr == 1 ? "TH" : l.arr == 2 ? "Y" : "FA[" + std::to_string(l.slot) + "]";
+      std::string arr = l.arr == 0 ? "X" : l.arr == 1 ? "TH" : l.arr == 2 ? "Y" : l.arr == 4 ? "V" : "FA[" + std::to_string(l.slot) + "]";
       head << "  const double l" << i << " = " << guard_or(l.guards) << " ? " << arr << "[i" << l.idxval << "] : 0.0;\n";
       alg_r_loads_++;
       // algorithmic read footprint: index range of this load over the launch domain
@@ -976,7 +1050,7 @@ class KernelBuilder {
         if (e < 0) lo += e; else hi += e;
       }
       if (!iv.ind.empty()) { lo = 0; hi = g_.ext[0] * g_.ext[1] * g_.ext[2] - 1; }
-      int akey = l.arr == 3 ? 100 + l.slot : l.arr;
+      int akey = l.arr == 3 ? 100 + l.slot : l.arr;   // 0 x, 1 theta, 2 y, 4 v, 100+ item columns
       ranges_[akey].emplace_back(lo, hi);
     }
     {
@@ -1000,11 +1074,12 @@ class KernelBuilder {
     std::ostringstream os;
     size_t nip = std::max<size_t>(1, ipv_.size()), ndp = std::max<size_t>(1, dpv_.size());
     size_t nfa = std::max<size_t>(1, fav_.size()), nia = std::max<size_t>(1, iav_.size());
-    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; double* out; double w;\n"
+    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n"
        << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
     os << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt_.min_waves > 0 ? ", " + std::to_string(opt_.min_waves) : std::string())
        << ") void " << name_ << "(const Args_" << name_ << " A) {\n";
     os << "  const double* __restrict__ X = A.x; const double* __restrict__ TH = A.th; const double* __restrict__ Y = A.y;\n";
+    os << "  const double* __restrict__ V = A.v; (void)V;\n";
     os << "  double* __restrict__ OUT = A.out;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
@@ -1194,10 +1269,10 @@ Program generate(const Model &m, const Options &opt) {
   std::vector<Group> groups = make_groups(m);
   std::ostringstream src;
   src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";
-  static const char *kname[] = {"cons", "jac", "hess", "obj", "grad"};
+  static const char *kname[] = {"cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod"};
 
   // gradient slot classification needs a global view of every objective slot's index range
-  struct GSlot { int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; int64_t count = 0; };
+  struct GSlot { int kind; int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; int64_t count = 0; };
   std::vector<GSlot> gslots;
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
@@ -1206,7 +1281,7 @@ Program generate(const Model &m, const Options &opt) {
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const Group &g = groups[gi];
     if (g.ext[1] > 65535 || g.ext[2] > 65535) throw std::runtime_error("support grid too large in dims 2/3 (limit 65535)");
-    for (int kind = 0; kind < 5; ++kind) {
+    for (int kind = 0; kind < KK_COUNT; ++kind) {
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
       if (!kb->build(nullptr)) continue;
@@ -1217,14 +1292,14 @@ Program generate(const Model &m, const Options &opt) {
       kd.grid[0] = (g.ext[0] + opt.block - 1) / opt.block; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
       kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
       if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
-      if (kind == KK_GRAD) {
+      if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {
         auto &outs = kb->outputs();
         for (size_t oi = 0; oi < outs.size(); ++oi) {
           const Template &t = m.tpl[outs[oi].tpl];
           bool scalar = std::find(g.scalars.begin(), g.scalars.end(), outs[oi].tpl) != g.scalars.end();
           for (size_t s = 0; s < outs[oi].grad_idx.size(); ++s) {
             const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
-            GSlot gs{(int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
+            GSlot gs{kind, (int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
             if (gs.pure) {
               int64_t lo = iv.aff.c, hi = iv.aff.c;
               // q range of this template: q_d in [origin-lo, origin-lo+dims)
@@ -1263,12 +1338,16 @@ Program generate(const Model &m, const Options &opt) {
       for (size_t j = 0; j < gslots.size() && !clash; ++j) {
         if (i == j) continue;
         const GSlot &b = gslots[j];
+        if (b.kind != a.kind) continue;   // different output vectors
         if (!(b.hi < a.lo || b.lo > a.hi)) clash = true;
       }
       if (!clash) mode = 0;
       // a slot whose items tile its index range without gaps fully overwrites that range:
       // iem_grad need not zero it first
-      if (mode == 0 && a.hi - a.lo + 1 == a.count) P.grad_covered.emplace_back(a.lo, a.hi);
+      if (mode == 0 && a.hi - a.lo + 1 == a.count) {
+        P.covered[a.kind].emplace_back(a.lo, a.hi);
+        if (a.kind == KK_GRAD) P.grad_covered.emplace_back(a.lo, a.hi);
+      }
     }
     if (mode == 2 && a.pure && a.uniform0) mode = 1;
     builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;

@@ -9,13 +9,13 @@
 
 namespace iem {
 
-enum KernelKind { KK_CONS = 0, KK_JAC = 1, KK_HESS = 2, KK_OBJ = 3, KK_GRAD = 4 };
+enum KernelKind { KK_CONS = 0, KK_JAC = 1, KK_HESS = 2, KK_OBJ = 3, KK_GRAD = 4, KK_JPROD = 5, KK_JTPROD = 6, KK_HPROD = 7, KK_COUNT = 8 };
 
 struct KernelDesc {
   std::string name;
   int kind = 0;
   int64_t grid[3] = {1, 1, 1};  // workgroups
-  // argument block, in this order after the fixed head {x, th, y, out, w}:
+  // argument block, in this order after the fixed head {x, th, y, v, out, w}:
   std::vector<int64_t> ip;  // long long ip[]
   std::vector<double> dp;   // double dp[]
   std::vector<int> fa;      // const double* fa[]  (model array ids, uploaded as f64)
@@ -45,7 +45,8 @@ struct Program {
   std::vector<KernelDesc> kernels;
   int64_t n_partials = 0;
   // 0-based index ranges [lo, hi] of g that the gradient kernels overwrite completely
-  std::vector<std::pair<int64_t, int64_t>> grad_covered;
+  std::vector<std::pair<int64_t, int64_t>> grad_covered;      // KK_GRAD
+  std::vector<std::pair<int64_t, int64_t>> covered[KK_COUNT];  // per scatter kind (grad, jtprod, hprod)
 };
 
 Program generate(const Model &m, const Options &opt);

@@ -40,7 +40,7 @@ class KernelInfo(C.Structure):
 # every symbol include/iem.h declares (tests check the export list against the header)
 SYMBOLS = ["iem_create", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
-           "iem_jac_coord", "iem_hess_coord", "iem_jac_structure", "iem_hess_structure",
+           "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_last_error", "iem_version"]
 
@@ -81,6 +81,9 @@ def lib():
     L.iem_cons.argtypes = [vp, vp, vp]
     L.iem_jac_coord.argtypes = [vp, vp, vp]
     L.iem_hess_coord.argtypes = [vp, vp, vp, dbl, vp]
+    L.iem_jprod.argtypes = [vp, vp, vp, vp]
+    L.iem_jtprod.argtypes = [vp, vp, vp, vp]
+    L.iem_hprod.argtypes = [vp, vp, vp, vp, dbl, vp]
     for f in ("iem_jac_structure", "iem_hess_structure", "iem_jac_structure_device", "iem_hess_structure_device"):
         getattr(L, f).argtypes = [vp, vp, vp, i32]
     L.iem_csr_values.argtypes = [vp, i64, vp, vp, vp, vp]

@@ -180,6 +180,33 @@ class ExaModel:
         self.counters.neval_hess += 1
         return vals
 
+    def jprod(self, x, v, Jv=None):
+        """``jprod!(m, x, v, Jv)``: Jacobian–vector product (ncon)."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(v, self.meta.nvar, "v")
+        Jv = Jv if Jv is not None else self._new(self.meta.ncon)
+        self._chk(Jv, self.meta.ncon, "Jv")
+        self._sync_stream()
+        _lib.check(self._L.iem_jprod(self._h, _ptr(x), _ptr(v), _ptr(Jv)))
+        return Jv
+
+    def jtprod(self, x, v, Jtv=None):
+        """``jtprod!(m, x, v, Jtv)``: transposed Jacobian–vector product (nvar)."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(v, self.meta.ncon, "v")
+        Jtv = Jtv if Jtv is not None else self._new(self.meta.nvar)
+        self._chk(Jtv, self.meta.nvar, "Jtv")
+        self._sync_stream()
+        _lib.check(self._L.iem_jtprod(self._h, _ptr(x), _ptr(v), _ptr(Jtv)))
+        return Jtv
+
+    def hprod(self, x, y, v, Hv=None, obj_weight: float = 1.0):
+        """``hprod!(m, x, y, v, Hv; obj_weight)``: Lagrangian-Hessian–vector product (nvar)."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(y, self.meta.ncon, "y"); self._chk(v, self.meta.nvar, "v")
+        Hv = Hv if Hv is not None else self._new(self.meta.nvar)
+        self._chk(Hv, self.meta.nvar, "Hv")
+        self._sync_stream()
+        _lib.check(self._L.iem_hprod(self._h, _ptr(x), _ptr(y), _ptr(v), float(obj_weight), _ptr(Hv)))
+        return Hv
+
     def jac_structure(self, base: int = 0):
         """``jac_structure!(m, rows, cols)`` → host int64 arrays (``base`` 1 = Julia)."""
         r = np.zeros(max(self.meta.nnzj, 1), dtype=np.int64)

@@ -820,3 +820,35 @@ void orc_hess_coord(const orc_model *m, const double *x, const double *y, double
     scratch_free(s);
   }
 }
+
+/* matrix-free products, restated through the COO output (checker for jprod!/jtprod!/hprod!) */
+void orc_jprod(const orc_model *m, const double *x, const double *v, double *Jv) {
+  double *vals = (double *)malloc(sizeof(double) * (m->nnzj ? m->nnzj : 1));
+  int64_t *r = (int64_t *)malloc(sizeof(int64_t) * (m->nnzj ? m->nnzj : 1)), *c = (int64_t *)malloc(sizeof(int64_t) * (m->nnzj ? m->nnzj : 1));
+  orc_jac_coord(m, x, vals);
+  orc_jac_structure(m, r, c, 0);
+  for (int64_t i = 0; i < m->ncon; ++i) Jv[i] = 0.0;
+  for (int64_t e = 0; e < m->nnzj; ++e) Jv[r[e]] += vals[e] * v[c[e]];
+  free(vals); free(r); free(c);
+}
+void orc_jtprod(const orc_model *m, const double *x, const double *v, double *Jtv) {
+  double *vals = (double *)malloc(sizeof(double) * (m->nnzj ? m->nnzj : 1));
+  int64_t *r = (int64_t *)malloc(sizeof(int64_t) * (m->nnzj ? m->nnzj : 1)), *c = (int64_t *)malloc(sizeof(int64_t) * (m->nnzj ? m->nnzj : 1));
+  orc_jac_coord(m, x, vals);
+  orc_jac_structure(m, r, c, 0);
+  for (int64_t i = 0; i < m->nvar; ++i) Jtv[i] = 0.0;
+  for (int64_t e = 0; e < m->nnzj; ++e) Jtv[c[e]] += vals[e] * v[r[e]];
+  free(vals); free(r); free(c);
+}
+void orc_hprod(const orc_model *m, const double *x, const double *y, const double *v, double obj_weight, double *Hv) {
+  double *vals = (double *)malloc(sizeof(double) * (m->nnzh ? m->nnzh : 1));
+  int64_t *r = (int64_t *)malloc(sizeof(int64_t) * (m->nnzh ? m->nnzh : 1)), *c = (int64_t *)malloc(sizeof(int64_t) * (m->nnzh ? m->nnzh : 1));
+  orc_hess_coord(m, x, y, obj_weight, vals);
+  orc_hess_structure(m, r, c, 0);
+  for (int64_t i = 0; i < m->nvar; ++i) Hv[i] = 0.0;
+  for (int64_t e = 0; e < m->nnzh; ++e) {
+    Hv[r[e]] += vals[e] * v[c[e]];
+    if (r[e] != c[e]) Hv[c[e]] += vals[e] * v[r[e]];
+  }
+  free(vals); free(r); free(c);
+}

@@ -47,6 +47,9 @@ def lib():
         L.orc_jac_coord.argtypes = [vp, pd, pd]
         L.orc_hess_structure.argtypes = [vp, pi, pi, C.c_int]
         L.orc_hess_coord.argtypes = [vp, pd, pd, dbl, pd]
+        L.orc_jprod.argtypes = [vp, pd, pd, pd]
+        L.orc_jtprod.argtypes = [vp, pd, pd, pd]
+        L.orc_hprod.argtypes = [vp, pd, pd, pd, dbl, pd]
         _LIB = L
     return _LIB
 
@@ -125,6 +128,21 @@ class OracleModel:
         v = np.zeros(self.nnzj)
         self._L.orc_jac_coord(self._h, self._x(x), v)
         return v
+
+    def jprod(self, x, v) -> np.ndarray:
+        out = np.zeros(self.ncon)
+        self._L.orc_jprod(self._h, self._x(x), self._x(v), out)
+        return out
+
+    def jtprod(self, x, v) -> np.ndarray:
+        out = np.zeros(self.nvar)
+        self._L.orc_jtprod(self._h, self._x(x), self._x(v), out)
+        return out
+
+    def hprod(self, x, y, v, obj_weight: float = 1.0) -> np.ndarray:
+        out = np.zeros(self.nvar)
+        self._L.orc_hprod(self._h, self._x(x), self._x(y), self._x(v), float(obj_weight), out)
+        return out
 
     def hess_structure(self, base: int = 0):
         r = np.zeros(self.nnzh, dtype=np.int64)

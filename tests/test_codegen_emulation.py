@@ -31,6 +31,12 @@ def test_emulated_kernels_match_oracle(name, built):
     assert not np.isnan(j).any() and not np.isnan(h).any(), "every output slot must be written"
     assert _rel(j, om.jac_coord(x)) <= 1e-14
     assert _rel(h, om.hess_coord(x, y, 0.7)) <= 1e-14
+    # matrix-free products (jprod! / jtprod! / hprod!)
+    rng = np.random.default_rng(5)
+    v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+    assert _rel(em.jprod(x, v), om.jprod(x, v)) <= 1e-13
+    assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])

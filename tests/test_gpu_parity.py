@@ -85,6 +85,14 @@ def test_all_entry_points_match_oracle(name, torch_cuda):
         _close(gm.jac_coord(xd, jv).cpu().numpy(), om.jac_coord(x), "jac_coord")
         for w in (1.0, 0.3):
             _close(gm.hess_coord(xd, yd, hv, obj_weight=w).cpu().numpy(), om.hess_coord(x, y, w), "hess_coord")
+        # matrix-free products into poisoned buffers
+        rng = np.random.default_rng(seed + 40)
+        v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+        vd, vcd = torch.tensor(v, device="cuda"), torch.tensor(vc, device="cuda")
+        nanv = lambda n: torch.full((n,), float("nan"), device="cuda", dtype=torch.float64)
+        _close(gm.jprod(xd, vd, nanv(om.ncon)).cpu().numpy(), om.jprod(x, v), "jprod")
+        _close(gm.jtprod(xd, vcd, nanv(om.nvar)).cpu().numpy(), om.jtprod(x, vc), "jtprod")
+        _close(gm.hprod(xd, yd, vd, nanv(om.nvar), obj_weight=0.3).cpu().numpy(), om.hprod(x, y, v, 0.3), "hprod")
     gm.close()
 
 

@@ -27,6 +27,12 @@ def test_oracle_matches_autograd(name, built):
     assert (r >= cc).all(), "Hessian structure must be lower triangular"
     Ho = lower_to_full(coo_to_dense(r, cc, om.hess_coord(x, y, 0.7), (om.nvar, om.nvar)))
     np.testing.assert_allclose(Ho, H, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(H).max()))
+    # matrix-free products against the dense autograd matrices
+    rng = np.random.default_rng(9)
+    v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+    np.testing.assert_allclose(om.jprod(x, v), J @ v, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(om.jtprod(x, vc), J.T @ vc, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(om.hprod(x, y, v, 0.7), H @ v, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(H).max()))
 
 
 def test_operator_zoo_first_and_second_derivatives(built):
