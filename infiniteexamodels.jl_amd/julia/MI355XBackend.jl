@@ -105,6 +105,17 @@ function NLPModels.hess_structure!(m::MI355XModel, rows::AbstractVector{Int}, co
     return rows, cols
 end
 
+NLPModels.jprod!(m::MI355XModel, x::ROCVector{Float64}, v::ROCVector{Float64}, Jv::ROCVector{Float64}) =
+    (check(ccall((:iem_jprod, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), m.handle, dptr(x), dptr(v), dptr(Jv))); Jv)
+NLPModels.jtprod!(m::MI355XModel, x::ROCVector{Float64}, v::ROCVector{Float64}, Jtv::ROCVector{Float64}) =
+    (check(ccall((:iem_jtprod, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), m.handle, dptr(x), dptr(v), dptr(Jtv))); Jtv)
+function NLPModels.hprod!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Float64}, v::ROCVector{Float64},
+                          Hv::ROCVector{Float64}; obj_weight = 1.0)
+    check(ccall((:iem_hprod, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}),
+                m.handle, dptr(x), dptr(y), dptr(v), obj_weight, dptr(Hv)))
+    return Hv
+end
+
 # ExaModels.set_parameter!(core, param, vals)  (src/infiniteopt_backend.jl:522,546)
 function set_parameter!(m::MI355XModel, param, vals)
     v = collect(Float64, vec(vals))
