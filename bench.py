@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--nt", type=int, default=1)
     ap.add_argument("--fma", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
+    ap.add_argument("--hess-layout", choices=("exa", "merged"), default="exa",
+                    help="'merged' is an opt-in extension (not the reference's COO layout; not the headline metric)")
     ap.add_argument("--emulate-shard", default="", help="R/N: time shard R of an N-way sharded run on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
@@ -133,7 +135,7 @@ def main():
     else:
         core, S_local = shard.quadrotor_shard(S_global, rank, world)
     blob = core.to_blob()
-    gm = ExaModel(core, device=local_rank, blob=blob)
+    gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout)
     del blob
     x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22, seed=rank * 2)
     xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
@@ -196,7 +198,7 @@ def main():
             "config": {"workload": f"quadrotor (examples/quadrotor.jl), backward FD, {int(supports_total)} supports total, "
                                    f"{S_local} per GPU, jac_coord!+hess_coord! only, seed 0/1 inputs resident in HBM",
                        "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
-                       "store_mode": args.store_mode, "parallelism": f"support-sharded x{world}"},
+                       "store_mode": args.store_mode, "hess_layout": args.hess_layout, "parallelism": f"support-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes": alg, "kernel_ms": ms_dom,

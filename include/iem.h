@@ -127,9 +127,16 @@ int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int6
 int iem_emit_source(const void *blob, size_t nbytes, char **out_src, uint64_t *out_key);
 /* text description of the launches (kernel name, grid, argument tables) — for tooling/tests */
 int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt);
+/* Hessian structure of a blob under the current options, computed on the host (tooling/tests;
+ * arrays are malloc'ed, release with iem_free). */
+int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t **out_rows, int64_t **out_cols, int64_t *out_nnz);
 void iem_free(void *p);
 
-/* knobs: "store_mode" 0 = direct strided stores, 1 = LDS-transposed coalesced stores */
+/* knobs (set BEFORE iem_create / iem_emit_*): "store_mode" 0 direct strided stores, 1 wave-level
+ * LDS-transposed stores, 2 (default) workgroup-staged 128-B-aligned stores; "nt_stores";
+ * "block" (workgroup size); "lds_slots"; "fp_contract"; "hess_merge" = 1 selects the opt-in
+ * MERGED Hessian layout (duplicate (row,col) slots of one support summed in registers: fewer
+ * nnzh, not ExaModels' COO layout — hess_structure!/hess_coord! stay mutually consistent). */
 int iem_set_option(const char *name, int64_t value);
 
 /* per-kernel timing of the last jac/hess call pair, measured with HIP events on the

@@ -306,6 +306,29 @@ int structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base, b
   if (!ptrs.empty()) HIP_TRY(hipMemcpy(d_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice));
   std::vector<void *> to_free{(void *)d_ptrs};
   int rc = IEM_OK;
+  if (hess && !m->prog.hess_classes.empty()) {
+    for (const iem::HessClass &hc : m->prog.hess_classes) {
+      const int ns = (int)hc.idx_i.size();
+      if (ns == 0) continue;
+      std::vector<IdxDescH> a(ns), b(ns);
+      for (int s = 0; s < ns; ++s) {
+        a[s] = make_idx_desc(m->model.tpl[hc.idx_i[s] / 65536], hc.idx_i[s] % 65536, slot);
+        b[s] = make_idx_desc(m->model.tpl[hc.idx_j[s] / 65536], hc.idx_j[s] % 65536, slot);
+      }
+      IdxDescH *da = nullptr, *db = nullptr;
+      HIP_TRY(hipMalloc((void **)&da, sizeof(IdxDescH) * ns)); to_free.push_back(da);
+      HIP_TRY(hipMalloc((void **)&db, sizeof(IdxDescH) * ns)); to_free.push_back(db);
+      HIP_TRY(hipMemcpy(da, a.data(), sizeof(IdxDescH) * ns, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(db, b.data(), sizeof(IdxDescH) * ns, hipMemcpyHostToDevice));
+      const iem::Template &t = m->model.tpl[hc.tpl];
+      StructArgsH A{(long long *)d_rows, (long long *)d_cols, da, db, d_ptrs, t.dims[0], t.dims[1], hc.n_items, hc.o, 0, base, ns};
+      size_t sz = sizeof A;
+      void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      long long total = hc.n_items * ns;
+      hipError_t e = hipModuleLaunchKernel(m->fn_struct, (unsigned)((total + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg);
+      if (e != hipSuccess) { rc = fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e)); break; }
+    }
+  } else
   for (const iem::Template &t : m->model.tpl) {
     int ns = hess ? t.o2step : t.o1step;
     if (ns == 0 || (!hess && t.kind != IEM_T_CON)) continue;
@@ -353,6 +376,26 @@ void jac_structure_host(const iem::Model &m, int64_t *rows, int64_t *cols, int b
   }
 }
 
+void hess_structure_merged_host(const iem::Model &m, const std::vector<iem::HessClass> &classes, int64_t *rows,
+                                int64_t *cols, int base) {
+  for (const iem::HessClass &hc : classes) {
+    std::map<int, ItemIdx> evals;
+    for (size_t s = 0; s < hc.idx_i.size(); ++s)
+      for (int v : {hc.idx_i[s], hc.idx_j[s]})
+        if (!evals.count(v / 65536)) evals.emplace(v / 65536, ItemIdx(m, m.tpl[v / 65536]));
+    const int ns = (int)hc.idx_i.size();
+    for (int64_t k = 0; k < hc.n_items; ++k) {
+      for (auto &kv : evals) kv.second.eval(k);
+      for (int s = 0; s < ns; ++s) {
+        int64_t a = evals.at(hc.idx_i[s] / 65536).idx[hc.idx_i[s] % 65536];
+        int64_t b = evals.at(hc.idx_j[s] / 65536).idx[hc.idx_j[s] % 65536];
+        rows[hc.o + (int64_t)ns * k + s] = (a >= b ? a : b) - 1 + base;
+        cols[hc.o + (int64_t)ns * k + s] = (a >= b ? b : a) - 1 + base;
+      }
+    }
+  }
+}
+
 void hess_structure_host(const iem::Model &m, int64_t *rows, int64_t *cols, int base) {
   for (const iem::Template &t : m.tpl) {
     if (t.o2step == 0) continue;
@@ -382,6 +425,7 @@ int iem_set_option(const char *name, int64_t value) {
   if (!name) return fail(IEM_E_ARG, "null option name");
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "hess_merge") == 0) { g_opt.hess_merge = (int)value; return IEM_OK; }
   if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }
   if (std::strcmp(name, "block") == 0) {
     if (value < 64 || value > 1024 || value % 64) return fail(IEM_E_ARG, "block must be a multiple of 64 in 64..1024");
@@ -433,6 +477,23 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
       *out_txt = (char *)std::malloc(s.size() + 1);
       std::memcpy(*out_txt, s.c_str(), s.size() + 1);
     }
+    return IEM_OK;
+  } catch (const std::exception &e) {
+    return fail(IEM_E_BLOB, e.what());
+  }
+}
+
+int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t **out_rows, int64_t **out_cols, int64_t *out_nnz) {
+  try {
+    iem::Model model;
+    iem::parse_blob(blob, nbytes, model);
+    iem::Program p = iem::generate(model, g_opt);
+    int64_t n = p.hess_classes.empty() ? model.nnzh : p.nnzh_merged;
+    int64_t *r = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1));
+    int64_t *c = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1));
+    if (!p.hess_classes.empty()) hess_structure_merged_host(model, p.hess_classes, r, c, base);
+    else hess_structure_host(model, r, c, base);
+    *out_rows = r; *out_cols = c; *out_nnz = n;
     return IEM_OK;
   } catch (const std::exception &e) {
     return fail(IEM_E_BLOB, e.what());
@@ -507,7 +568,8 @@ int iem_destroy(iem_model *m) {
 int iem_meta(const iem_model *m, iem_meta_t *out) {
   if (!m || !out) return fail(IEM_E_ARG, "null argument");
   out->nvar = m->model.nvar; out->ncon = m->model.ncon; out->npar = m->model.npar;
-  out->nnzj = m->model.nnzj; out->nnzh = m->model.nnzh;
+  out->nnzj = m->model.nnzj;
+  out->nnzh = m->prog.hess_classes.empty() ? m->model.nnzh : m->prog.nnzh_merged;
   out->n_templates = (int64_t)m->model.tpl.size();
   out->minimize = m->model.minimize;
   out->n_kernels = (int32_t)m->prog.kernels.size();
@@ -656,7 +718,8 @@ int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) 
 
 int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
   if (!m || ((!h_rows || !h_cols) && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
-  hess_structure_host(m->model, h_rows, h_cols, base);
+  if (!m->prog.hess_classes.empty()) hess_structure_merged_host(m->model, m->prog.hess_classes, h_rows, h_cols, base);
+  else hess_structure_host(m->model, h_rows, h_cols, base);
   return IEM_OK;
 }
 

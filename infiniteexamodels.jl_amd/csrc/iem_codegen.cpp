@@ -122,6 +122,8 @@ struct Output {
   std::vector<int> vals;      // DAG ids
   std::vector<int> grad_idx;  // KK_GRAD: IdxVal ids (0-based) per value
   std::vector<int> grad_mode; // 0 exclusive store, 1 wave-uniform, 2 atomic
+  std::vector<int> slot_ia, slot_ib;  // KK_HESS: 1-based IdxVal ids of each slot's pair
+  std::vector<int> slot_ti, slot_tj;  // ... and the template-local index-expression ids
   bool scalar = false;
   int64_t qlo[3] = {0, 0, 0}, qhi[3] = {1, 1, 1};  // valid q range of the template in the launch domain
 };
@@ -728,9 +730,13 @@ class KernelBuilder {
           }
           tg.hr0(t.root, 0, adj, C(0.0));
           o.vals = tg.slots2;
+          for (int s2 = 0; s2 < t.o2step; ++s2) {
+            o.slot_ia.push_back(tg.idx1(t.slot2_i[s2])); o.slot_ib.push_back(tg.idx1(t.slot2_j[s2]));
+            o.slot_ti.push_back(t.slot2_i[s2]); o.slot_tj.push_back(t.slot2_j[s2]);
+          }
           IdxVal iv; iv.aff = klin_aff(t, G, t.o2step, t.o2);
           o.pos_idx = idxval(iv);
-          alg_w_ += t.n_items * t.o2step;
+          if (!opt_.hess_merge) alg_w_ += t.n_items * t.o2step;
           break;
         }
       }
@@ -738,6 +744,63 @@ class KernelBuilder {
       outs_.push_back(std::move(o));
     }
     return !outs_.empty();
+  }
+
+  // Opt-in merged Hessian layout: templates of this kernel that cover the same lanes form a
+  // class; slots of a class with the same unordered index pair always hit the same (row, col),
+  // so the lane sums them in registers and the class owns one contiguous block
+  // [o, o + n_items*nslots).  Not ExaModels' layout: for solvers that only need a consistent
+  // hess_structure!/hess_coord! pair.
+  void merge_hess(int64_t &o2m, std::vector<HessClass> &classes) {
+    std::vector<Output> merged;
+    std::vector<char> used(outs_.size(), 0);
+    for (size_t a = 0; a < outs_.size(); ++a) {
+      if (used[a]) continue;
+      Output m = outs_[a];
+      m.vals.clear(); m.slot_ia.clear(); m.slot_ib.clear(); m.slot_ti.clear(); m.slot_tj.clear();
+      std::map<std::pair<int, int>, int> slot_of;
+      for (size_t b = a; b < outs_.size(); ++b) {
+        const Output &ob = outs_[b];
+        if (used[b] || ob.guard != outs_[a].guard || ob.scalar != outs_[a].scalar) continue;
+        if (ob.scalar && b != a) continue;   // single-item templates stay separate
+        used[b] = 1;
+        for (size_t s = 0; s < ob.vals.size(); ++s) {
+          auto key = std::make_pair(std::min(ob.slot_ia[s], ob.slot_ib[s]), std::max(ob.slot_ia[s], ob.slot_ib[s]));
+          auto it = slot_of.find(key);
+          if (it == slot_of.end()) {
+            slot_of.emplace(key, (int)m.vals.size());
+            m.vals.push_back(ob.vals[s]);
+            m.slot_ia.push_back(ob.slot_ia[s]); m.slot_ib.push_back(ob.slot_ib[s]);
+            // representative index expressions, re-expressed in the FIRST template's tables is not
+            // possible in general, so each slot remembers the template it came from
+            m.slot_ti.push_back((int)b * 65536 + ob.slot_ti[s]); m.slot_tj.push_back((int)b * 65536 + ob.slot_tj[s]);
+          } else {
+            m.vals[it->second] = add(m.vals[it->second], ob.vals[s]);
+          }
+        }
+      }
+      const Template &t = m_.tpl[m.tpl];
+      HessClass hc;
+      hc.tpl = m.tpl; hc.n_items = m.scalar ? 1 : t.n_items; hc.o = o2m;
+      for (size_t s = 0; s < m.vals.size(); ++s) {
+        hc.idx_i.push_back(m.slot_ti[s]); hc.idx_j.push_back(m.slot_tj[s]);
+      }
+      // the class position as a function of q: same item box as its first template
+      TGeo G = geo(m.tpl, m.scalar);
+      IdxVal iv; iv.aff = klin_aff(t, G, (int64_t)m.vals.size(), o2m);
+      m.pos_idx = idxval(iv);
+      o2m += hc.n_items * (int64_t)m.vals.size();
+      alg_w_ += hc.n_items * (int64_t)m.vals.size();
+      // resolve (output index, idx id) → (template id, idx id)
+      for (size_t s = 0; s < hc.idx_i.size(); ++s) {
+        int ob_i = hc.idx_i[s] / 65536, ob_j = hc.idx_j[s] / 65536;
+        hc.idx_i[s] = outs_[ob_i].tpl * 65536 + hc.idx_i[s] % 65536;
+        hc.idx_j[s] = outs_[ob_j].tpl * 65536 + hc.idx_j[s] % 65536;
+      }
+      classes.push_back(hc);
+      merged.push_back(std::move(m));
+    }
+    outs_ = std::move(merged);
   }
 
   // gradient store classification (needs every objective slot of the model)
@@ -1285,6 +1348,7 @@ Program generate(const Model &m, const Options &opt) {
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
       if (!kb->build(nullptr)) continue;
+      if (kind == KK_HESS && opt.hess_merge) kb->merge_hess(P.nnzh_merged, P.hess_classes);
       KernelDesc kd;
       kd.name = name;
       kd.kind = kind;

@@ -33,10 +33,19 @@ struct Options {
   int block = 512;     // workgroup size of the fused kernels (multiple of 64); 512 halves the partial cache lines at block seams
   int lds_slots = 24;  // store_mode 2: values per lane staged per barrier pair (LDS = 2 KB x this per workgroup)
   int reorder = 1;     // 1: emit cheap templates first so the store stream starts early
+  int hess_merge = 0;  // 1: opt-in merged Hessian layout (duplicate (row,col) slots of one support summed in registers)
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
   int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels
   int nt_stores = 1;   // 1: non-temporal stores for the streamed COO outputs
   int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)
+};
+
+// one block of the merged Hessian layout: `nslots` values per item, position o + nslots*k + s;
+// slot s is the pair (idx_i[s], idx_j[s]) of index-expression ids of template `tpl`
+struct HessClass {
+  int tpl = 0;
+  int64_t n_items = 0, o = 0;
+  std::vector<int> idx_i, idx_j;
 };
 
 struct Program {
@@ -44,6 +53,8 @@ struct Program {
   uint64_t key = 0;
   std::vector<KernelDesc> kernels;
   int64_t n_partials = 0;
+  std::vector<HessClass> hess_classes;  // non-empty iff Options::hess_merge
+  int64_t nnzh_merged = 0;
   // 0-based index ranges [lo, hi] of g that the gradient kernels overwrite completely
   std::vector<std::pair<int64_t, int64_t>> grad_covered;      // KK_GRAD
   std::vector<std::pair<int64_t, int64_t>> covered[KK_COUNT];  // per scatter kind (grad, jtprod, hprod)

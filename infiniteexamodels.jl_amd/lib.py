@@ -41,7 +41,7 @@ class KernelInfo(C.Structure):
 SYMBOLS = ["iem_create", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_last_error", "iem_version"]
 
 
@@ -128,6 +128,23 @@ def emit_launch_plan(blob: bytes) -> str:
         return C.string_at(p).decode()
     finally:
         L.iem_free(p)
+
+
+def blob_hess_structure(blob: bytes, base: int = 0):
+    """Hessian structure of a blob under the current options (host computation, no device)."""
+    import numpy as np
+    L = lib()
+    L.iem_blob_hess_structure.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_int64)]
+    r, c, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+    check(L.iem_blob_hess_structure(blob, len(blob), base, C.byref(r), C.byref(c), C.byref(n)))
+    try:
+        rows = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_int64)), shape=(max(n.value, 1),))[:n.value].copy()
+        cols = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_int64)), shape=(max(n.value, 1),))[:n.value].copy()
+    finally:
+        L.iem_free(r)
+        L.iem_free(c)
+    return rows, cols
 
 
 def precompile(blob: bytes, arch: str = "gfx950", force: bool = False) -> str:

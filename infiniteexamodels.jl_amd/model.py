@@ -42,7 +42,11 @@ def _ptr(t) -> int:
 class ExaModel:
     """Device-resident NLP model built from an :class:`ExaCore`."""
 
-    def __init__(self, core: ExaCore, device: Optional[int] = None, blob: Optional[bytes] = None):
+    def __init__(self, core: ExaCore, device: Optional[int] = None, blob: Optional[bytes] = None,
+                 hess_layout: str = "exa"):
+        """``hess_layout``: ``"exa"`` = ExaModels' COO layout (default, what parity is stated on);
+        ``"merged"`` = opt-in layout in which duplicate ``(row, col)`` slots of one support are
+        summed in registers (smaller ``nnzh``; ``hess_structure``/``hess_coord`` stay consistent)."""
         import torch
 
         if device is None:
@@ -54,8 +58,15 @@ class ExaModel:
         self.device = torch.device("cuda", device)
         self._L = _lib.lib()
         blob = blob if blob is not None else core.to_blob()
+        if hess_layout not in ("exa", "merged"):
+            raise ValueError(hess_layout)
+        self.hess_layout = hess_layout
         h = C.c_void_p()
-        _lib.check(self._L.iem_create(blob, len(blob), device, C.byref(h)))
+        _lib.set_option("hess_merge", 1 if hess_layout == "merged" else 0)
+        try:
+            _lib.check(self._L.iem_create(blob, len(blob), device, C.byref(h)))
+        finally:
+            _lib.set_option("hess_merge", 0)
         self._h = h
         core._model = self
         m = _lib.Meta()
@@ -101,7 +112,7 @@ class ExaModel:
         for k in range(self.meta.n_kernels):
             ki = _lib.KernelInfo()
             _lib.check(self._L.iem_kernel_info(self._h, k, C.byref(ki)))
-            out.append(dict(name=ki.name.decode(), kind=("cons", "jac", "hess", "obj", "grad")[ki.kind],
+            out.append(dict(name=ki.name.decode(), kind=("cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod")[ki.kind],
                             grid=tuple(ki.grid), lds_bytes=int(ki.lds_bytes), jit=bool(ki.jit),
                             alg_bytes_read=int(ki.alg_bytes_read), alg_bytes_written=int(ki.alg_bytes_written)))
         return out

@@ -68,3 +68,25 @@ def test_cross_template_cse(built):
     jac = src[src.index("void iem_jac_g0"):src.index("void iem_hess_g0")]
     assert jac.count("sincos(") == 3 and jac.count(" tan(") == 1
     assert jac.count("? X[") == 6   # x7, x8, x9, u1, u2, u3 (u4 and every affine row enter linearly: no loads)
+
+
+@pytest.mark.parametrize("name", ["quadrotor_100", "pandemic_20x3", "opf_7", "operator_zoo", "irregular", "rosenbrock"])
+def test_merged_hessian_layout_is_equivalent(name, built):
+    """Opt-in merged layout: fewer entries, same matrix (dense sums equal), lower triangular."""
+    from helpers import coo_to_dense
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    iemlib.set_option("hess_merge", 1)
+    try:
+        r, c = iemlib.blob_hess_structure(blob)
+        h = EmulatedModel(core, blob).hess_coord(x, y, 0.7, len(r))
+    finally:
+        iemlib.set_option("hess_merge", 0)
+    assert len(r) < om.nnzh and (r >= c).all() and not np.isnan(h).any()
+    ro, co = om.hess_structure()
+    D = coo_to_dense(r, c, h, (om.nvar, om.nvar))
+    Do = coo_to_dense(ro, co, om.hess_coord(x, y, 0.7), (om.nvar, om.nvar))
+    np.testing.assert_allclose(D, Do, rtol=1e-13, atol=1e-13 * max(1.0, np.abs(Do).max()))

@@ -270,3 +270,35 @@ def test_eval_loop_is_graph_capturable(torch_cuda):
     _close(jv.cpu().numpy(), om.jac_coord(x1), "jac (graph)")
     _close(hv.cpu().numpy(), om.hess_coord(x1, y1, 0.4), "hess (graph)")
     gm.close()
+
+
+@pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "opf_600", "irregular"])
+def test_merged_hessian_layout_gpu(name, torch_cuda):
+    """hess_layout="merged": structure (host and device) and values are mutually consistent and
+    sum to the oracle's Hessian."""
+    torch = torch_cuda
+    import scipy.sparse as sp
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    gm = ExaModel(core, device=0, blob=blob, hess_layout="merged")
+    assert gm.meta.nnzh < om.nnzh
+    x, y = cases.eval_point_for(name, om)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    hv = torch.full((gm.meta.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
+    h = gm.hess_coord(xd, yd, hv, obj_weight=0.7).cpu().numpy()
+    r, c = gm.hess_structure()
+    rd, cd = gm.hess_structure_device()
+    assert np.array_equal(rd.cpu().numpy(), r) and np.array_equal(cd.cpu().numpy(), c) and (r >= c).all()
+    ro, co = om.hess_structure()
+    A = sp.coo_matrix((h, (r, c)), shape=(om.nvar, om.nvar)).tocsr()
+    B = sp.coo_matrix((om.hess_coord(x, y, 0.7), (ro, co)), shape=(om.nvar, om.nvar)).tocsr()
+    d = abs(A - B)
+    assert (d.max() if d.nnz else 0.0) <= 1e-10 * max(1.0, abs(B).max())
+    # jac / cons / hprod are unaffected by the Hessian layout
+    _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac")
+    v = np.random.default_rng(2).standard_normal(om.nvar)
+    _close(gm.hprod(xd, yd, torch.tensor(v, device="cuda"), obj_weight=0.7).cpu().numpy(), om.hprod(x, y, v, 0.7), "hprod")
+    gm.close()
