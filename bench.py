@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
     ap.add_argument("--hess-layout", choices=("exa", "merged"), default="exa",
                     help="'merged' is an opt-in extension (not the reference's COO layout; not the headline metric)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo + --same-device rehearses the N>1 path with several ranks on ONE GPU")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--emulate-shard", default="", help="R/N: time shard R of an N-way sharded run on this GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
@@ -98,6 +101,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torchrun (RANK set) the process group is always created — also at world 1, so the
@@ -106,11 +111,18 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            if args.dist_backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
     if not os.path.exists(iemlib.LIB_PATH):   # the prebuilt in-tree library is the normal case; never let N ranks run make at once
         if rank == 0:
             iemlib.build_library()
@@ -157,10 +169,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        sl = torch.tensor([float(S_local)], device=dev, dtype=torch.float64)
+        sl = torch.tensor([float(S_local)], device=red_dev, dtype=torch.float64)
         dist.all_reduce(sl)
         supports_total = float(sl.item())
     else:
