@@ -109,6 +109,7 @@ struct iem_model {
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *h_obj = nullptr;  // pinned
   std::map<int, void *> d_arrays;  // model array id -> device copy
+  std::vector<void *> d_tables;    // per kernel: device copy of {ip, dp, fa, ia} when they do not fit the argument block
   std::vector<double> theta_host;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool jit = false;
@@ -209,14 +210,20 @@ int launch(iem_model *m, size_t k, const double *x, const double *y, double *out
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
   push_ptr(x); push_ptr(m->d_theta); push_ptr(y); push_ptr(v); push_ptr(out);
   uint64_t wb; std::memcpy(&wb, &w, 8); buf.push_back(wb);
-  for (int64_t v : kd.ip) buf.push_back((uint64_t)v);
-  if (kd.ip.empty()) buf.push_back(0);
-  for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); buf.push_back(b); }
-  if (kd.dp.empty()) buf.push_back(0);
-  for (int id : kd.fa) push_ptr(m->d_arrays[id]);
-  if (kd.fa.empty()) buf.push_back(0);
-  for (int id : kd.ia) push_ptr(m->d_arrays[id]);
-  if (kd.ia.empty()) buf.push_back(0);
+  if (kd.tables_in_memory) {
+    const uint64_t *tb = (const uint64_t *)m->d_tables[k];
+    size_t nip = std::max<size_t>(1, kd.ip.size()), ndp = std::max<size_t>(1, kd.dp.size()), nfa = std::max<size_t>(1, kd.fa.size());
+    push_ptr(tb); push_ptr(tb + nip); push_ptr(tb + nip + ndp); push_ptr(tb + nip + ndp + nfa);
+  } else {
+    for (int64_t v : kd.ip) buf.push_back((uint64_t)v);
+    if (kd.ip.empty()) buf.push_back(0);
+    for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); buf.push_back(b); }
+    if (kd.dp.empty()) buf.push_back(0);
+    for (int id : kd.fa) push_ptr(m->d_arrays[id]);
+    if (kd.fa.empty()) buf.push_back(0);
+    for (int id : kd.ia) push_ptr(m->d_arrays[id]);
+    if (kd.ia.empty()) buf.push_back(0);
+  }
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
@@ -466,7 +473,7 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     os << "partials " << p.n_partials << "\n";
     for (const iem::KernelDesc &kd : p.kernels) {
       os << "kernel " << kd.name << " kind " << kd.kind << " grid " << kd.grid[0] << " " << kd.grid[1] << " " << kd.grid[2]
-         << " lds " << kd.lds_bytes << " rbytes " << kd.alg_bytes_read << " wbytes " << kd.alg_bytes_written << " block " << kd.block << "\n";
+         << " lds " << kd.lds_bytes << " rbytes " << kd.alg_bytes_read << " wbytes " << kd.alg_bytes_written << " block " << kd.block << " tim " << (kd.tables_in_memory ? 1 : 0) << "\n";
       os << "ip " << kd.ip.size(); for (int64_t v : kd.ip) os << " " << v; os << "\n";
       os << "dp " << kd.dp.size(); for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); os << " " << b; } os << "\n";
       os << "fa " << kd.fa.size(); for (int v : kd.fa) os << " " << v; os << "\n";
@@ -534,6 +541,22 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
     for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return bail(rc);
     for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return bail(rc);
   }
+  m->d_tables.assign(m->prog.kernels.size(), nullptr);
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k) {
+    const iem::KernelDesc &kd = m->prog.kernels[k];
+    if (!kd.tables_in_memory) continue;
+    std::vector<uint64_t> tb;
+    for (int64_t v : kd.ip) tb.push_back((uint64_t)v);
+    if (kd.ip.empty()) tb.push_back(0);
+    for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); tb.push_back(b); }
+    if (kd.dp.empty()) tb.push_back(0);
+    for (int id : kd.fa) tb.push_back((uint64_t)(uintptr_t)m->d_arrays[id]);
+    if (kd.fa.empty()) tb.push_back(0);
+    for (int id : kd.ia) tb.push_back((uint64_t)(uintptr_t)m->d_arrays[id]);
+    if (kd.ia.empty()) tb.push_back(0);
+    if (hipMalloc(&m->d_tables[k], tb.size() * 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc tables"));
+    if (hipMemcpy(m->d_tables[k], tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(IEM_E_HIP, "upload tables"));
+  }
   for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) {
     // complement of the ranges the scatter kernels of this kind overwrite completely
     auto cov = m->prog.covered[kind];
@@ -558,6 +581,7 @@ int iem_destroy(iem_model *m) {
   if (m->d_obj) hipFree(m->d_obj);
   if (m->h_obj) hipHostFree(m->h_obj);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
+  for (void *t : m->d_tables) if (t) hipFree(t);
   if (m->ev0) hipEventDestroy(m->ev0);
   if (m->ev1) hipEventDestroy(m->ev1);
   if (m->mod) hipModuleUnload(m->mod);

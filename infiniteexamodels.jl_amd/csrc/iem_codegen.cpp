@@ -1137,8 +1137,14 @@ class KernelBuilder {
     std::ostringstream os;
     size_t nip = std::max<size_t>(1, ipv_.size()), ndp = std::max<size_t>(1, dpv_.size());
     size_t nfa = std::max<size_t>(1, fav_.size()), nia = std::max<size_t>(1, iav_.size());
-    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n"
-       << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
+    // the kernel-argument segment is limited (4 KB): big tables move to device memory and the
+    // struct carries pointers instead — `A.ip[i]` reads the same either way (uniform scalar loads)
+    kd.tables_in_memory = (nip + ndp + nfa + nia) > 320;
+    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n";
+    if (kd.tables_in_memory)
+      os << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
+    else
+      os << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
     os << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt_.min_waves > 0 ? ", " + std::to_string(opt_.min_waves) : std::string())
        << ") void " << name_ << "(const Args_" << name_ << " A) {\n";
     os << "  const double* __restrict__ X = A.x; const double* __restrict__ TH = A.th; const double* __restrict__ Y = A.y;\n";

@@ -21,6 +21,7 @@ struct KernelDesc {
   std::vector<int> fa;      // const double* fa[]  (model array ids, uploaded as f64)
   std::vector<int> ia;      // const long long* ia[] (model array ids, uploaded as i64)
   int lds_bytes = 0;
+  bool tables_in_memory = false;  // ip/dp/fa/ia passed as pointers to device tables (argument block too large)
   int block = 256;          // threads per workgroup of this kernel
   int64_t partial_off = 0;  // KK_OBJ: first partial slot written by this kernel
   int64_t n_blocks = 1;

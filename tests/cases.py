@@ -119,6 +119,7 @@ def small_cases():
         "operator_zoo": operator_zoo,
         "irregular": irregular,
         "wide_rows": None,
+        "many_templates": None,
     }
 
 
@@ -140,6 +141,8 @@ def eval_point_for(name, om, seed=0):
 def build_core(name):
     if name == "wide_rows":
         return wide_rows()
+    if name == "many_templates":
+        return many_templates()
     return transcribe.exa_core(small_cases()[name]())
 
 
@@ -158,4 +161,20 @@ def wide_rows():
     core.add_con(FUNCS["sin"](prod), it)
     core.add_con(vs[0][ds.i] * vs[1][ds.i], it)
     core.add_obj(FUNCS["abs2"](vs[2][ds.i]), it)
+    return core
+
+
+def many_templates():
+    """200 distinct constraint templates over one grid: the kernel's offset tables no longer fit
+    the 4 KB argument block and travel through device memory instead."""
+    from infiniteexamodels.jl_amd import DataSource, ExaCore, Items, FUNCS
+    core = ExaCore()
+    n = 260
+    vs = [core.add_var(n, start=0.05 * (k + 1)) for k in range(40)]
+    ds = DataSource()
+    it = Items.from_supports("i", n, {"t": np.linspace(0, 1, n)}, group_id=1)
+    for k in range(200):
+        a, b, c = vs[k % 40], vs[(3 * k + 1) % 40], vs[(7 * k + 2) % 40]
+        core.add_con(a[ds.i] * FUNCS["sin"](b[ds.i]) + (0.1 + 0.01 * k) * c[ds.i] * c[ds.i], it)
+    core.add_obj(FUNCS["abs2"](vs[0][ds.i]) + vs[1][ds.i] * vs[2][ds.i], it)
     return core
