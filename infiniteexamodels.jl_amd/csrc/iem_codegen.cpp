@@ -1041,7 +1041,9 @@ class KernelBuilder {
             bool any = false;
             for (int d = 1; d < g_.nd; ++d) {
               if (o.qlo[d] > 0) { gb << (any ? " && " : "") << "q" << d << " >= " << coefstr(o.qlo[d]); any = true; }
-              if (o.qhi[d] < g_.ext[d]) { gb << (any ? " && " : "") << "q" << d << " < " << ip(o.qhi[d]); any = true; }
+              // a folded second dimension (blockIdx.y + gridDim.y*blockIdx.z) overshoots ext[1]
+              bool folded = d == 1 && g_.nd == 2 && g_.ext[1] > 65535;
+              if (o.qhi[d] < g_.ext[d] || folded) { gb << (any ? " && " : "") << "q" << d << " < " << ip(std::min(o.qhi[d], g_.ext[d])); any = true; }
             }
             int64_t k0 = pb.k[0];
             pb.k[0] = 0;
@@ -1084,8 +1086,14 @@ class KernelBuilder {
     // head: coordinates, guards, integer loads, index values, loads
     std::ostringstream head;
     head << "  const long long q0 = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
-    head << "  const long long q1 = blockIdx.y, q2 = blockIdx.z;\n";
-    head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+    if (g_.nd == 2 && g_.ext[1] > 65535) {
+      // second grid dimension longer than gridDim.y allows: fold it over blockIdx.z
+      head << "  const long long q1 = (long long)blockIdx.y + (long long)gridDim.y * blockIdx.z, q2 = 0;\n";
+      head << "  const bool inb = q0 < " << ip(g_.ext[0]) << " && q1 < " << ip(g_.ext[1]) << ";\n";
+    } else {
+      head << "  const long long q1 = blockIdx.y, q2 = blockIdx.z;\n";
+      head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+    }
     for (size_t gi = 0; gi < guards_.size(); ++gi) head << "  const bool g" << gi << " = " << guards_[gi] << ";\n";
     for (size_t i = 0; i < iloads_.size(); ++i) {
       head << "  const long long il" << i << " = " << guard_or(iloads_[i].guards) << " ? IA" << "[" << iloads_[i].ia_slot << "]["
@@ -1349,7 +1357,8 @@ Program generate(const Model &m, const Options &opt) {
   int64_t partial_off = 0;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const Group &g = groups[gi];
-    if (g.ext[1] > 65535 || g.ext[2] > 65535) throw std::runtime_error("support grid too large in dims 2/3 (limit 65535)");
+    if ((g.nd > 2 && g.ext[1] > 65535) || g.ext[2] > 65535 || g.ext[1] > 65535LL * 65535LL)
+      throw std::runtime_error("support grid too large in dims 2/3 (limit 65535 per dimension for 3-D grids)");
     for (int kind = 0; kind < KK_COUNT; ++kind) {
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
@@ -1360,6 +1369,7 @@ Program generate(const Model &m, const Options &opt) {
       kd.kind = kind;
       kd.block = opt.block;
       kd.grid[0] = (g.ext[0] + opt.block - 1) / opt.block; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
+      if (g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
       kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
       if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
       if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {

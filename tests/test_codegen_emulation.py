@@ -90,3 +90,19 @@ def test_merged_hessian_layout_is_equivalent(name, built):
     D = coo_to_dense(r, c, h, (om.nvar, om.nvar))
     Do = coo_to_dense(ro, co, om.hess_coord(x, y, 0.7), (om.nvar, om.nvar))
     np.testing.assert_allclose(D, Do, rtol=1e-13, atol=1e-13 * max(1.0, np.abs(Do).max()))
+
+
+def test_long_second_grid_dimension_is_folded(built):
+    """A 2-D support grid whose second extent exceeds gridDim.y (65535) is folded over blockIdx.z;
+    the overshoot blocks must neither load nor store."""
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    core = transcribe.exa_core(workloads.pandemic(2, 70000))     # 12 x 70000 supports
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
+    y = np.random.default_rng(1).standard_normal(om.ncon)
+    em = EmulatedModel(core, blob)
+    assert any(k["grid"][2] > 1 for k in em.kernels)
+    assert _rel(em.cons(x), om.cons(x)) <= 1e-14
+    assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
+    assert _rel(em.hess_coord(x, y, 1.0, om.nnzh), om.hess_coord(x, y, 1.0)) <= 1e-14

@@ -302,3 +302,25 @@ def test_merged_hessian_layout_gpu(name, torch_cuda):
     v = np.random.default_rng(2).standard_normal(om.nvar)
     _close(gm.hprod(xd, yd, torch.tensor(v, device="cuda"), obj_weight=0.7).cpu().numpy(), om.hprod(x, y, v, 0.7), "hprod")
     gm.close()
+
+
+def test_folded_second_dimension_gpu(torch_cuda):
+    """12 x 70000 supports: the second grid dimension is folded over blockIdx.z."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    core = transcribe.exa_core(workloads.pandemic(2, 70000))
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    om.set_threads(min(16, om.max_threads()))
+    gm = ExaModel(core, device=0, blob=blob)
+    x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
+    y = np.random.default_rng(1).standard_normal(om.ncon)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    nanv = lambda n: torch.full((n,), float("nan"), device="cuda", dtype=torch.float64)
+    _close(gm.cons(xd, nanv(om.ncon)).cpu().numpy(), om.cons(x), "cons")
+    _close(gm.jac_coord(xd, nanv(om.nnzj)).cpu().numpy(), om.jac_coord(x), "jac")
+    _close(gm.hess_coord(xd, yd, nanv(om.nnzh)).cpu().numpy(), om.hess_coord(x, y, 1.0), "hess")
+    assert abs(gm.obj(xd) - om.obj(x)) <= 1e-10 * max(1.0, abs(om.obj(x)))
+    gm.close()
