@@ -67,7 +67,8 @@ def _tree(rng, leaves, depth):
 
 def random_core(seed: int) -> ExaCore:
     rng = np.random.default_rng(seed)
-    n1 = int(rng.integers(5, 70))
+    # seeds >= 100: several workgroups per template (block seams, partial last blocks)
+    n1 = int(rng.integers(5, 70)) if seed < 100 else int(rng.integers(600, 2600))
     n2 = int(rng.integers(2, 6))
     core = ExaCore()
     z = core.add_var(1, start=0.3)                        # finite variable shared by every item
@@ -105,6 +106,7 @@ def random_core(seed: int) -> ExaCore:
 
 
 SEEDS = list(range(16))
+BIG_SEEDS = [100, 101, 102, 103]
 
 
 @pytest.mark.parametrize("seed", SEEDS)
@@ -171,3 +173,29 @@ def test_random_model_gpu(seed, built):
     _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac")
     _close(gm.hess_coord(xd, yd, obj_weight=0.6).cpu().numpy(), om.hess_coord(x, y, 0.6), "hess")
     gm.close()
+
+
+@pytest.mark.parametrize("seed", BIG_SEEDS)
+def test_random_model_multi_block_emulated(seed, built):
+    from emu import EmulatedModel
+    core = random_core(seed)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    rng = np.random.default_rng(1000 + seed)
+    x = om.x0 + 0.2 * rng.standard_normal(om.nvar)
+    y = rng.standard_normal(om.ncon)
+    em = EmulatedModel(core, blob)
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max())) if len(b) else 0.0
+
+    j, h = em.jac_coord(x, om.nnzj), em.hess_coord(x, y, 0.6, om.nnzh)
+    assert not np.isnan(j).any() and not np.isnan(h).any()
+    assert rel(j, om.jac_coord(x)) <= 1e-13 and rel(h, om.hess_coord(x, y, 0.6)) <= 1e-12
+    assert rel(em.cons(x), om.cons(x)) <= 1e-13 and rel(em.grad(x), om.grad(x)) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", BIG_SEEDS)
+def test_random_model_multi_block_gpu(seed, built):
+    test_random_model_gpu(seed, built)
