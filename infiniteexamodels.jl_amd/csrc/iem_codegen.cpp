@@ -1222,7 +1222,7 @@ class KernelBuilder {
 // ---------------------------------------------------------------------------
 // grouping + validation
 // ---------------------------------------------------------------------------
-std::vector<Group> make_groups(const Model &m) {
+std::vector<Group> make_groups(const Model &m, bool no_fuse) {
   std::vector<Group> groups;
   std::map<std::pair<int64_t, int>, int> by_key;
   std::vector<int> scalars;
@@ -1233,7 +1233,7 @@ std::vector<Group> make_groups(const Model &m) {
       continue;
     }
     int gi;
-    if (t.grid_id > 0) {
+    if (t.grid_id > 0 && !no_fuse) {
       auto key = std::make_pair(t.grid_id, t.nd);
       auto it = by_key.find(key);
       if (it == by_key.end()) {
@@ -1255,7 +1255,8 @@ std::vector<Group> make_groups(const Model &m) {
       groups.emplace_back();
       groups[gi].grid_id = -1 - (int64_t)ti;
       groups[gi].nd = t.nd;
-      for (int d = 0; d < 3; ++d) { groups[gi].lo[d] = 0; groups[gi].ext[d] = d < t.nd ? t.dims[d] : 1; }
+      // own launch domain = the template's item box (at its grid origin when it sits on a support grid)
+      for (int d = 0; d < 3; ++d) { groups[gi].lo[d] = (t.grid_id > 0 && d < t.nd) ? t.origin[d] : 0; groups[gi].ext[d] = d < t.nd ? t.dims[d] : 1; }
     }
     groups[gi].tpls.push_back((int)ti);
   }
@@ -1343,7 +1344,7 @@ void validate_indices(const Model &m) {
 Program generate(const Model &m, const Options &opt) {
   validate_indices(m);
   Program P;
-  std::vector<Group> groups = make_groups(m);
+  std::vector<Group> groups = make_groups(m, opt.no_fuse != 0);
   std::ostringstream src;
   src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";
   static const char *kname[] = {"cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod"};

@@ -34,6 +34,7 @@ struct Options {
   int block = 512;     // workgroup size of the fused kernels (multiple of 64); 512 halves the partial cache lines at block seams
   int lds_slots = 24;  // store_mode 2: values per lane staged per barrier pair (LDS = 2 KB x this per workgroup)
   int reorder = 1;     // 1: emit cheap templates first so the store stream starts early
+  int no_fuse = 0;     // 1: one kernel per template (the reference design's launch structure; baseline/ablation only)
   int hess_merge = 0;  // 1: opt-in merged Hessian layout (duplicate (row,col) slots of one support summed in registers)
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
   int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels

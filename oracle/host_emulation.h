@@ -1,6 +1,8 @@
-// emu_header.h — host stand-ins for the device primitives of iem_device.h so that the
-// GENERATED kernel bodies can be compiled with g++ and run one lane at a time
-// (tests/emu.py).  Test tool only; the HIP primitives themselves are exercised on the GPU.
+// host_emulation.h — host stand-ins for the device primitives of iem_device.h so that the
+// GENERATED kernel bodies can be compiled with g++ and run one lane at a time.
+// TEST / BASELINE INFRASTRUCTURE ONLY (like everything under oracle/): used by tests/emu.py
+// (generator checks without a GPU) and by oracle/cpu_compiled_baseline.py (a compiled,
+// per-template CPU baseline for bench.py).  The HIP primitives themselves run only on the GPU.
 #pragma once
 #include <cmath>
 #include <cstddef>
@@ -16,10 +18,10 @@
 #define __forceinline__ inline
 #define __launch_bounds__(x)
 #define __restrict__
-#define __shared__ static
+#define __shared__ static thread_local
 
 struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };
-static emu_dim3 threadIdx, blockIdx, gridDim;
+static thread_local emu_dim3 threadIdx, blockIdx, gridDim;
 
 inline int iem_lane() { return (int)(threadIdx.x & 63); }
 inline int iem_wave() { return (int)(threadIdx.x >> 6); }

@@ -1,4 +1,4 @@
-"""Generated kernels, compiled for the host against tests/emu_header.h and driven with the
+"""Generated kernels, compiled for the host against oracle/host_emulation.h and driven with the
 library's own launch plan, must reproduce the oracle — a GPU-free check of the generator
 (template fusion, symbolic sweeps, slot layout, guards, index arithmetic, block-store
 position arithmetic)."""
