@@ -294,7 +294,7 @@ class ExaCore:
             if grid is not None and len(grid[0]) == nd:
                 gid = 0
                 for g in grid[0]:
-                    gid = gid * 64 + (int(g) + 1)
+                    gid = gid * 4096 + (int(g) + 1)   # group ids (and virtual collocation grids) < 4095
                 origin = list(grid[1]) + [0] * (3 - nd)
             elif grid is not None and len(grid[0]) == 0:
                 gid, origin = 0, [0, 0, 0]

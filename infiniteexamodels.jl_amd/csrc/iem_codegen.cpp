@@ -54,6 +54,10 @@ struct Group {
   int nd = 1;
   int64_t lo[3] = {0, 0, 0}, ext[3] = {1, 1, 1};
   std::vector<int> tpls, scalars;
+  // flat: the box is walked by ONE linear lane index (q = q0 + ext0*(q1 + ext1*q2)) instead of
+  // lanes along dim 0 only — used when dim 0 is too short to fill a wave (e.g. the 2 x (S-1)
+  // item box of an OrthogonalCollocation(3) derivative)
+  bool flat = false;
 };
 
 std::string hexf(double v) {
@@ -1026,6 +1030,9 @@ class KernelBuilder {
           int ns = (int)o.vals.size();
           bool scalar_tpl = o.scalar;
           if (ns > ns_cap) scalar_tpl = true;   // direct strided stores for this template
+          bool full_box = true;
+          for (int d = 0; d < g_.nd; ++d) if (o.qlo[d] != 0 || o.qhi[d] != g_.ext[d]) full_box = false;
+          if (g_.flat && !full_box) scalar_tpl = true;   // item ordinal is not linear in the flat lane index
           if (opt_.store_mode == 2 && !scalar_tpl) {
             // stage now, flush with the rest of the batch (one barrier pair per batch)
             if (batch_slots + ns > lds_budget) flush_batch();
@@ -1047,10 +1054,17 @@ class KernelBuilder {
             }
             int64_t k0 = pb.k[0];
             pb.k[0] = 0;
+            if (g_.flat) {
+              // full-box template in a flat group: item ordinal == flat lane index
+              fl << "  { const long long pb = " << ip(pv.aff.c) << " + " << coefstr(k0) << " * qb0;\n";
+              fl << "    const int v0 = 0;\n";
+              fl << "    const int v1 = iem_clamp256(" << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << " - qb0);\n";
+            } else {
             fl << "  { const long long pb = " << aff_str(pb) << " + " << coefstr(k0) << " * qb0;\n";
             fl << "    const int v0 = iem_clamp256(" << coefstr(o.qlo[0]) << " - qb0);\n";
             fl << "    const int v1 = " << (any ? "(" + gb.str() + ") ? " : "") << "iem_clamp256(" << ip(std::min(o.qhi[0], g_.ext[0])) << " - qb0)"
                << (any ? " : v0" : "") << ";\n";
+            }
             fl << "    iem_flush<" << ns << ">(OUT, pb, v0, v1, lds_blk + " << (batch_slots * opt_.block) << "); }\n";
             pending_flush.push_back(fl.str());
             batch_slots += ns;
@@ -1085,6 +1099,12 @@ class KernelBuilder {
 
     // head: coordinates, guards, integer loads, index values, loads
     std::ostringstream head;
+    if (g_.flat) {
+      head << "  const long long q = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
+      head << "  const bool inb = q < " << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << ";\n";
+      head << "  const long long q0 = q % " << ip(g_.ext[0]) << ", qr = q / " << ip(g_.ext[0]) << ";\n";
+      head << "  const long long q1 = qr % " << ip(g_.ext[1]) << ", q2 = qr / " << ip(g_.ext[1]) << ";\n";
+    } else {
     head << "  const long long q0 = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
     if (g_.nd == 2 && g_.ext[1] > 65535) {
       // second grid dimension longer than gridDim.y allows: fold it over blockIdx.z
@@ -1093,6 +1113,7 @@ class KernelBuilder {
     } else {
       head << "  const long long q1 = blockIdx.y, q2 = blockIdx.z;\n";
       head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+    }
     }
     for (size_t gi = 0; gi < guards_.size(); ++gi) head << "  const bool g" << gi << " = " << guards_[gi] << ";\n";
     for (size_t i = 0; i < iloads_.size(); ++i) {
@@ -1263,6 +1284,8 @@ std::vector<Group> make_groups(const Model &m, bool no_fuse) {
   for (auto &g : groups)
     if (g.grid_id > 0)
       for (int d = 0; d < g.nd; ++d) g.ext[d] -= g.lo[d];  // hi -> extent
+  for (auto &g : groups)
+    if (g.nd > 1 && g.ext[0] < 64 && g.ext[1] * g.ext[2] > 1) g.flat = true;
   if (!scalars.empty()) {
     if (groups.empty()) {
       groups.emplace_back();
@@ -1358,7 +1381,7 @@ Program generate(const Model &m, const Options &opt) {
   int64_t partial_off = 0;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const Group &g = groups[gi];
-    if ((g.nd > 2 && g.ext[1] > 65535) || g.ext[2] > 65535 || g.ext[1] > 65535LL * 65535LL)
+    if (!g.flat && ((g.nd > 2 && g.ext[1] > 65535) || g.ext[2] > 65535 || g.ext[1] > 65535LL * 65535LL))
       throw std::runtime_error("support grid too large in dims 2/3 (limit 65535 per dimension for 3-D grids)");
     for (int kind = 0; kind < KK_COUNT; ++kind) {
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
@@ -1370,7 +1393,8 @@ Program generate(const Model &m, const Options &opt) {
       kd.kind = kind;
       kd.block = opt.block;
       kd.grid[0] = (g.ext[0] + opt.block - 1) / opt.block; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
-      if (g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
+      if (g.flat) { kd.grid[0] = (g.ext[0] * g.ext[1] * g.ext[2] + opt.block - 1) / opt.block; kd.grid[1] = kd.grid[2] = 1; }
+      if (!g.flat && g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
       kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
       if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
       if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {
@@ -1398,7 +1422,8 @@ Program generate(const Model &m, const Options &opt) {
               }
               gs.lo = lo; gs.hi = hi; gs.injective = inj;
               gs.count = scalar ? 1 : t.n_items;
-              gs.uniform0 = !scalar && iv.aff.k[0] == 0 && t.dims[0] > 1;
+              // wave-uniform destination: every lane of a wave shares q1/q2 — not true for flat groups
+              gs.uniform0 = !g.flat && !scalar && iv.aff.k[0] == 0 && t.dims[0] > 1;
             } else {
               gs.lo = INT64_MIN; gs.hi = INT64_MAX;
             }

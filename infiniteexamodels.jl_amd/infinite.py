@@ -31,6 +31,28 @@ for _name in _UNARY:
         globals()[_name] = nl(_name)
 
 
+def OrthogonalCollocation(num_nodes: int):
+    """``OrthogonalCollocation(num_nodes)`` (Gauss–Lobatto; ``num_nodes`` counts the two element
+    boundaries, so ``num_nodes - 2`` internal supports are generated per interval)."""
+    if num_nodes < 2:
+        raise ValueError("OrthogonalCollocation needs at least 2 nodes")
+    return ("oc", int(num_nodes))
+
+
+def FiniteDifference(kind: str = "backward"):
+    return ("fd_" + kind,)
+
+
+def lobatto_internal_nodes(num_nodes: int) -> np.ndarray:
+    """Interior Gauss–Lobatto nodes on (−1, 1): the roots of P'_{n−1} (n = num_nodes)."""
+    n = num_nodes - 1
+    if n < 2:
+        return np.zeros(0)
+    c = np.zeros(n + 1)
+    c[n] = 1.0
+    return np.sort(np.polynomial.legendre.legroots(np.polynomial.legendre.legder(c)))
+
+
 def _round_sig(a: np.ndarray, sig: int = 12) -> np.ndarray:
     a = np.asarray(a, dtype=np.float64)
     out = a.copy()
@@ -55,6 +77,8 @@ class ParameterGroup:
         self.supports = np.zeros((0, 0))   # (n_supports, n_prefs); sorted for independent
         self.derivative_method = ("fd_backward",)
         self.lb = self.ub = None
+        self.public_supports = None      # set once generative (collocation) supports are merged in
+        self.internal = None             # bool per support: generated internal collocation node
 
     @property
     def num_supports(self) -> int:
@@ -231,6 +255,7 @@ class InfiniteModel:
         self.semi_infinite_variables: List[SemiInfiniteVariableRef] = []
         self.point_variables: List[PointVariableRef] = []
         self.constraints: List[ConstraintObject] = []
+        self.piecewise_vars: Dict[InfiniteParameterRef, list] = {}
         self.objective_sense: Optional[str] = None
         self.objective_function = None
         self.backend = backend
@@ -240,9 +265,11 @@ class InfiniteModel:
 
     # -- parameters ---------------------------------------------------------
     def infinite_parameter(self, name: str, lb: float = None, ub: float = None, num_supports: int = 0,
-                           supports: Sequence[float] = None) -> InfiniteParameterRef:
+                           supports: Sequence[float] = None, derivative_method=None) -> InfiniteParameterRef:
         g = ParameterGroup(len(self.groups) + 1, dependent=False)
         g.lb, g.ub = lb, ub
+        if derivative_method is not None:
+            g.derivative_method = tuple(derivative_method)
         if supports is not None:
             s = np.unique(_round_sig(np.asarray(supports, dtype=np.float64)))
         else:
@@ -271,6 +298,38 @@ class InfiniteModel:
         s = np.concatenate([g.supports[:, 0], _round_sig(np.asarray(values, dtype=np.float64))])
         g.supports = np.unique(s).reshape(-1, 1)
         self._ready = False
+
+    def set_derivative_method(self, pref: InfiniteParameterRef, method) -> None:
+        pref.group.derivative_method = tuple(method)
+        self._ready = False
+
+    def constant_over_collocation(self, var, pref: InfiniteParameterRef) -> None:
+        """``constant_over_collocation(u, t)``: ``u`` is held constant over the internal
+        collocation supports of each element (transform.jl:565-601)."""
+        self.piecewise_vars.setdefault(pref, [])
+        if all(v is not var for v in self.piecewise_vars[pref]):
+            self.piecewise_vars[pref].append(var)
+        self._ready = False
+
+    def add_generative_supports(self, g: ParameterGroup) -> None:
+        """``InfiniteOpt.add_generative_supports``: merge the internal collocation nodes of every
+        interval into the group's supports (idempotent)."""
+        if g.derivative_method[0] != "oc" or g.dependent:
+            return
+        if g.public_supports is None:
+            g.public_supports = g.supports[:, 0].copy()
+        pub = g.public_supports
+        nodes = lobatto_internal_nodes(g.derivative_method[1])
+        if len(nodes) == 0 or len(pub) < 2:
+            g.supports = pub.reshape(-1, 1)
+            g.internal = np.zeros(len(pub), dtype=bool)
+            return
+        lo, hi = pub[:-1], pub[1:]
+        inner = (lo[:, None] + hi[:, None]) / 2 + (hi[:, None] - lo[:, None]) / 2 * nodes[None, :]
+        allp = np.concatenate([np.column_stack([lo, _round_sig(inner)]).reshape(-1), pub[-1:]])
+        flag = np.concatenate([np.tile(np.r_[False, np.ones(len(nodes), dtype=bool)], len(lo)), [False]])
+        g.supports = allp.reshape(-1, 1)
+        g.internal = flag
 
     def finite_parameter(self, name: str, value: float) -> FiniteParameterRef:
         p = FiniteParameterRef(self, name, value)

@@ -70,6 +70,7 @@ def _build_base_iterators(data: ExaMappingData, m: InfiniteModel) -> None:
     raw = 0
     for g in m.groups:
         raw += 1
+        m.add_generative_supports(g)        # transform.jl:22
         for pref in g.prefs:
             data.param_alias[pref] = f"dp{raw}{pref.pos + 1}" if g.dependent else f"ip{raw}"
         itr_sym = f"group_idx{len(data.group_alias) + 1}"
@@ -78,7 +79,7 @@ def _build_base_iterators(data: ExaMappingData, m: InfiniteModel) -> None:
             data.support_to_index[(g.index, _supp_key(g.supports[i]))] = i + 1
         vals = {data.param_alias[p]: np.ascontiguousarray(g.supports[:, p.pos]) for p in g.prefs}
         data.base_itrs.append(Items.from_supports(itr_sym, g.num_supports, vals, group_id=g.index))
-        data.has_internal_supps.append(False)
+        data.has_internal_supps.append(bool(g.internal is not None and g.internal.any()))   # transform.jl:35
 
 
 # bounds / start ----------------------------------------------------------------
@@ -445,6 +446,45 @@ def derivative_expr_data(method: tuple, supps: np.ndarray):
     raise NotImplementedError(f"derivative method {method!r}")
 
 
+def collocation_items(pref, base_itr: Items, supps: np.ndarray, internal: np.ndarray, data: ExaMappingData) -> Items:
+    """Item iterator of an orthogonal-collocation derivative [EXT — InfiniteOpt
+    ``evaluate_derivative(::OrthogonalCollocation{GaussLobatto})`` restated]: for every element
+    with nodes ``t_0 (lower boundary), t_1..t_n`` one row per node ``j = 1..n``:
+
+        Σ_k Minvᵀ[k, j]·∂y(t_k) − y(t_j) + y(t_0) = 0,   M1ᵀ[k,j] = k·τ_j^{k−1}, M2ᵀ[k,j] = τ_j^k,
+        Minvᵀ = M1ᵀ \\ M2ᵀ,  τ_j = t_j − t_0.
+
+    Items form the box (j fastest, element): integer fields = node index (the group alias),
+    ``d_lb`` (lower-boundary index), ``d_n1..d_nn`` (the element's node indices); float fields
+    ``d_arg1..d_argn`` = column j of Minvᵀ."""
+    n_tot = len(supps)
+    lb_idx = np.nonzero(~internal)[0][:-1]                 # 0-based lower boundaries
+    n = int(lb_idx[1] - lb_idx[0]) if len(lb_idx) > 1 else n_tot - 1
+    assert np.all(np.diff(lb_idx) == n) and lb_idx[-1] + n == n_tot - 1
+    ne = len(lb_idx)
+    coef = np.zeros((ne, n, n))                             # [element, j, k]
+    for e, L in enumerate(lb_idx):
+        tau = supps[L + 1:L + 1 + n] - supps[L]
+        kk = np.arange(1, n + 1)[:, None]
+        M1t = kk * tau[None, :] ** (kk - 1)
+        M2t = tau[None, :] ** kk
+        Minvt = np.linalg.solve(M1t, M2t)                   # [k, j]
+        coef[e] = Minvt.T
+    alias = data.group_alias[pref.group.index - 1]
+    p_alias = data.param_alias[pref]
+    fields = {
+        alias: Field("int", "affine", 2, (1, n)),           # node index (1-based)
+        "d_lb": Field("int", "affine", 1, (0, n)),
+        p_alias: Field("float", "gather", 1, (1, n), np.ascontiguousarray(supps)),
+    }
+    for k in range(n):
+        fields[f"d_n{k + 1}"] = Field("int", "affine", 2 + k, (0, n))
+        fields[f"d_arg{k + 1}"] = Field("float", "gather", 0, (1, n), np.ascontiguousarray(coef[:, :, k].reshape(-1)))
+    # a virtual grid shared by every collocation template of this parameter → one fused kernel
+    gi = pref.group.index
+    return Items((n, ne), fields, grid=((1000 + gi, 2000 + gi), (0, 0)))
+
+
 def make_indexed_derivative_expr(dref, vref, pref, idx, data_src, data, method: tuple, d_args):
     """``InfiniteOpt.make_indexed_derivative_expr`` [EXT]; first order, finite differences.
     Backward: ``h·∂y[i] − y[i] + y[i−1]`` with ``h = tᵢ − tᵢ₋₁``."""
@@ -459,6 +499,14 @@ def make_indexed_derivative_expr(dref, vref, pref, idx, data_src, data, method: 
     if kind == "fd_central":
         return d_args[0] * d - _make_reduced_expr(vref, pref, idx + 1, data_src, data) \
             + _make_reduced_expr(vref, pref, idx - 1, data_src, data)
+    if kind == "oc":
+        n = len(d_args)
+        acc = None
+        for k in range(n):
+            term = d_args[k] * _make_reduced_expr(dref, pref, data_src[f"d_n{k + 1}"], data_src, data)
+            acc = term if acc is None else acc + term
+        return acc - _make_reduced_expr(vref, pref, idx, data_src, data) \
+            + _make_reduced_expr(vref, pref, data_src["d_lb"], data_src, data)
     raise NotImplementedError(kind)
 
 
@@ -476,11 +524,18 @@ def _add_derivative_approximations(core: ExaCore, data: ExaMappingData, m: Infin
             srt_itr, supps = base_itr.take(order), supps[order]
         else:
             srt_itr = base_itr
-        idxs, arg_cols = derivative_expr_data(method, supps)
-        aliases = [f"d_arg{i + 1}" for i in range(len(arg_cols))]
-        pref_itr = srt_itr.take(idxs)
-        for a, col in zip(aliases, arg_cols):
-            pref_itr = pref_itr.with_float(a, col)
+        if method[0] == "oc":
+            if pref.group.internal is None:
+                raise RuntimeError("collocation supports were not generated")
+            pref_itr = collocation_items(pref, srt_itr, supps, pref.group.internal, data)
+            aliases = [f"d_arg{i + 1}" for i in range(max(1, method[1] - 1))]
+            idxs = np.arange(1, len(supps))
+        else:
+            idxs, arg_cols = derivative_expr_data(method, supps)
+            aliases = [f"d_arg{i + 1}" for i in range(len(arg_cols))]
+            pref_itr = srt_itr.take(idxs)
+            for a, col in zip(aliases, arg_cols):
+                pref_itr = pref_itr.with_float(a, col)
         sp = _shard(m)
         if sp is not None and sp.group_index == pref_group:
             # the window carries the stencil halo, so every local row of a backward difference
@@ -505,9 +560,34 @@ def _add_derivative_approximations(core: ExaCore, data: ExaMappingData, m: Infin
 
 # 10 --------------------------------------------------------------------------------
 def _add_collocation_restrictions(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
-    # transform.jl:565-601 only acts on parameters with generative (collocation) supports,
-    # which this layer does not create yet.
-    return
+    """Piecewise-constant variables over collocation elements (transform.jl:565-601):
+    ``v[i1] − v[i2] == 0`` with ``i1`` the element's upper boundary, ``i2`` each internal node."""
+    for pref, vrefs in m.piecewise_vars.items():
+        g = pref.group
+        if g.internal is None or not g.internal.any():
+            continue                                                           # :573-575
+        pref_group = g.index
+        pref_alias = data.group_alias[pref_group - 1]
+        num_nodes = int(g.derivative_method[1]) - 2                              # internal nodes per element (:578)
+        num_supps = g.num_supports
+        ubs = np.repeat(np.arange(2 + num_nodes, num_supps + 1, num_nodes + 1), num_nodes)   # :580
+        ub_set = set(ubs.tolist())
+        pts = np.array([i for i in range(2, num_supps) if i not in ub_set])                 # :581
+        assert len(ubs) == len(pts)
+        recs = Items.from_records([dict(i1=int(a), i2=int(b)) for a, b in zip(ubs, pts)])   # :582
+        recs.grid = ((3000 + pref_group,), (0,))   # virtual grid: the restrictions of all variables fuse
+        for k, vref in enumerate(vrefs):
+            group_idxs = vref.group_idxs
+            itrs = [recs if gi == pref_group else data.base_itrs[gi - 1] for gi in group_idxs]
+            itr = _product_itr(itrs) if len(itrs) > 1 else itrs[0]
+            data_src = N.DataSource()
+            ivar = data.infvar_mappings[vref]
+            idx1 = tuple(data_src["i1"] if data.group_alias[gi - 1] == pref_alias else data_src[data.group_alias[gi - 1]]
+                         for gi in group_idxs)
+            idx2 = tuple(data_src["i2"] if data.group_alias[gi - 1] == pref_alias else data_src[data.group_alias[gi - 1]]
+                         for gi in group_idxs)
+            core.add_con(ivar[idx1] - ivar[idx2], itr)                                       # :593-597
+            core.templates[-1].tag = ("colloc", id_index(list(m.piecewise_vars), pref), k)
 
 
 # 11 --------------------------------------------------------------------------------

@@ -12,15 +12,18 @@ from . import infinite as io
 from .infinite import InfiniteModel
 
 
-def quadrotor(num_supports: int = 100, backend=None, supports=None) -> InfiniteModel:
+def quadrotor(num_supports: int = 100, backend=None, supports=None, collocation: int = 0) -> InfiniteModel:
     """``/root/reference/examples/quadrotor.jl:6-77`` — 9 states, 4 controls, T = 60,
-    backward finite differences (InfiniteOpt default)."""
+    backward finite differences (InfiniteOpt default).  ``collocation = 3`` gives the
+    ``ESCAPE34/quadrotor.jl:13-14,73`` variant: ``OrthogonalCollocation(3)`` and controls held
+    constant over each element (``constant_over_collocation.(u, t)``)."""
     n, p, T = 9, 4, 60.0
     im = InfiniteModel(backend)
+    method = io.OrthogonalCollocation(collocation) if collocation else None
     if supports is not None:   # explicit support window (shard.py)
-        t = im.infinite_parameter("t", 0.0, T, supports=supports)
+        t = im.infinite_parameter("t", 0.0, T, supports=supports, derivative_method=method)
     else:
-        t = im.infinite_parameter("t", 0.0, T, num_supports=num_supports)       # :19
+        t = im.infinite_parameter("t", 0.0, T, num_supports=num_supports, derivative_method=method)   # :19
     d1 = im.parameter_function("d1", lambda t: np.sin(2 * np.pi * t / T), t)        # :21
     d3 = im.parameter_function("d3", lambda t: 2 * np.sin(4 * np.pi * t / T), t)    # :22
     d5 = im.parameter_function("d5", lambda t: 2 * (t / T), t)                      # :23
@@ -44,6 +47,9 @@ def quadrotor(num_supports: int = 100, backend=None, supports=None) -> InfiniteM
     im.constraint(d(X[7]) == U[2] * cos(X[7]) / cos(X[8]) + U[3] * sin(X[7]) / cos(X[8]))
     im.constraint(d(X[8]) == -U[2] * sin(X[7]) + U[3] * cos(X[7]))
     im.constraint(d(X[9]) == U[2] * cos(X[7]) * tan(X[8]) + U[3] * sin(X[7]) * tan(X[8]) + U[4])  # :74-77
+    if collocation:
+        for uk in u:                                                                # ESCAPE34/quadrotor.jl:73
+            im.constant_over_collocation(uk, t)
     return im
 
 

@@ -106,6 +106,8 @@ def small_cases():
         "quadrotor_5": lambda: workloads.quadrotor(5),
         "quadrotor_100": lambda: workloads.quadrotor(100),
         "quadrotor_1000": lambda: workloads.quadrotor(1000),
+        "quadrotor_oc3_40": lambda: workloads.quadrotor(40, collocation=3),
+        "quadrotor_oc3_700": lambda: workloads.quadrotor(700, collocation=3),
         "pandemic_20x3": lambda: workloads.pandemic(20, 3),
         "pandemic_300x7": lambda: workloads.pandemic(300, 7),
         "farmer_5": lambda: workloads.farmer(5),

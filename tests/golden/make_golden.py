@@ -22,7 +22,7 @@ import numpy as np
 import cases
 from pyoracle import OracleModel
 
-CASES = ["quadrotor_5", "quadrotor_100", "pandemic_20x3", "farmer_5", "opf_7", "ode_5x5", "test_problem_1",
+CASES = ["quadrotor_5", "quadrotor_oc3_40", "quadrotor_100", "pandemic_20x3", "farmer_5", "opf_7", "ode_5x5", "test_problem_1",
          "rosenbrock", "pfun", "operator_zoo", "irregular"]
 
 

@@ -96,13 +96,28 @@ def test_long_second_grid_dimension_is_folded(built):
     """A 2-D support grid whose second extent exceeds gridDim.y (65535) is folded over blockIdx.z;
     the overshoot blocks must neither load nor store."""
     from infiniteexamodels.jl_amd import transcribe, workloads
-    core = transcribe.exa_core(workloads.pandemic(2, 70000))     # 12 x 70000 supports
+    core = transcribe.exa_core(workloads.pandemic(54, 66000))     # 64 x 66000 supports
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
+    em = EmulatedModel(core, blob)
+    assert any(k["grid"][2] > 1 for k in em.kernels)
+    assert _rel(em.cons(x), om.cons(x)) <= 1e-14
+    assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
+
+
+def test_short_first_dimension_uses_flat_lanes(built):
+    """A box whose first dimension cannot fill a wave (12 x 70000 supports; the 2 x (S-1) box
+    of an OrthogonalCollocation(3) derivative) is walked by one linear lane index."""
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    core = transcribe.exa_core(workloads.pandemic(2, 70000))
     blob = core.to_blob()
     om = OracleModel(blob)
     x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
     y = np.random.default_rng(1).standard_normal(om.ncon)
     em = EmulatedModel(core, blob)
-    assert any(k["grid"][2] > 1 for k in em.kernels)
+    big = [k for k in em.kernels if k["name"].startswith("iem_jac")]
+    assert all(k["grid"][1] == 1 and k["grid"][2] == 1 for k in big)
     assert _rel(em.cons(x), om.cons(x)) <= 1e-14
     assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
     assert _rel(em.hess_coord(x, y, 1.0, om.nnzh), om.hess_coord(x, y, 1.0)) <= 1e-14

@@ -304,13 +304,15 @@ def test_merged_hessian_layout_gpu(name, torch_cuda):
     gm.close()
 
 
-def test_folded_second_dimension_gpu(torch_cuda):
-    """12 x 70000 supports: the second grid dimension is folded over blockIdx.z."""
+@pytest.mark.parametrize("nt,nxi", [(54, 66000), (2, 70000)])
+def test_folded_or_flat_grids_gpu(nt, nxi, torch_cuda):
+    """64 x 66000 supports: the second grid dimension is folded over blockIdx.z;
+    12 x 70000: the short first dimension switches the kernel to flat lane indexing."""
     torch = torch_cuda
     from infiniteexamodels.jl_amd import transcribe, workloads
     from infiniteexamodels.jl_amd.model import ExaModel
     from pyoracle import OracleModel
-    core = transcribe.exa_core(workloads.pandemic(2, 70000))
+    core = transcribe.exa_core(workloads.pandemic(nt, nxi))
     blob = core.to_blob()
     om = OracleModel(blob)
     om.set_threads(min(16, om.max_threads()))

@@ -8,7 +8,7 @@ import cases
 from helpers import TorchModel, coo_to_dense, lower_to_full
 from pyoracle import OracleModel
 
-SMALL = ["quadrotor_5", "pandemic_20x3", "farmer_5", "ode_5x5", "test_problem_1", "rosenbrock", "pfun",
+SMALL = ["quadrotor_5", "quadrotor_oc3_40", "pandemic_20x3", "farmer_5", "ode_5x5", "test_problem_1", "rosenbrock", "pfun",
          "irregular"]
 
 

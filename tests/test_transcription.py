@@ -200,3 +200,34 @@ def test_build_order_matches_build_exa_core():
     ode = core.templates[4]
     cols = ode.items.column("group_idx1"), ode.items.column("group_idx2")
     assert list(cols[0][:4]) == [1, 2, 3, 4] and list(cols[1][:4]) == [1, 1, 1, 1]
+
+
+def test_orthogonal_collocation_structure_and_exactness(built):
+    """ESCAPE34/quadrotor.jl:13-14,73 — OrthogonalCollocation(3) + constant_over_collocation.
+    Structure follows the reference's own code (transform.jl:565-601: pairs (3,2),(5,4),…) and
+    SURVEY Appendix B (2S−1 supports, 2(S−1) rows per derivative); the collocation equations
+    themselves are an [EXT] restatement, so they are checked for what any order-n collocation
+    must satisfy: exactness on polynomials of degree ≤ n − 1."""
+    from infiniteexamodels.jl_amd import workloads
+    from infiniteexamodels.jl_amd.infinite import OrthogonalCollocation
+    from pyoracle import OracleModel
+    S = 9
+    core = transcribe.exa_core(workloads.quadrotor(S, collocation=3))
+    assert core.nvar == 22 * (2 * S - 1)
+    deriv = [t for t in core.templates if t.tag[0] == "deriv"]
+    colloc = [t for t in core.templates if t.tag[0] == "colloc"]
+    assert len(deriv) == 9 and all(len(t.items) == 2 * (S - 1) for t in deriv)
+    assert len(colloc) == 4 and all(len(t.items) == S - 1 for t in colloc)
+    assert [(r["i1"], r["i2"]) for r in colloc[0].items.records()[:3]] == [(3, 2), (5, 4), (7, 6)]
+    for nodes, poly, dpoly in ((3, lambda t: 0.7 - 1.3 * t + 2.1 * t ** 2, lambda t: -1.3 + 4.2 * t),
+                               (4, lambda t: 0.7 - 1.3 * t + 2.1 * t ** 2 - 0.4 * t ** 3,
+                                lambda t: -1.3 + 4.2 * t - 1.2 * t ** 2)):
+        m = InfiniteModel()
+        tt = m.infinite_parameter("t", 0, 2, supports=[0, 0.3, 1.1, 2.0], derivative_method=OrthogonalCollocation(nodes))
+        y = m.variable("y", tt)
+        m.constraint(m.deriv(y, tt) == 0 * y)
+        om = OracleModel(transcribe.exa_core(m).to_blob())
+        ts = m.groups[0].supports[:, 0]
+        assert len(ts) == 3 * (nodes - 1) + 1
+        x = np.concatenate([poly(ts), dpoly(ts)])
+        assert np.abs(om.cons(x)[len(ts):]).max() < 1e-13

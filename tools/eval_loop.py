@@ -42,6 +42,9 @@ def main():
     elif args.workload == "farmer":
         im = workloads.farmer(args.supports)
         desc = f"two-stage farmer, {args.supports} scenarios"
+    elif args.workload == "quadrotor_oc3":
+        im = workloads.quadrotor(args.supports, collocation=3)
+        desc = f"quadrotor ESCAPE34 variant (OrthogonalCollocation(3), piecewise-constant controls), {args.supports} public supports"
     else:
         im = workloads.quadrotor(args.supports)
         desc = f"quadrotor, {args.supports} supports"
@@ -50,7 +53,7 @@ def main():
     t_build = time.perf_counter() - t0
     rng = np.random.default_rng(0)
     x0 = gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)
-    x = torch.tensor(x0 if args.workload in ("opf", "quadrotor") else np.abs(x0) + 0.05, device="cuda")
+    x = torch.tensor(x0 if args.workload in ("opf", "quadrotor", "quadrotor_oc3") else np.abs(x0) + 0.05, device="cuda")
     y = torch.tensor(np.random.default_rng(1).standard_normal(gm.meta.ncon), device="cuda")
     g = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
     c = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
