@@ -184,6 +184,16 @@ def main():
     else:
         supports_total = float(S_local)
 
+    # distribution of single pairs (median, p10/p90), HIP events on the
+    # launch stream, outside the timed region
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(min(args.steps, 200) + 1)]
+    ev[0].record()
+    for e in ev[1:]:
+        step()
+        e.record()
+    torch.cuda.synchronize()
+    pair_ms = np.array([a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])])
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = supports_total / 1e6 * args.steps / dt
@@ -223,7 +233,9 @@ def main():
                          "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
                          "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline:
+        line["pair_ms"] = {"median": float(np.median(pair_ms)), "p10": float(np.percentile(pair_ms, 10)),
+                           "p90": float(np.percentile(pair_ms, 90)), "n": int(pair_ms.size)}
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -41,7 +41,7 @@ enum {
 };
 
 /* mirrors NLPModels' `meta` fields the reference reads
- * (infiniteopt_backend.jl:600-601 get_x0/get_y0; ext/*.jl solver construction) */
+ * (infiniteopt_backend.jl:600-601 get_x0/get_y0; ext/InfiniteExaModels{Ipopt,MadNLP}.jl solver construction) */
 typedef struct iem_meta_t {
   int64_t nvar, ncon, npar;
   int64_t nnzj, nnzh;

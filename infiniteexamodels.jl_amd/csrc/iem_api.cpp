@@ -46,6 +46,16 @@ int fail(int code, const std::string &msg) {
       return fail(IEM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
   } while (0)
 
+// Entry points run on the handle's device whatever the calling thread's current device is.
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(int d) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != d) switched = hipSetDevice(d) == hipSuccess;
+  }
+  ~DevGuard() { if (switched) hipSetDevice(prev); }
+};
+
 std::string contract_flag() { return g_opt.fp_contract ? "-ffp-contract=fast" : "-ffp-contract=off"; }
 
 // first line carries the compile flags so that an offline build (lib.precompile) and the
@@ -109,6 +119,7 @@ struct iem_model {
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *h_obj = nullptr;  // pinned
   std::map<int, void *> d_arrays;  // model array id -> device copy
+  std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
   std::vector<void *> d_tables;    // per kernel: device copy of {ip, dp, fa, ia} when they do not fit the argument block
   std::vector<double> theta_host;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -204,12 +215,13 @@ int compile_or_load(iem_model *m) {
   return IEM_OK;
 }
 
-int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
+// Builds the static part of kernel k's argument block once (iem_create); launch() only rewrites
+// the head {x, theta, y, v, out, w}.
+void build_argbuf(iem_model *m, size_t k) {
   const iem::KernelDesc &kd = m->prog.kernels[k];
-  std::vector<uint64_t> buf;
+  std::vector<uint64_t> &buf = m->argbuf[k];
+  buf.assign(6, 0);
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
-  push_ptr(x); push_ptr(m->d_theta); push_ptr(y); push_ptr(v); push_ptr(out);
-  uint64_t wb; std::memcpy(&wb, &w, 8); buf.push_back(wb);
   if (kd.tables_in_memory) {
     const uint64_t *tb = (const uint64_t *)m->d_tables[k];
     size_t nip = std::max<size_t>(1, kd.ip.size()), ndp = std::max<size_t>(1, kd.dp.size()), nfa = std::max<size_t>(1, kd.fa.size());
@@ -224,6 +236,14 @@ int launch(iem_model *m, size_t k, const double *x, const double *y, double *out
     for (int id : kd.ia) push_ptr(m->d_arrays[id]);
     if (kd.ia.empty()) buf.push_back(0);
   }
+}
+
+int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
+  const iem::KernelDesc &kd = m->prog.kernels[k];
+  std::vector<uint64_t> &buf = m->argbuf[k];
+  buf[0] = (uint64_t)(uintptr_t)x; buf[1] = (uint64_t)(uintptr_t)m->d_theta; buf[2] = (uint64_t)(uintptr_t)y;
+  buf[3] = (uint64_t)(uintptr_t)v; buf[4] = (uint64_t)(uintptr_t)out;
+  std::memcpy(&buf[5], &w, 8);
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
@@ -308,10 +328,17 @@ int structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base, b
         slot[f.arr] = (int)ptrs.size();
         ptrs.push_back((const long long *)m->d_arrays[f.arr]);
       }
+  // scratch descriptors live until the structure kernels have drained; freed on every exit path
+  // (hipFree waits for the device)
+  struct Scratch {
+    std::vector<void *> v;
+    void push_back(void *p) { v.push_back(p); }
+    ~Scratch() { for (void *p : v) hipFree(p); }
+  } to_free;
   const long long **d_ptrs = nullptr;
   HIP_TRY(hipMalloc((void **)&d_ptrs, std::max<size_t>(ptrs.size(), 1) * 8));
+  to_free.push_back((void *)d_ptrs);
   if (!ptrs.empty()) HIP_TRY(hipMemcpy(d_ptrs, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice));
-  std::vector<void *> to_free{(void *)d_ptrs};
   int rc = IEM_OK;
   if (hess && !m->prog.hess_classes.empty()) {
     for (const iem::HessClass &hc : m->prog.hess_classes) {
@@ -362,7 +389,6 @@ int structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base, b
     if (e != hipSuccess) { rc = fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e)); break; }
   }
   hipError_t e = hipStreamSynchronize(m->stream);
-  for (void *p : to_free) hipFree(p);
   if (rc) return rc;
   if (e != hipSuccess) return fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e));
   return IEM_OK;
@@ -558,6 +584,8 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
     if (hipMalloc(&m->d_tables[k], tb.size() * 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc tables"));
     if (hipMemcpy(m->d_tables[k], tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(IEM_E_HIP, "upload tables"));
   }
+  m->argbuf.resize(m->prog.kernels.size());
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k) build_argbuf(m, k);
   for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) {
     // complement of the ranges the scatter kernels of this kind overwrite completely
     auto cov = m->prog.covered[kind];
@@ -577,6 +605,7 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
 
 int iem_destroy(iem_model *m) {
   if (!m) return IEM_OK;
+  DevGuard dg_(m->device);
   if (m->d_theta) hipFree(m->d_theta);
   if (m->d_partials) hipFree(m->d_partials);
   if (m->d_obj) hipFree(m->d_obj);
@@ -658,12 +687,14 @@ int iem_set_stream(iem_model *m, void *hip_stream) {
 
 int iem_synchronize(iem_model *m) {
   if (!m) return fail(IEM_E_ARG, "null handle");
+  DevGuard dg_(m->device);
   HIP_TRY(hipStreamSynchronize(m->stream));
   return IEM_OK;
 }
 
 int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_vals) {
   if (!m || !h_vals) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   if (off < 0 || len < 0 || off + len > m->model.npar) return fail(IEM_E_ARG, "parameter range out of bounds");
   std::memcpy(m->theta_host.data() + off, h_vals, (size_t)len * 8);
   HIP_TRY(hipMemcpyAsync(m->d_theta + off, m->theta_host.data() + off, (size_t)len * 8, hipMemcpyHostToDevice, m->stream));
@@ -673,6 +704,7 @@ int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_va
 
 int iem_obj_device(iem_model *m, const double *d_x, double *d_out) {
   if (!m || !d_x || !d_out) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   int rc = launch_kind(m, iem::KK_OBJ, d_x, nullptr, m->d_partials, 0.0);
   if (rc) return rc;
   long long n = m->prog.n_partials;
@@ -693,6 +725,7 @@ int iem_obj(iem_model *m, const double *d_x, double *h_out) {
 
 int iem_grad(iem_model *m, const double *d_x, double *d_g) {
   if (!m || !d_x || !d_g) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   for (auto &z : m->grad_zero)   // zero only what the kernels do not overwrite completely
     HIP_TRY(hipMemsetAsync(d_g + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
   return launch_kind(m, iem::KK_GRAD, d_x, nullptr, d_g, 0.0);
@@ -701,12 +734,14 @@ int iem_grad(iem_model *m, const double *d_x, double *d_g) {
 /* NLPModels.jprod!(m, x, v, Jv) */
 int iem_jprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jv) {
   if (!m || !d_x || !d_v || (!d_Jv && m->model.ncon)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   return launch_kind(m, iem::KK_JPROD, d_x, nullptr, d_Jv, 0.0, d_v);
 }
 
 /* NLPModels.jtprod!(m, x, v, Jtv) */
 int iem_jtprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jtv) {
   if (!m || !d_x || (!d_v && m->model.ncon) || !d_Jtv) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   for (auto &z : m->zero_ranges[iem::KK_JTPROD])
     HIP_TRY(hipMemsetAsync(d_Jtv + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
   return launch_kind(m, iem::KK_JTPROD, d_x, nullptr, d_Jtv, 0.0, d_v);
@@ -715,6 +750,7 @@ int iem_jtprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jtv
 /* NLPModels.hprod!(m, x, y, v, Hv; obj_weight) */
 int iem_hprod(iem_model *m, const double *d_x, const double *d_y, const double *d_v, double obj_weight, double *d_Hv) {
   if (!m || !d_x || (!d_y && m->model.ncon) || !d_v || !d_Hv) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   for (auto &z : m->zero_ranges[iem::KK_HPROD])
     HIP_TRY(hipMemsetAsync(d_Hv + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
   return launch_kind(m, iem::KK_HPROD, d_x, d_y, d_Hv, obj_weight, d_v);
@@ -722,27 +758,32 @@ int iem_hprod(iem_model *m, const double *d_x, const double *d_y, const double *
 
 int iem_cons(iem_model *m, const double *d_x, double *d_c) {
   if (!m || !d_x || (!d_c && m->model.ncon)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   return launch_kind(m, iem::KK_CONS, d_x, nullptr, d_c, 0.0);
 }
 
 int iem_jac_coord(iem_model *m, const double *d_x, double *d_vals) {
   if (!m || !d_x || (!d_vals && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   return launch_kind(m, iem::KK_JAC, d_x, nullptr, d_vals, 0.0);
 }
 
 int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_vals) {
   if (!m || !d_x || (!d_y && m->model.ncon) || (!d_vals && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   return launch_kind(m, iem::KK_HESS, d_x, d_y, d_vals, obj_weight);
 }
 
 int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
   if (!m || ((!h_rows || !h_cols) && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   jac_structure_host(m->model, h_rows, h_cols, base);
   return IEM_OK;
 }
 
 int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
   if (!m || ((!h_rows || !h_cols) && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   if (!m->prog.hess_classes.empty()) hess_structure_merged_host(m->model, m->prog.hess_classes, h_rows, h_cols, base);
   else hess_structure_host(m->model, h_rows, h_cols, base);
   return IEM_OK;
@@ -750,17 +791,20 @@ int iem_hess_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base)
 
 int iem_jac_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
   if (!m || ((!d_rows || !d_cols) && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   return structure_device(m, d_rows, d_cols, base, false);
 }
 
 int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base) {
   if (!m || ((!d_rows || !d_cols) && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
   return structure_device(m, d_rows, d_cols, base, true);
 }
 
 int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int64_t *d_perm, const double *d_coo,
                    double *d_csr) {
   if (!m || n_csr < 0 || (n_csr && (!d_seg || !d_perm || !d_coo || !d_csr))) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
   if (n_csr == 0) return IEM_OK;
   long long n = n_csr;
   void *args[] = {(void *)&d_seg, (void *)&d_perm, (void *)&d_coo, (void *)&d_csr, (void *)&n};
@@ -771,6 +815,7 @@ int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int6
 int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess, int iters,
                      double *h_ms_jac, double *h_ms_hess) {
   if (!m || iters <= 0) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
   // Average launch duration in steady state: the jac/hess pair is enqueued `iters` times back to
   // back (as a solver loop does) with an event pair around EVERY launch, all on the launch
   // stream, and nothing synchronises until the end — the same quantity rocprofv3

@@ -125,19 +125,203 @@ function set_parameter!(m::MI355XModel, param, vals)
 end
 
 # ---- blob writer ----------------------------------------------------------------------------
-# Walks the host ExaCore (`core.obj` / `core.con` linked lists of SIMDFunction-carrying terms)
-# and emits include/iem_blob.h.  Node mapping (ExaModels graph.jl types → opcodes):
-#   Var{I}            → IEM_OP_VAR  + index expression (I an Int or a ParIndexed/Node2 ± Int tree)
-#   ParameterNode{I}  → IEM_OP_PAR
-#   ParIndexed{_, n}  → IEM_OP_DATA on item field n (float)  /  index field (int)
+# Serialises a host ExaCore into the wire format of include/iem_blob.h.  [EXT]: the field and
+# type names of ExaModels' internal structs (Objective/Constraint linked lists, SIMDFunction,
+# Node1/Node2/Var/ParameterNode, the data-source leaf types) are matched by NAME through
+# `nameof(typeof(·))`, so that a rename between ExaModels versions (ParSource/ParIndexed in
+# 0.9-0.10, DataSource/DataIndexed in 0.11) needs a one-line change in the sets below.
+#
+# Node mapping (ExaModels graph types → opcodes of iem_blob.h):
+#   Var{I}            → IEM_OP_VAR  + affine index expression over Int item fields
+#   ParameterNode{I}  → IEM_OP_PAR  + affine index expression
+#   data-indexed leaf → IEM_OP_DATA on a Float64 item column
 #   Real              → IEM_OP_CONST
-#   Node1{F}          → unary opcode of F,  Node2{F} → binary opcode of F (Real operands → CONST)
-# Item iterators (Vector{NamedTuple}) are written as explicit columns (mode GATHER); columns
-# that are arithmetic progressions are written as AFFINE fields so that the generator can fuse
-# templates over a support grid (grid_id = hash of the group aliases, origin = first index - 1).
+#   Node1{F}          → unary opcode of F;  Node2{F} → binary opcode of F
+# Items (`itr`, any iterable of NamedTuples / tuples / scalars) become explicit columns; a column
+# that is an arithmetic progression is written as an AFFINE field (no payload), anything else as
+# a GATHER field.  Templates whose first Int column is the progression b+1, b+2, … are placed on
+# fusion grid 1 with origin b (a scheduling hint only: results never depend on it).
+
+const _SRC_NAMES = (:ParSource, :DataSource)
+const _IDX_NAMES = (:ParIndexed, :DataIndexed)
+const _BINOP = Dict{Any,Int}(+ => 10, - => 11, * => 12, / => 13, ^ => 14)
+const _UNOP = Dict{Any,Int}(
+    - => 20, + => 21, inv => 22, sqrt => 23, cbrt => 24, abs => 25, abs2 => 26, exp => 27, exp2 => 28,
+    log => 29, log2 => 30, log10 => 31, log1p => 32, sin => 33, cos => 34, tan => 35, asin => 36,
+    acos => 37, csc => 38, sec => 39, cot => 40, atan => 41, acot => 42, sind => 43, cosd => 44,
+    tand => 45, cscd => 46, secd => 47, cotd => 48, atand => 49, acotd => 50, sinh => 51, cosh => 52,
+    tanh => 53, csch => 54, sech => 55, coth => 56, atanh => 57, acoth => 58)
+
+_tname(e) = nameof(typeof(e))
+_fn_of(e) = typeof(e).parameters[1].instance            # Node1{F,…} / Node2{F,…}: F = typeof(f)
+_w(x::Integer) = reinterpret(UInt64, Int64(x))
+_w(x::AbstractFloat) = reinterpret(UInt64, Float64(x))
+
+# key of a data leaf: the chain of getindex/getproperty selectors from the source, e.g. (:t,) or (2, 1)
+function _leaf_key(e)
+    _tname(e) in _SRC_NAMES && return ()
+    _tname(e) in _IDX_NAMES || error("to_blob: not a data leaf: $(typeof(e))")
+    return (_leaf_key(getfield(e, :inner))..., typeof(e).parameters[2])
+end
+_select(item, key::Tuple) = isempty(key) ? item : _select(_pick(item, key[1]), Base.tail(key))
+_pick(item, k::Symbol) = getproperty(item, k)
+_pick(item, k) = getindex(item, k)
+
+mutable struct _Arrays
+    recs::Vector{NTuple{5,Any}}        # (kind, n, payload | nothing, a, b)
+    seen::Dict{Any,Int}
+end
+function _add_array!(A::_Arrays, v::AbstractVector)
+    v = v isa AbstractVector{<:Integer} ? collect(Int64, v) : collect(Float64, v)
+    if eltype(v) == Float64 && !isempty(v) && all(==(v[1]), v) && !isnan(v[1])
+        key = (:fill, length(v), v[1])
+        return get!(A.seen, key) do
+            push!(A.recs, (2, length(v), nothing, _w(v[1]), UInt64(0))); length(A.recs) - 1
+        end
+    end
+    key = (eltype(v), hash(v), length(v))
+    return get!(A.seen, key) do
+        push!(A.recs, (eltype(v) == Float64 ? 0 : 1, length(v), v, UInt64(0), UInt64(0))); length(A.recs) - 1
+    end
+end
+
+mutable struct _Tpl
+    items::Vector{Any}
+    A::_Arrays
+    icol::Dict{Any,Int}; fcol::Dict{Any,Int}
+    ifields::Vector{Vector{UInt64}}; ffields::Vector{Vector{UInt64}}
+    idx::Vector{Vector{UInt64}}
+    nodes::Vector{NTuple{4,UInt64}}
+    first_ap::Union{Nothing,Int64}      # base of the first unit-step Int column (fusion hint)
+end
+
+function _column_field(T::_Tpl, col::Vector, asint::Bool)
+    n = length(col)
+    if asint
+        c = collect(Int64, col)
+        step = n > 1 ? c[2] - c[1] : 0
+        if all(k -> c[k] == c[1] + step * (k - 1), 1:n)
+            step == 1 && T.first_ap === nothing && (T.first_ap = c[1] - 1)
+            return UInt64[_w(0), _w(c[1]), _w(step), _w(0), _w(0), _w(-1)]         # AFFINE
+        end
+        return UInt64[_w(1), _w(0), _w(1), _w(0), _w(0), _w(_add_array!(T.A, c))]    # GATHER, k-th entry
+    end
+    return UInt64[_w(1), _w(0), _w(1), _w(0), _w(0), _w(_add_array!(T.A, collect(Float64, col)))]
+end
+function _ifield!(T::_Tpl, key)
+    get!(T.icol, key) do
+        push!(T.ifields, _column_field(T, [_select(it, key) for it in T.items], true)); length(T.ifields) - 1
+    end
+end
+function _ffield!(T::_Tpl, key)
+    get!(T.fcol, key) do
+        push!(T.ffields, _column_field(T, [_select(it, key) for it in T.items], false)); length(T.ffields) - 1
+    end
+end
+
+# affine index algebra: value = c0 + Σ coef·field
+function _affine(T::_Tpl, e)
+    e isa Integer && return (Int64(e), Dict{Int,Int64}())
+    n = _tname(e)
+    (n in _IDX_NAMES || n in _SRC_NAMES) && return (Int64(0), Dict(_ifield!(T, _leaf_key(e)) => Int64(1)))
+    if n == :Node2
+        f = _fn_of(e); a = getfield(e, :inner1); b = getfield(e, :inner2)
+        if f === (+) || f === (-)
+            (ca, ta), (cb, tb) = _affine(T, a), _affine(T, b); s = f === (+) ? 1 : -1
+            for (k, v) in tb; ta[k] = get(ta, k, 0) + s * v; end
+            return (ca + s * cb, ta)
+        elseif f === (*) && (a isa Integer || b isa Integer)
+            k, (c, t) = a isa Integer ? (a, _affine(T, b)) : (b, _affine(T, a))
+            return (k * c, Dict(i => k * v for (i, v) in t))
+        end
+    elseif n == :Node1 && _fn_of(e) === (-)
+        c, t = _affine(T, getfield(e, :inner)); return (-c, Dict(i => -v for (i, v) in t))
+    end
+    error("to_blob: index expression is not affine in the item fields: $(typeof(e))")
+end
+function _idx!(T::_Tpl, e)
+    c0, terms = _affine(T, e)
+    filter!(p -> p.second != 0, terms)
+    length(terms) <= 3 || error("to_blob: more than IEM_MAX_IDX_TERMS item fields in one index")
+    w = UInt64[_w(c0), _w(length(terms))]
+    for (fid, coef) in sort!(collect(terms)); push!(w, _w(fid), _w(coef)); end
+    append!(w, fill(UInt64(0), 2 * (3 - length(terms))))
+    push!(T.idx, w); return length(T.idx) - 1
+end
+
+_node!(T, op, a = 0, b = 0, imm = 0.0) = (push!(T.nodes, (_w(op), _w(a), _w(b), _w(Float64(imm)))); length(T.nodes) - 1)
+function _walk!(T::_Tpl, e)
+    e isa Real && return _node!(T, 0, 0, 0, e)
+    n = _tname(e)
+    n == :Null && return _node!(T, 0, 0, 0, something(getfield(e, :value), 0.0))
+    n == :Var && return _node!(T, 3, _idx!(T, getfield(e, :i)))
+    n == :ParameterNode && return _node!(T, 2, _idx!(T, getfield(e, :i)))
+    (n in _IDX_NAMES || n in _SRC_NAMES) && return _node!(T, 1, _ffield!(T, _leaf_key(e)))
+    if n == :Node1
+        a = _walk!(T, getfield(e, :inner))
+        return _node!(T, get(() -> error("to_blob: unary operator $(_fn_of(e)) has no opcode"), _UNOP, _fn_of(e)), a)
+    elseif n == :Node2
+        a = _walk!(T, getfield(e, :inner1)); b = _walk!(T, getfield(e, :inner2))
+        return _node!(T, get(() -> error("to_blob: binary operator $(_fn_of(e)) has no opcode"), _BINOP, _fn_of(e)), a, b)
+    end
+    error("to_blob: unsupported expression node $(typeof(e))")
+end
+
+# linked list (newest first, `.inner` = previous) → call order
+function _chain(head)
+    out = Any[]
+    while hasfield(typeof(head), :f) && hasfield(typeof(head), :itr)
+        pushfirst!(out, head); head = getfield(head, :inner)
+    end
+    return out
+end
+
 function to_blob(core)::Vector{UInt8}
-    error("to_blob: serialise `core` following include/iem_blob.h — see infiniteexamodels.jl_amd/core.py " *
-          "(ExaCore.to_blob) for the reference implementation of the writer")
+    A = _Arrays(NTuple{5,Any}[], Dict{Any,Int}())
+    core_ids = [_add_array!(A, Array(core.x0)), _add_array!(A, Array(core.lvar)),
+                _add_array!(A, Array(core.uvar)), _add_array!(A, Array(core.θ))]
+    lcon, ucon = Array(core.lcon), Array(core.ucon)
+    objs, cons = _chain(core.obj), _chain(core.con)
+    # add_obj/add_con CALL order decides the Hessian block offsets: merge the two lists by o2
+    order = Tuple{Int,Any}[]
+    i = j = 1
+    while i <= length(objs) || j <= length(cons)
+        takeobj = j > length(cons) || (i <= length(objs) && objs[i].f.o2 <= cons[j].f.o2)
+        takeobj ? (push!(order, (0, objs[i])); i += 1) : (push!(order, (1, cons[j])); j += 1)
+    end
+    tpls = Vector{Vector{UInt64}}()
+    for (kind, t) in order
+        items = collect(Any, t.itr)
+        T = _Tpl(items, A, Dict{Any,Int}(), Dict{Any,Int}(), [], [], [], NTuple{4,UInt64}[], nothing)
+        root = _walk!(T, t.f.f)
+        n = length(items)
+        gid, origin = T.first_ap === nothing ? (n == 1 ? (0, 0) : (-1, 0)) : (4096 + 1, T.first_ap)
+        w = UInt64[_w(kind), _w(n), _w(1), _w(n), _w(1), _w(1), _w(gid), _w(origin), _w(0), _w(0),
+                   _w(length(T.ifields)), _w(length(T.ffields)), _w(length(T.idx)), _w(length(T.nodes)), _w(root)]
+        if kind == 1
+            rows = (t.f.o0 + 1):(t.f.o0 + n)
+            append!(w, [_w(1), _w(0), _w(_add_array!(A, lcon[rows])), _w(1), _w(0), _w(_add_array!(A, ucon[rows]))])
+        else
+            append!(w, [_w(0), _w(0.0), _w(-1), _w(0), _w(0.0), _w(-1)])
+        end
+        foreach(f -> append!(w, f), T.ifields); foreach(f -> append!(w, f), T.ffields)
+        foreach(x -> append!(w, x), T.idx)
+        for nd in T.nodes; append!(w, nd); end
+        push!(tpls, w)
+    end
+    narr, ntpl = length(A.recs), length(tpls)
+    pos = 14 + 6 * narr + ntpl
+    tpl_off = Int[]; for w in tpls; push!(tpl_off, pos); pos += length(w); end
+    arr_off = Int[]; for r in A.recs; push!(arr_off, r[3] === nothing ? 0 : pos); r[3] === nothing || (pos += r[2]); end
+    head = UInt64[_w(0x31424f4c424d4549), _w(1), _w(core.nvar), _w(core.npar), _w(core.ncon), _w(ntpl), _w(narr),
+                  _w(core.minimize ? 1 : 0), _w(pos), _w(0), _w.(core_ids)...]
+    for (r, off) in zip(A.recs, arr_off); append!(head, [_w(r[1]), _w(r[2]), _w(off), r[4], r[5], _w(0)]); end
+    append!(head, _w.(tpl_off)); foreach(w -> append!(head, w), tpls)
+    for r in A.recs
+        r[3] === nothing || append!(head, reinterpret(UInt64, r[3]))
+    end
+    @assert length(head) == pos
+    return collect(reinterpret(UInt8, head))
 end
 
 end # module

@@ -42,7 +42,13 @@ def _ptr(t) -> int:
 class ExaModel:
     """Device-resident NLP model built from an :class:`ExaCore`."""
 
-    def __init__(self, core: ExaCore, device: Optional[int] = None, blob: Optional[bytes] = None,
+    @classmethod
+    def from_blob(cls, blob: bytes, device: int = 0, hess_layout: str = "exa") -> "ExaModel":
+        """Model from a blob written by any producer of include/iem_blob.h (e.g. the Julia
+        writer in julia/MI355XBackend.jl) — no host-side core."""
+        return cls(None, device=device, blob=blob, hess_layout=hess_layout)
+
+    def __init__(self, core: Optional[ExaCore], device: Optional[int] = None, blob: Optional[bytes] = None,
                  hess_layout: str = "exa"):
         """``hess_layout``: ``"exa"`` = ExaModels' COO layout (default, what parity is stated on);
         ``"merged"`` = opt-in layout in which duplicate ``(row, col)`` slots of one support are
@@ -50,7 +56,7 @@ class ExaModel:
         import torch
 
         if device is None:
-            device = core.backend.device if isinstance(core.backend, MI355XBackend) else 0
+            device = core.backend.device if core is not None and isinstance(core.backend, MI355XBackend) else 0
         if not torch.cuda.is_available():
             raise _lib.IemError("no GPU visible: the evaluation path has no CPU fallback")
         self._torch = torch
@@ -68,7 +74,8 @@ class ExaModel:
         finally:
             _lib.set_option("hess_merge", 0)
         self._h = h
-        core._model = self
+        if core is not None:
+            core._model = self
         m = _lib.Meta()
         _lib.check(self._L.iem_meta(self._h, C.byref(m)))
         host = lambda which, n: self._host(which, n)
