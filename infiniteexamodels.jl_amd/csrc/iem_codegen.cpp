@@ -1303,48 +1303,60 @@ std::vector<Group> make_groups(const Model &m, bool no_fuse) {
 }
 
 // min / max of an index expression over the template's item box — host-side safety check
+// (128-bit arithmetic: blobs come from foreign producers and may hold anything)
 void validate_indices(const Model &m) {
+  typedef __int128 wide;
   for (size_t ti = 0; ti < m.tpl.size(); ++ti) {
     const Template &t = m.tpl[ti];
-    std::vector<std::pair<int64_t, int64_t>> frange(t.ifields.size());
+    if (t.n_items == 0) continue;
+    std::vector<std::pair<wide, wide>> frange(t.ifields.size());
     for (size_t f = 0; f < t.ifields.size(); ++f) {
       const FieldDesc &fd = t.ifields[f];
       if (fd.mode == IEM_F_AFFINE) {
-        int64_t lo = fd.base, hi = fd.base;
+        wide lo = fd.base, hi = fd.base;
         for (int d = 0; d < 3; ++d) {
-          int64_t e = fd.step[d] * (t.dims[d] - 1);
+          wide e = (wide)fd.step[d] * (t.dims[d] - 1);
           if (e < 0) lo += e; else hi += e;
         }
         frange[f] = {lo, hi};
       } else {
         const ArrayDesc &a = m.arrs[fd.arr];
         int64_t lo = INT64_MAX, hi = INT64_MIN;
-        for (int64_t j = 0; j < a.n; ++j) { int64_t v = a.i(j); lo = std::min(lo, v); hi = std::max(hi, v); }
+        if (a.kind == IEM_A_I64_RANGE) {
+          if (a.n > 0) {
+            wide last = (wide)a.r0 + (wide)a.rstep * (a.n - 1);
+            if (last > INT64_MAX || last < INT64_MIN) throw std::runtime_error("template " + std::to_string(ti) + ": range array overflows");
+            lo = std::min(a.r0, (int64_t)last); hi = std::max(a.r0, (int64_t)last);
+          }
+        } else {
+          for (int64_t j = 0; j < a.n; ++j) { int64_t v = a.i(j); lo = std::min(lo, v); hi = std::max(hi, v); }
+        }
         frange[f] = {lo, hi};
       }
     }
-    std::vector<std::pair<int64_t, int64_t>> irange(t.idx.size());
+    std::vector<std::pair<wide, wide>> irange(t.idx.size());
     for (size_t i = 0; i < t.idx.size(); ++i) {
       const IdxExpr &ix = t.idx[i];
-      int64_t lo = ix.c0, hi = ix.c0;
+      wide lo = ix.c0, hi = ix.c0;
       // affine terms over the same box are correlated; evaluate the box corners exactly when all affine
       bool all_aff = true;
       for (int j = 0; j < ix.nterms; ++j) if (t.ifields[ix.field[j]].mode != IEM_F_AFFINE) all_aff = false;
       if (all_aff) {
-        int64_t c = ix.c0, k[3] = {0, 0, 0};
+        wide c = ix.c0, k[3] = {0, 0, 0};
         for (int j = 0; j < ix.nterms; ++j) {
           const FieldDesc &fd = t.ifields[ix.field[j]];
-          c += ix.coef[j] * fd.base;
-          for (int d = 0; d < 3; ++d) k[d] += ix.coef[j] * fd.step[d];
+          c += (wide)ix.coef[j] * fd.base;
+          for (int d = 0; d < 3; ++d) k[d] += (wide)ix.coef[j] * fd.step[d];
         }
         lo = hi = c;
         for (int d = 0; d < 3; ++d) {
-          int64_t e = k[d] * (t.dims[d] - 1);
+          if (k[d] > ((wide)1 << 62) || k[d] < -((wide)1 << 62)) throw std::runtime_error("template " + std::to_string(ti) + ": index stride overflows");
+          wide e = k[d] * (t.dims[d] - 1);
           if (e < 0) lo += e; else hi += e;
         }
       } else {
         for (int j = 0; j < ix.nterms; ++j) {
-          int64_t a = ix.coef[j] * frange[ix.field[j]].first, b = ix.coef[j] * frange[ix.field[j]].second;
+          wide a = (wide)ix.coef[j] * frange[ix.field[j]].first, b = (wide)ix.coef[j] * frange[ix.field[j]].second;
           lo += std::min(a, b); hi += std::max(a, b);
         }
       }
@@ -1355,7 +1367,7 @@ void validate_indices(const Model &m) {
       int64_t lim = nd.op == IEM_OP_VAR ? m.nvar : m.npar;
       if (irange[nd.a].first < 1 || irange[nd.a].second > lim)
         throw std::runtime_error("template " + std::to_string(ti) + ": " + (nd.op == IEM_OP_VAR ? "variable" : "parameter") +
-                                 " index range [" + std::to_string(irange[nd.a].first) + ", " + std::to_string(irange[nd.a].second) +
+                                 " index range [" + std::to_string((double)irange[nd.a].first) + ", " + std::to_string((double)irange[nd.a].second) +
                                  "] outside 1:" + std::to_string(lim));
     }
   }

@@ -147,6 +147,9 @@ struct SymWalk {
   }
 };
 
+// upper bound on any count in a blob (items, array lengths, nvar …): 2^40 elements = 8 TiB of doubles
+constexpr int64_t IEM_MAX_COUNT = (int64_t)1 << 40;
+
 inline void analyse_template(Template &t) {
   for (size_t n = 0; n < t.nodes.size(); ++n) {
     Node &nd = t.nodes[n];
@@ -201,6 +204,9 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
   const int64_t total = w[8];
   m.nvar = w[2]; m.npar = w[3]; m.ncon = w[4];
   int64_t n_tpl = w[5], n_arr = w[6];
+  if (m.nvar < 0 || m.npar < 0 || m.ncon < 0 || m.nvar > IEM_MAX_COUNT || m.npar > IEM_MAX_COUNT || m.ncon > IEM_MAX_COUNT)
+    throw std::runtime_error("nvar / npar / ncon out of range");
+  if (n_tpl < 0 || n_arr < 0 || n_tpl > total || n_arr > total) throw std::runtime_error("blob tables overrun");
   m.minimize = (int)w[7];
   m.arr_x0 = (int)w[10]; m.arr_lvar = (int)w[11]; m.arr_uvar = (int)w[12]; m.arr_theta = (int)w[13];
   if (IEM_HDR_WORDS + IEM_ARR_WORDS * n_arr + n_tpl > total) throw std::runtime_error("blob tables overrun");
@@ -209,8 +215,10 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
   for (int64_t i = 0; i < n_arr; ++i, aw += IEM_ARR_WORDS) {
     ArrayDesc &a = m.arrs[i];
     a.kind = (int)aw[0]; a.n = aw[1];
+    if (aw[0] < IEM_A_F64_DATA || aw[0] > IEM_A_I64_RANGE) throw std::runtime_error("unknown array kind");
+    if (a.n < 0 || a.n > IEM_MAX_COUNT) throw std::runtime_error("array length out of range");
     if (a.kind == IEM_A_F64_DATA || a.kind == IEM_A_I64_DATA) {
-      if (aw[2] < 0 || aw[2] + a.n > total) throw std::runtime_error("array payload out of range");
+      if (aw[2] < 0 || aw[2] > total || a.n > total - aw[2]) throw std::runtime_error("array payload out of range");
       a.data = w + aw[2];
     }
     a.fill = w2d(aw[3]); a.r0 = aw[3]; a.rstep = aw[4];
@@ -218,6 +226,7 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
   auto chk_arr = [&](int id, int64_t need, const char *what) {
     if (id < 0 || id >= (int)n_arr || m.arrs[id].n < need) throw std::runtime_error(std::string("bad array for ") + what);
   };
+  if (w[10] != m.arr_x0 || w[11] != m.arr_lvar || w[12] != m.arr_uvar || w[13] != m.arr_theta) throw std::runtime_error("bad core array id");
   chk_arr(m.arr_x0, m.nvar, "x0"); chk_arr(m.arr_lvar, m.nvar, "lvar");
   chk_arr(m.arr_uvar, m.nvar, "uvar"); chk_arr(m.arr_theta, m.npar, "theta");
   const int64_t *tw = w + IEM_HDR_WORDS + IEM_ARR_WORDS * n_arr;
@@ -235,28 +244,46 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
     t.root = (int)*p++;
     t.lmode = (int)*p++; t.lval = w2d(*p++); t.larr = (int)*p++;
     t.umode = (int)*p++; t.uval = w2d(*p++); t.uarr = (int)*p++;
-    if (t.nd < 1 || t.nd > 3 || t.n_items != t.dims[0] * t.dims[1] * t.dims[2] || t.n_items < 0)
+    bool box_ok = t.nd >= 1 && t.nd <= 3 && t.n_items >= 0 && t.n_items <= IEM_MAX_COUNT;
+    for (int d = 0; d < 3 && box_ok; ++d) box_ok = t.dims[d] >= 0 && t.dims[d] <= IEM_MAX_COUNT && (d < t.nd || t.dims[d] == 1);
+    if (!box_ok || (__int128)t.dims[0] * t.dims[1] * t.dims[2] != (__int128)t.n_items)
       throw std::runtime_error("bad template item box");
+    for (int d = 0; d < 3; ++d)
+      if (t.origin[d] < -IEM_MAX_COUNT || t.origin[d] > IEM_MAX_COUNT) throw std::runtime_error("bad template grid origin");
+    auto chk_bound = [&](int mode, int arr) {
+      if (mode != 0 && mode != 1) throw std::runtime_error("bad constraint bound mode");
+      if (mode == 1 && (arr < 0 || arr >= (int)n_arr || m.arrs[arr].n < t.n_items)) throw std::runtime_error("bad constraint bound array");
+    };
+    chk_bound(t.lmode, t.larr); chk_bound(t.umode, t.uarr);
     int64_t need = (int64_t)IEM_FIELD_WORDS * (n_if + n_ff) + (int64_t)IEM_IDX_WORDS * n_idx + (int64_t)IEM_NODE_WORDS * n_nodes;
     if (n_if < 0 || n_ff < 0 || n_idx < 0 || n_nodes <= 0 || (p - w) + need > total)
       throw std::runtime_error("template record overruns blob");
-    auto rd_field = [&](FieldDesc &f) {
-      f.mode = (int)*p++; f.base = *p++;
+    if (n_if >= 65536 || n_ff >= 65536 || n_idx >= 65536 || n_nodes >= 65536)
+      throw std::runtime_error("template too large (more than 65535 fields / index expressions / nodes)");
+    auto rd_field = [&](FieldDesc &f, bool is_int) {
+      const int64_t mode = *p++, arr = p[4];
+      f.mode = (int)mode; f.base = *p++;
       for (int d = 0; d < 3; ++d) f.step[d] = *p++;
       f.arr = (int)*p++;
-      if (f.mode == IEM_F_GATHER) {
-        if (f.arr < 0 || f.arr >= (int)n_arr) throw std::runtime_error("field array id out of range");
-        int64_t lo = f.base, hi = f.base;
-        for (int d = 0; d < 3; ++d) {
-          int64_t e = f.step[d] * (t.dims[d] - 1);
-          if (e < 0) lo += e; else hi += e;
-        }
-        if (lo < 0 || hi >= m.arrs[f.arr].n) throw std::runtime_error("field gather out of array bounds");
+      if (mode != IEM_F_AFFINE && mode != IEM_F_GATHER) throw std::runtime_error("unknown field mode");
+      if (!is_int && mode != IEM_F_GATHER) throw std::runtime_error("float item field must be a gather");
+      __int128 lo = f.base, hi = f.base;
+      for (int d = 0; d < 3; ++d) {
+        if (t.dims[d] == 0) continue;
+        __int128 e = (__int128)f.step[d] * (t.dims[d] - 1);
+        if (e < 0) lo += e; else hi += e;
+      }
+      if (lo < -(__int128)IEM_MAX_COUNT || hi > (__int128)IEM_MAX_COUNT) throw std::runtime_error("item field value range too large");
+      if (mode == IEM_F_GATHER) {
+        if (arr < 0 || arr >= n_arr) throw std::runtime_error("field array id out of range");
+        const ArrayDesc &a = m.arrs[arr];
+        if (is_int && a.kind != IEM_A_I64_DATA && a.kind != IEM_A_I64_RANGE) throw std::runtime_error("integer item field gathers from a float array");
+        if (t.n_items > 0 && (lo < 0 || hi >= a.n)) throw std::runtime_error("field gather out of array bounds");
       }
     };
     t.ifields.resize(n_if); t.ffields.resize(n_ff);
-    for (auto &f : t.ifields) rd_field(f);
-    for (auto &f : t.ffields) rd_field(f);
+    for (auto &f : t.ifields) rd_field(f, true);
+    for (auto &f : t.ffields) rd_field(f, false);
     t.idx.resize(n_idx);
     for (auto &ix : t.idx) {
       ix.c0 = *p++; ix.nterms = (int)*p++;
@@ -279,6 +306,7 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
     if (t.root < 0 || t.root >= n_nodes) throw std::runtime_error("bad root");
     analyse_template(t);
     t.o2 = o2; o2 += t.n_items * t.o2step;
+    if (o2 > IEM_MAX_COUNT * 64 || o1 > IEM_MAX_COUNT * 64) throw std::runtime_error("nnz out of range");
     if (t.kind == IEM_T_CON) {
       t.o0 = o0; o0 += t.n_items;
       t.o1 = o1; o1 += t.n_items * t.o1step;
