@@ -231,6 +231,32 @@ class ShardMaps:
         return self
 
 
+def replicated_indices(core: ExaCore) -> np.ndarray:
+    """0-based local indices of the variables every rank holds a copy of (finite variables and
+    infinite variables that do not depend on the sharded parameter) — the gradient entries that
+    need the all-reduce.  Computed from the shard alone (no global core)."""
+    g = core._shard_spec.group_index
+    d = core._shard_data
+    out = [np.arange(v.offset, v.offset + v.length) for v, groups in list(d.finvar_slabs) + list(d.infvar_slabs)
+           if g not in groups]
+    return np.concatenate(out).astype(np.int64) if out else np.zeros(0, dtype=np.int64)
+
+
+def allreduce_obj_grad_device(obj_dev, grad_dev, shared_idx_dev, buf, dist=None):
+    """Device-resident form of :func:`allreduce_obj_grad` (no host round trip, stream-ordered):
+    ``obj_dev`` is a 1-element tensor (``ExaModel.obj_device``), ``buf`` a preallocated
+    ``1 + len(shared)`` float64 tensor.  Returns ``buf[0:1]`` (the global objective, on device)."""
+    if dist is None:
+        import torch.distributed as dist
+    buf[0:1] = obj_dev
+    if shared_idx_dev.numel():
+        buf[1:] = grad_dev[shared_idx_dev]
+    dist.all_reduce(buf)
+    if shared_idx_dev.numel():
+        grad_dev[shared_idx_dev] = buf[1:]
+    return buf[0:1]
+
+
 def allreduce_obj_grad(obj_local: float, grad_local, shared_idx, dist=None):
     """The only data-path collective: sum the scalar objective and the gradient entries of
     replicated variables in ONE small buffer (8·(1+len(shared_idx)) bytes)."""

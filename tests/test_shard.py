@@ -67,6 +67,7 @@ def test_shards_reassemble_to_global(name, size, world, built):
         core = _shard(name, size, r, world)
         L = OracleModel(core.to_blob())
         maps = shard.ShardMaps(core, gcore, core._shard_spec, core._shard_data, gdata)
+        assert np.array_equal(shard.replicated_indices(core), np.nonzero(maps.replicated)[0])   # shard-only derivation
         x = xg[maps.var_map]
         y = yg[maps.row_map]
         f += L.obj(x)
