@@ -459,6 +459,7 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "no_fuse") == 0) { g_opt.no_fuse = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fuse_zero") == 0) { g_opt.fuse_zero = (int)value; return IEM_OK; }
   if (std::strcmp(name, "hess_merge") == 0) { g_opt.hess_merge = (int)value; return IEM_OK; }
   if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }
   if (std::strcmp(name, "block") == 0) {
@@ -498,6 +499,8 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     std::ostringstream os;
     os.precision(17);
     os << "partials " << p.n_partials << "\n";
+    for (int kind = 0; kind < iem::KK_COUNT; ++kind)   // ranges the runtime memsets before launching a scatter kind
+      for (auto &z : p.zero_ranges[kind]) os << "zero " << kind << " " << z.first << " " << z.second << "\n";
     for (const iem::KernelDesc &kd : p.kernels) {
       os << "kernel " << kd.name << " kind " << kd.kind << " grid " << kd.grid[0] << " " << kd.grid[1] << " " << kd.grid[2]
          << " lds " << kd.lds_bytes << " rbytes " << kd.alg_bytes_read << " wbytes " << kd.alg_bytes_written << " block " << kd.block << " tim " << (kd.tables_in_memory ? 1 : 0) << "\n";
@@ -586,17 +589,7 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
   }
   m->argbuf.resize(m->prog.kernels.size());
   for (size_t k = 0; k < m->prog.kernels.size(); ++k) build_argbuf(m, k);
-  for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) {
-    // complement of the ranges the scatter kernels of this kind overwrite completely
-    auto cov = m->prog.covered[kind];
-    std::sort(cov.begin(), cov.end());
-    int64_t pos = 0;
-    for (auto &c : cov) {
-      if (c.first > pos) m->zero_ranges[kind].emplace_back(pos, c.first);
-      pos = std::max(pos, c.second + 1);
-    }
-    if (pos < M.nvar) m->zero_ranges[kind].emplace_back(pos, M.nvar);
-  }
+  for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) m->zero_ranges[kind] = m->prog.zero_ranges[kind];
   m->grad_zero = m->zero_ranges[iem::KK_GRAD];
   if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) return bail(fail(IEM_E_HIP, "hipEventCreate"));
   *out = m;

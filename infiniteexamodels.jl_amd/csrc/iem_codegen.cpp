@@ -1099,6 +1099,16 @@ class KernelBuilder {
 
     // head: coordinates, guards, integer loads, index values, loads
     std::ostringstream head;
+    if (!zero_fill_.empty()) {
+      // fused memset of the output entries no template of this call writes (disjoint from every store)
+      head << "  {\n    const long long nb_ = (long long)gridDim.x * gridDim.y * gridDim.z;\n"
+           << "    const long long b_ = (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * blockIdx.z);\n";
+      for (auto &z : zero_fill_) {
+        head << "    iem_zero_fill(OUT + " << ip(z.first) << ", " << ip(z.second - z.first) << ", b_, nb_);\n";
+        alg_w_ += z.second - z.first;
+      }
+      head << "  }\n";
+    }
     if (g_.flat) {
       head << "  const long long q = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
       head << "  const bool inb = q < " << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << ";\n";
@@ -1200,6 +1210,8 @@ class KernelBuilder {
 
   // values per lane staged per barrier pair: `lds_slots` is quoted for 256-thread workgroups
   // (2 KB of LDS per slot) and scaled so the LDS per workgroup stays the same for other sizes
+  void set_zero_fill(const std::vector<std::pair<int64_t, int64_t>> &ranges) { zero_fill_ = ranges; }
+
   int stage_budget(int max_ns) const {
     int b = std::max(1, opt_.lds_slots * 256 / opt_.block);
     b = std::max(b, max_ns);
@@ -1237,6 +1249,7 @@ class KernelBuilder {
   std::map<int, int> fa_ids_, ia_ids_;
   std::vector<int> fav_, iav_;
   int64_t alg_w_ = 0, alg_r_loads_ = 0;
+  std::vector<std::pair<int64_t, int64_t>> zero_fill_;  // [lo, hi) ranges of OUT this kernel zeroes itself
   std::map<int, std::vector<std::pair<int64_t, int64_t>>> ranges_;
 };
 
@@ -1447,6 +1460,7 @@ Program generate(const Model &m, const Options &opt) {
       descs.push_back(kd);
     }
   }
+  bool accumulates[KK_COUNT] = {};
   // classify gradient slots: exclusive iff injective and its range meets no other slot's range
   for (size_t i = 0; i < gslots.size(); ++i) {
     GSlot &a = gslots[i];
@@ -1469,6 +1483,33 @@ Program generate(const Model &m, const Options &opt) {
     }
     if (mode == 2 && a.pure && a.uniform0) mode = 1;
     builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;
+    if (!(mode == 0 && a.hi - a.lo + 1 == a.count)) accumulates[a.kind] = true;
+  }
+  // Entries of the scatter outputs (g, Jᵀv, Hv) that no template overwrites completely must be
+  // zero before the kernels run.  When NOTHING of a kind accumulates (every slot stores
+  // exclusively and tiles its range), the complement is disjoint from every store and the largest
+  // kernel of the kind zeroes it itself (fused memset); otherwise the runtime issues memsets.
+  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
+    auto cov = P.covered[kind];
+    std::sort(cov.begin(), cov.end());
+    std::vector<std::pair<int64_t, int64_t>> holes;
+    int64_t pos = 0;
+    for (auto &c : cov) {
+      if (c.first > pos) holes.emplace_back(pos, c.first);
+      pos = std::max(pos, c.second + 1);
+    }
+    if (pos < m.nvar) holes.emplace_back(pos, m.nvar);
+    int best = -1;
+    for (size_t k = 0; k < descs.size(); ++k)
+      if (descs[k].kind == kind && (best < 0 || descs[k].n_blocks > descs[best].n_blocks)) best = (int)k;
+    int64_t hole_len = 0;
+    for (auto &h : holes) hole_len += h.second - h.first;
+    // per-workgroup share bounded (64 rounds of the block) so a small kernel never serialises a big memset
+    if (opt.fuse_zero && !accumulates[kind] && best >= 0 && !holes.empty() && holes.size() <= 16 &&
+        hole_len <= descs[best].n_blocks * 64 * (int64_t)opt.block)
+      builders[best]->set_zero_fill(holes);
+    else
+      P.zero_ranges[kind] = holes;
   }
   for (size_t k = 0; k < builders.size(); ++k) {
     src << builders[k]->emit(descs[k]);

@@ -39,6 +39,7 @@ struct Options {
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
   int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels
   int nt_stores = 1;   // 1: non-temporal stores for the streamed COO outputs
+  int fuse_zero = 1;   // 1: scatter kernels zero the untouched output entries themselves when nothing accumulates (no memset launch)
   int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)
 };
 
@@ -60,6 +61,7 @@ struct Program {
   // 0-based index ranges [lo, hi] of g that the gradient kernels overwrite completely
   std::vector<std::pair<int64_t, int64_t>> grad_covered;      // KK_GRAD
   std::vector<std::pair<int64_t, int64_t>> covered[KK_COUNT];  // per scatter kind (grad, jtprod, hprod)
+  std::vector<std::pair<int64_t, int64_t>> zero_ranges[KK_COUNT];  // [lo, hi) the runtime must memset before launching the kind (empty when fused into a kernel)
 };
 
 Program generate(const Model &m, const Options &opt);

@@ -170,6 +170,15 @@ __device__ __forceinline__ void iem_block_partial(double v, double *__restrict__
 }
 
 // gradient entry shared by every lane of the wave (index does not depend on q0)
+// Fused memset: workgroup b of nb zeroes its contiguous share of p[0, n) (chunks are multiples of
+// 16 doubles so that every workgroup but the first starts on a 128-byte line of the range).
+__device__ __forceinline__ void iem_zero_fill(double *__restrict__ p, long long n, long long b, long long nb) {
+  long long chunk = (n + nb - 1) / nb;
+  chunk = (chunk + 15) & ~15LL;
+  const long long lo = b * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (long long i = lo + threadIdx.x; i < hi; i += IEM_TILE) iem_stg(p + i, 0.0);
+}
+
 __device__ __forceinline__ void iem_grad_wave_uniform(double *__restrict__ g, long long idx, double v, bool valid) {
   v = iem_wave_sum(valid ? v : 0.0);
   const unsigned long long m = __ballot(valid);

@@ -53,5 +53,11 @@ inline void iem_flush(double *out, long long P0, int v0, int v1, const double *l
 }
 inline void __syncthreads() {}
 inline void iem_block_partial(double v, double *partials, long long slot, double *) { partials[slot] += v; }
+inline void iem_zero_fill(double *p, long long n, long long b, long long nb) {
+  long long chunk = (n + nb - 1) / nb;
+  chunk = (chunk + 15) & ~15LL;
+  const long long lo = b * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (long long i = lo + threadIdx.x; i < hi; i += IEM_TILE) p[i] = 0.0;
+}
 inline void iem_grad_wave_uniform(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }
 inline void iem_grad_atomic(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }

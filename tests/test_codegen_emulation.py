@@ -121,3 +121,30 @@ def test_short_first_dimension_uses_flat_lanes(built):
     assert _rel(em.cons(x), om.cons(x)) <= 1e-14
     assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
     assert _rel(em.hess_coord(x, y, 1.0, om.nnzh), om.hess_coord(x, y, 1.0)) <= 1e-14
+
+
+def test_gradient_zero_fill_is_fused_when_nothing_accumulates(built):
+    """grad!: 12 of the quadrotor's 22 slabs get no objective contribution.  Every gradient slot
+    stores exclusively, so the kernel zeroes those slabs itself (no memset launch); with
+    fuse_zero = 0 the launch plan lists the ranges for the runtime instead.  The emulator starts
+    from a NaN-poisoned vector either way."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core("quadrotor_100")
+    om = OracleModel(core.to_blob())
+    x, _ = cases.eval_point_for("quadrotor_100", om)
+    em = EmulatedModel(core)
+    assert "iem_zero_fill(OUT" in em.source and not [z for z in em.zero_ranges if z[0] == 4]
+    np.testing.assert_allclose(em.grad(x), om.grad(x), rtol=1e-13, atol=1e-13)
+    iemlib.set_option("fuse_zero", 0)
+    try:
+        em0 = EmulatedModel(core)
+    finally:
+        iemlib.set_option("fuse_zero", 1)
+    assert "iem_zero_fill(OUT" not in em0.source
+    assert sum(hi - lo for k, lo, hi in em0.zero_ranges if k == 4) == 12 * 100
+    np.testing.assert_allclose(em0.grad(x), om.grad(x), rtol=1e-13, atol=1e-13)
+    # a model whose objective accumulates into shared entries (farmer: E over scenarios of first-stage terms) keeps the memset
+    emf = EmulatedModel(cases.build_core("pandemic_20x3"))
+    omf = OracleModel(emf.blob)
+    xf, _ = cases.eval_point_for("pandemic_20x3", omf)
+    np.testing.assert_allclose(emf.grad(xf), omf.grad(xf), rtol=1e-13, atol=1e-13)
