@@ -240,6 +240,7 @@ void build_argbuf(iem_model *m, size_t k) {
 
 int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
   const iem::KernelDesc &kd = m->prog.kernels[k];
+  if (kd.n_blocks <= 0) return IEM_OK;   // a support grid none of whose templates has an item
   std::vector<uint64_t> &buf = m->argbuf[k];
   buf[0] = (uint64_t)(uintptr_t)x; buf[1] = (uint64_t)(uintptr_t)m->d_theta; buf[2] = (uint64_t)(uintptr_t)y;
   buf[3] = (uint64_t)(uintptr_t)v; buf[4] = (uint64_t)(uintptr_t)out;
@@ -359,6 +360,7 @@ int structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base, b
       size_t sz = sizeof A;
       void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
       long long total = hc.n_items * ns;
+      if (total == 0) continue;   // template without items (e.g. difference rows of a one-support grid)
       hipError_t e = hipModuleLaunchKernel(m->fn_struct, (unsigned)((total + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg);
       if (e != hipSuccess) { rc = fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e)); break; }
     }
@@ -385,6 +387,7 @@ int structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, int base, b
     size_t sz = sizeof A;
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     long long total = t.n_items * ns;
+    if (total == 0) continue;
     hipError_t e = hipModuleLaunchKernel(m->fn_struct, (unsigned)((total + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg);
     if (e != hipSuccess) { rc = fail(IEM_E_HIP, std::string("structure kernel: ") + hipGetErrorString(e)); break; }
   }
@@ -459,6 +462,7 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "no_fuse") == 0) { g_opt.no_fuse = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fuse_groups") == 0) { g_opt.fuse_groups = (int)value; return IEM_OK; }
   if (std::strcmp(name, "fuse_zero") == 0) { g_opt.fuse_zero = (int)value; return IEM_OK; }
   if (std::strcmp(name, "hess_merge") == 0) { g_opt.hess_merge = (int)value; return IEM_OK; }
   if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }

@@ -934,7 +934,9 @@ class KernelBuilder {
     }
   }
 
-  std::string emit(KernelDesc &kd) {
+  // as_body: emit a __device__ function `<name>_body` for a multi-group kernel (generate() writes the
+  // __global__ wrapper that owns the LDS and decodes the workgroup id) instead of a kernel of its own
+  std::string emit(KernelDesc &kd, bool as_body = false) {
     std::ostringstream body;
     std::vector<char> live(v_.size(), 0), done(v_.size(), 0);
     for (auto &o : outs_) for (int v : o.vals) mark_live(v, live);
@@ -1179,6 +1181,15 @@ class KernelBuilder {
     // the kernel-argument segment is limited (4 KB): big tables move to device memory and the
     // struct carries pointers instead — `A.ip[i]` reads the same either way (uniform scalar loads)
     kd.tables_in_memory = (nip + ndp + nfa + nia) > 320;
+    if (as_body) {
+      os << "__device__ __forceinline__ void " << name_ << "_body(const double* __restrict__ X, const double* __restrict__ TH, "
+         << "const double* __restrict__ Y, const double* __restrict__ V, double* __restrict__ OUT, const double w_,\n"
+         << "    const long long* ip_, const double* dp_, const double* const* FA, const long long* const* IA, double* lds_blk, double* lds4,\n"
+         << "    const long long BX_, const long long BY_, const long long BZ_, const long long GX_, const long long GY_, const long long GZ_) {\n";
+      os << "  const struct { const long long* ip; const double* dp; double w; } A = {ip_, dp_, w_};\n";
+      os << "  (void)X; (void)TH; (void)Y; (void)V; (void)FA; (void)IA; (void)A; (void)lds_blk; (void)lds4; (void)BY_; (void)BZ_; (void)GX_; (void)GY_; (void)GZ_;\n";
+      kd.tables_in_memory = false;
+    } else {
     os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n";
     if (kd.tables_in_memory)
       os << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
@@ -1191,19 +1202,32 @@ class KernelBuilder {
     os << "  double* __restrict__ OUT = A.out;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
+    }
     if (use_lds) {
-      os << "  __shared__ double lds_all[" << (opt_.block * max_ns) << "];\n";
+      if (as_body) os << "  double* lds_all = lds_blk;\n";
+      else os << "  __shared__ double lds_all[" << (opt_.block * max_ns) << "];\n";
       os << "  double* lds_wave = lds_all + iem_wave() * " << (64 * max_ns) << ";\n";
       kd.lds_bytes = opt_.block * max_ns * 8;
     }
     if (use_blk) {
       const int budget = stage_budget(max_ns);
-      os << "  __shared__ double lds_blk[" << (opt_.block * budget) << "];\n";
+      if (!as_body) os << "  __shared__ double lds_blk[" << (opt_.block * budget) << "];\n";
       os << "  const long long qb0 = (long long)blockIdx.x * IEM_TILE;\n";
       kd.lds_bytes = opt_.block * budget * 8;
     }
-    if (kind_ == KK_OBJ) os << "  __shared__ double lds4[IEM_TILE / 64];\n";
+    if (kind_ == KK_OBJ && !as_body) os << "  __shared__ double lds4[IEM_TILE / 64];\n";
     os << head.str() << tail.str() << "}\n\n";
+    if (as_body) {
+      // the body sees the workgroup coordinates of ITS OWN grid, decoded by the wrapper
+      std::string t = os.str();
+      auto subst = [&](const std::string &from, const std::string &to) {
+        for (size_t pos = 0; (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
+      };
+      subst("blockIdx.x", "BX_"); subst("blockIdx.y", "BY_"); subst("blockIdx.z", "BZ_");
+      subst("gridDim.x", "GX_"); subst("gridDim.y", "GY_"); subst("gridDim.z", "GZ_");
+      kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
+      return t;
+    }
     kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
     return os.str();
   }
@@ -1511,9 +1535,71 @@ Program generate(const Model &m, const Options &opt) {
     else
       P.zero_ranges[kind] = holes;
   }
-  for (size_t k = 0; k < builders.size(); ++k) {
-    src << builders[k]->emit(descs[k]);
-    P.kernels.push_back(descs[k]);
+  // One launch per NLPModels call: when the templates of a call live on several support grids
+  // (pandemic: t x xi and t; collocation: the node grids), the per-grid bodies become
+  // __device__ functions and ONE kernel dispatches on the workgroup id (block-uniform branch,
+  // shared LDS, largest grid first so that its workgroups start first).
+  for (int kind = 0; kind < KK_COUNT; ++kind) {
+    std::vector<size_t> ks;
+    for (size_t k = 0; k < descs.size(); ++k) if (descs[k].kind == kind) ks.push_back(k);
+    if (ks.empty()) continue;
+    if (ks.size() == 1 || !opt.fuse_groups || opt.no_fuse) {
+      for (size_t k : ks) { src << builders[k]->emit(descs[k]); P.kernels.push_back(descs[k]); }
+      continue;
+    }
+    std::stable_sort(ks.begin(), ks.end(), [&](size_t a, size_t b) { return descs[a].n_blocks > descs[b].n_blocks; });
+    KernelDesc F;
+    F.name = std::string("iem_") + kname[kind] + "_all";
+    F.kind = kind; F.block = opt.block;
+    F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
+    std::vector<size_t> oip, odp, ofa, oia;   // table offsets of each body
+    for (size_t k : ks) {
+      src << builders[k]->emit(descs[k], true);
+      const KernelDesc &d = descs[k];
+      oip.push_back(F.ip.size()); odp.push_back(F.dp.size()); ofa.push_back(F.fa.size()); oia.push_back(F.ia.size());
+      F.ip.insert(F.ip.end(), d.ip.begin(), d.ip.end());
+      F.dp.insert(F.dp.end(), d.dp.begin(), d.dp.end());
+      F.fa.insert(F.fa.end(), d.fa.begin(), d.fa.end());
+      F.ia.insert(F.ia.end(), d.ia.begin(), d.ia.end());
+      F.grid[0] += d.n_blocks;
+      F.lds_bytes = std::max(F.lds_bytes, d.lds_bytes);
+      F.alg_bytes_read += d.alg_bytes_read; F.alg_bytes_written += d.alg_bytes_written;
+    }
+    if (F.grid[0] > 2147483647LL) throw std::runtime_error("support grids too large for one launch");
+    F.n_blocks = F.grid[0];
+    // workgroup decode table: per body {first workgroup, gx, gy, gz} (launch-size dependent -> arguments)
+    const size_t dec = F.ip.size();
+    int64_t first = 0;
+    for (size_t k : ks) {
+      const KernelDesc &d = descs[k];
+      F.ip.push_back(first); F.ip.push_back(d.grid[0]); F.ip.push_back(d.grid[1]); F.ip.push_back(d.grid[2]);
+      first += d.n_blocks;
+    }
+    size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
+    size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
+    F.tables_in_memory = (nip + ndp + nfa + nia) > 320;
+    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n";
+    if (F.tables_in_memory)
+      src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
+    else
+      src << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
+    src << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt.min_waves > 0 ? ", " + std::to_string(opt.min_waves) : std::string())
+        << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
+    if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
+    else src << "  double* lds_blk = nullptr;\n";
+    if (kind == KK_OBJ) src << "  __shared__ double lds4[IEM_TILE / 64];\n";
+    else src << "  double* lds4 = nullptr;\n";
+    src << "  const long long b = blockIdx.x;\n";
+    for (size_t j = 0; j < ks.size(); ++j) {
+      const size_t e = dec + 4 * j;
+      src << "  " << (j ? "else " : "");
+      if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
+      src << "{\n    const long long lb = b - A.ip[" << e << "], gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
+          << "    " << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
+          << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n  }\n";
+    }
+    src << "}\n\n";
+    P.kernels.push_back(F);
   }
   P.n_partials = partial_off;
   P.source = src.str();

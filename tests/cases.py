@@ -103,6 +103,7 @@ def irregular():
 def small_cases():
     """name -> (core builder, positive?)"""
     return {
+        "quadrotor_1": lambda: workloads.quadrotor(1),      # degenerate: the nine difference templates have NO items
         "quadrotor_5": lambda: workloads.quadrotor(5),
         "quadrotor_100": lambda: workloads.quadrotor(100),
         "quadrotor_1000": lambda: workloads.quadrotor(1000),
@@ -110,6 +111,7 @@ def small_cases():
         "quadrotor_oc3_700": lambda: workloads.quadrotor(700, collocation=3),
         "pandemic_20x3": lambda: workloads.pandemic(20, 3),
         "pandemic_300x7": lambda: workloads.pandemic(300, 7),
+        "farmer_1": lambda: workloads.farmer(1),
         "farmer_5": lambda: workloads.farmer(5),
         "farmer_1000": lambda: workloads.farmer(1000),
         "opf_7": lambda: workloads.opf(7),

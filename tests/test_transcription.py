@@ -231,3 +231,22 @@ def test_orthogonal_collocation_structure_and_exactness(built):
         assert len(ts) == 3 * (nodes - 1) + 1
         x = np.concatenate([poly(ts), dpoly(ts)])
         assert np.abs(om.cons(x)[len(ts):]).max() < 1e-13
+
+
+def test_objective_sense_travels_as_metadata(built):
+    """transform.jl:814-815: `minimize = objective_sense == MIN_SENSE` goes to ExaCore and from
+    there to `meta.minimize` (NLPModels convention: obj/grad are NOT negated, the solver reads
+    the flag)."""
+    from pyoracle import OracleModel
+
+    def make(sense):
+        m = InfiniteModel()
+        t = m.infinite_parameter("t", 0, 1, num_supports=4)
+        y = m.variable("y", t, start=0.5)
+        m.objective(sense, m.integral(y ** 2, t))
+        return transcribe.exa_core(m)
+    cmin, cmax = make("min"), make("max")
+    assert cmin.minimize and not cmax.minimize
+    omin, omax = OracleModel(cmin.to_blob()), OracleModel(cmax.to_blob())
+    assert omin.minimize and not omax.minimize
+    assert omin.obj(omin.x0) == omax.obj(omax.x0) > 0

@@ -31,7 +31,12 @@ def main():
     ap.add_argument("--nxi", type=int, default=100)
     ap.add_argument("--supports", type=int, default=100_000)
     ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
     args = ap.parse_args()
+    from infiniteexamodels.jl_amd import lib as iemlib
+    for kv in args.opt:
+        k, v = kv.split("=")
+        iemlib.set_option(k, int(v))
     t0 = time.perf_counter()
     if args.workload == "pandemic":
         im = workloads.pandemic(args.nt, args.nxi)
