@@ -115,9 +115,10 @@ struct iem_model {
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
-  hipFunction_t fn_reduce = nullptr, fn_struct = nullptr, fn_csr = nullptr;
+  hipFunction_t fn_struct = nullptr, fn_csr = nullptr;
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
-  double *h_obj = nullptr;  // pinned
+  double *h_obj = nullptr;   // pinned + mapped host scalar
+  double *d_hobj = nullptr;  // its device address
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
   std::vector<void *> d_tables;    // per kernel: device copy of {ip, dp, fa, ia} when they do not fit the argument block
@@ -209,18 +210,17 @@ int compile_or_load(iem_model *m) {
   m->fns.resize(m->prog.kernels.size());
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));
-  HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_reduce_partials"));
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
   return IEM_OK;
 }
 
 // Builds the static part of kernel k's argument block once (iem_create); launch() only rewrites
-// the head {x, theta, y, v, out, w}.
+// the head {x, theta, y, v, out, w, aux}.
 void build_argbuf(iem_model *m, size_t k) {
   const iem::KernelDesc &kd = m->prog.kernels[k];
   std::vector<uint64_t> &buf = m->argbuf[k];
-  buf.assign(6, 0);
+  buf.assign(7, 0);
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
   if (kd.tables_in_memory) {
     const uint64_t *tb = (const uint64_t *)m->d_tables[k];
@@ -238,13 +238,14 @@ void build_argbuf(iem_model *m, size_t k) {
   }
 }
 
-int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
+int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
   const iem::KernelDesc &kd = m->prog.kernels[k];
   if (kd.n_blocks <= 0) return IEM_OK;   // a support grid none of whose templates has an item
   std::vector<uint64_t> &buf = m->argbuf[k];
   buf[0] = (uint64_t)(uintptr_t)x; buf[1] = (uint64_t)(uintptr_t)m->d_theta; buf[2] = (uint64_t)(uintptr_t)y;
   buf[3] = (uint64_t)(uintptr_t)v; buf[4] = (uint64_t)(uintptr_t)out;
   std::memcpy(&buf[5], &w, 8);
+  buf[6] = (uint64_t)(uintptr_t)aux;
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
@@ -252,10 +253,10 @@ int launch(iem_model *m, size_t k, const double *x, const double *y, double *out
   return IEM_OK;
 }
 
-int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr) {
+int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     if (m->prog.kernels[k].kind == kind) {
-      int rc = launch(m, k, x, y, out, w, v);
+      int rc = launch(m, k, x, y, out, w, v, aux);
       if (rc) return rc;
     }
   return IEM_OK;
@@ -567,10 +568,17 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
   if (hipMalloc((void **)&m->d_theta, m->theta_host.size() * 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc theta"));
   if (hipMemcpy(m->d_theta, m->theta_host.data(), m->theta_host.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
     return bail(fail(IEM_E_HIP, "upload theta"));
-  if (hipMalloc((void **)&m->d_partials, (size_t)std::max<int64_t>(m->prog.n_partials, 1) * 8) != hipSuccess)
-    return bail(fail(IEM_E_HIP, "hipMalloc partials"));
+  // partials + the ticket counters behind them (iem_block_partial: 1 top + one per 32 workgroups),
+  // zeroed once — the workgroups that complete a count reset it
+  {
+    const size_t np = (size_t)std::max<int64_t>(m->prog.n_partials, 1);
+    const size_t words = np + 1 + (np + 31) / 32;
+    if (hipMalloc((void **)&m->d_partials, words * 8) != hipSuccess || hipMemset(m->d_partials, 0, words * 8) != hipSuccess)
+      return bail(fail(IEM_E_HIP, "hipMalloc partials"));
+  }
   if (hipMalloc((void **)&m->d_obj, 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc obj"));
-  if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocDefault) != hipSuccess) return bail(fail(IEM_E_HIP, "hipHostMalloc"));
+  if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&m->d_hobj, m->h_obj, 0) != hipSuccess) return bail(fail(IEM_E_HIP, "hipHostMalloc"));
   for (const iem::KernelDesc &kd : m->prog.kernels) {
     for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return bail(rc);
     for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return bail(rc);
@@ -702,19 +710,20 @@ int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_va
 int iem_obj_device(iem_model *m, const double *d_x, double *d_out) {
   if (!m || !d_x || !d_out) return fail(IEM_E_ARG, "null argument");
   DevGuard dg_(m->device);
-  int rc = launch_kind(m, iem::KK_OBJ, d_x, nullptr, m->d_partials, 0.0);
-  if (rc) return rc;
-  long long n = m->prog.n_partials;
-  void *args[] = {(void *)&m->d_partials, (void *)&n, (void *)&d_out};
-  HIP_TRY(hipModuleLaunchKernel(m->fn_reduce, 1, 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
-  return IEM_OK;
+  if (m->prog.n_partials == 0) {   // no objective template: f = 0
+    HIP_TRY(hipMemsetAsync(d_out, 0, 8, m->stream));
+    return IEM_OK;
+  }
+  // the last workgroup of the objective kernel(s) to finish writes the scalar to d_out
+  return launch_kind(m, iem::KK_OBJ, d_x, nullptr, m->d_partials, 0.0, nullptr, d_out);
 }
 
 int iem_obj(iem_model *m, const double *d_x, double *h_out) {
-  if (!h_out) return fail(IEM_E_ARG, "null argument");
-  int rc = iem_obj_device(m, d_x, m ? m->d_obj : nullptr);
+  if (!m || !h_out) return fail(IEM_E_ARG, "null argument");
+  if (m->prog.n_partials == 0) { *h_out = 0.0; return d_x ? IEM_OK : fail(IEM_E_ARG, "null argument"); }
+  // result written by the kernel straight into mapped pinned host memory: no copy, one synchronise
+  int rc = iem_obj_device(m, d_x, m->d_hobj);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(m->h_obj, m->d_obj, 8, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   *h_out = *m->h_obj;
   return IEM_OK;

@@ -1097,7 +1097,7 @@ class KernelBuilder {
     }
     flush_batch();
     if (kind_ == KK_OBJ)
-      tail << "  iem_block_partial(acc, OUT, A.ip[" << ip_index(kd.partial_off) << "] + (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * (long long)blockIdx.z), lds4);\n";
+      tail << "  iem_block_partial(acc, OUT, A.ip[" << ip_index(kd.partial_off) << "] + (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * (long long)blockIdx.z), lds4, " << ip(n_partials_) << ", AUX);\n";
 
     // head: coordinates, guards, integer loads, index values, loads
     std::ostringstream head;
@@ -1183,14 +1183,14 @@ class KernelBuilder {
     kd.tables_in_memory = (nip + ndp + nfa + nia) > 320;
     if (as_body) {
       os << "__device__ __forceinline__ void " << name_ << "_body(const double* __restrict__ X, const double* __restrict__ TH, "
-         << "const double* __restrict__ Y, const double* __restrict__ V, double* __restrict__ OUT, const double w_,\n"
+         << "const double* __restrict__ Y, const double* __restrict__ V, double* __restrict__ OUT, const double w_, double* __restrict__ AUX,\n"
          << "    const long long* ip_, const double* dp_, const double* const* FA, const long long* const* IA, double* lds_blk, double* lds4,\n"
          << "    const long long BX_, const long long BY_, const long long BZ_, const long long GX_, const long long GY_, const long long GZ_) {\n";
       os << "  const struct { const long long* ip; const double* dp; double w; } A = {ip_, dp_, w_};\n";
-      os << "  (void)X; (void)TH; (void)Y; (void)V; (void)FA; (void)IA; (void)A; (void)lds_blk; (void)lds4; (void)BY_; (void)BZ_; (void)GX_; (void)GY_; (void)GZ_;\n";
+      os << "  (void)X; (void)TH; (void)Y; (void)V; (void)FA; (void)IA; (void)A; (void)AUX; (void)lds_blk; (void)lds4; (void)BY_; (void)BZ_; (void)GX_; (void)GY_; (void)GZ_;\n";
       kd.tables_in_memory = false;
     } else {
-    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n";
+    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
     if (kd.tables_in_memory)
       os << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
     else
@@ -1199,7 +1199,7 @@ class KernelBuilder {
        << ") void " << name_ << "(const Args_" << name_ << " A) {\n";
     os << "  const double* __restrict__ X = A.x; const double* __restrict__ TH = A.th; const double* __restrict__ Y = A.y;\n";
     os << "  const double* __restrict__ V = A.v; (void)V;\n";
-    os << "  double* __restrict__ OUT = A.out;\n";
+    os << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; (void)AUX;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
     }
@@ -1215,7 +1215,7 @@ class KernelBuilder {
       os << "  const long long qb0 = (long long)blockIdx.x * IEM_TILE;\n";
       kd.lds_bytes = opt_.block * budget * 8;
     }
-    if (kind_ == KK_OBJ && !as_body) os << "  __shared__ double lds4[IEM_TILE / 64];\n";
+    if (kind_ == KK_OBJ && !as_body) os << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
     os << head.str() << tail.str() << "}\n\n";
     if (as_body) {
       // the body sees the workgroup coordinates of ITS OWN grid, decoded by the wrapper
@@ -1234,6 +1234,7 @@ class KernelBuilder {
 
   // values per lane staged per barrier pair: `lds_slots` is quoted for 256-thread workgroups
   // (2 KB of LDS per slot) and scaled so the LDS per workgroup stays the same for other sizes
+  void set_n_partials(int64_t n) { n_partials_ = n; }
   void set_zero_fill(const std::vector<std::pair<int64_t, int64_t>> &ranges) { zero_fill_ = ranges; }
 
   int stage_budget(int max_ns) const {
@@ -1273,6 +1274,7 @@ class KernelBuilder {
   std::map<int, int> fa_ids_, ia_ids_;
   std::vector<int> fav_, iav_;
   int64_t alg_w_ = 0, alg_r_loads_ = 0;
+  int64_t n_partials_ = 1;  // KK_OBJ: workgroups of ALL objective kernels of the call (the last one to finish reduces)
   std::vector<std::pair<int64_t, int64_t>> zero_fill_;  // [lo, hi) ranges of OUT this kernel zeroes itself
   std::map<int, std::vector<std::pair<int64_t, int64_t>>> ranges_;
 };
@@ -1484,6 +1486,7 @@ Program generate(const Model &m, const Options &opt) {
       descs.push_back(kd);
     }
   }
+  for (auto &kb : builders) kb->set_n_partials(std::max<int64_t>(partial_off, 1));
   bool accumulates[KK_COUNT] = {};
   // classify gradient slots: exclusive iff injective and its range meets no other slot's range
   for (size_t i = 0; i < gslots.size(); ++i) {
@@ -1578,7 +1581,7 @@ Program generate(const Model &m, const Options &opt) {
     size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
     size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
     F.tables_in_memory = (nip + ndp + nfa + nia) > 320;
-    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w;\n";
+    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
     if (F.tables_in_memory)
       src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
     else
@@ -1587,7 +1590,7 @@ Program generate(const Model &m, const Options &opt) {
         << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
     if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
     else src << "  double* lds_blk = nullptr;\n";
-    if (kind == KK_OBJ) src << "  __shared__ double lds4[IEM_TILE / 64];\n";
+    if (kind == KK_OBJ) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
     else src << "  double* lds4 = nullptr;\n";
     src << "  const long long b = blockIdx.x;\n";
     for (size_t j = 0; j < ks.size(); ++j) {
@@ -1595,7 +1598,7 @@ Program generate(const Model &m, const Options &opt) {
       src << "  " << (j ? "else " : "");
       if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
       src << "{\n    const long long lb = b - A.ip[" << e << "], gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-          << "    " << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
+          << "    " << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
           << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n  }\n";
     }
     src << "}\n\n";

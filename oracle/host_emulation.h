@@ -52,7 +52,17 @@ inline void iem_flush(double *out, long long P0, int v0, int v1, const double *l
   if (t >= v0 && t < v1) for (int s = 0; s < NS; ++s) out[P0 + (long long)t * NS + s] = lds_reg[t * NS + s];
 }
 inline void __syncthreads() {}
-inline void iem_block_partial(double v, double *partials, long long slot, double *) { partials[slot] += v; }
+inline void iem_block_partial(double v, double *partials, long long slot, double *, long long n, double *out) {
+  partials[slot] += v;                       // lanes run one at a time: the partial accumulates in place
+  if (threadIdx.x != IEM_TILE - 1) return;   // last lane of the workgroup takes the ticket
+  double &ticket = partials[n];
+  ticket += 1.0;
+  if (ticket < (double)n) return;
+  double tot = 0.0;
+  for (long long i = 0; i < n; ++i) tot += partials[i];
+  out[0] = tot;
+  ticket = 0.0;
+}
 inline void iem_zero_fill(double *p, long long n, long long b, long long nb) {
   long long chunk = (n + nb - 1) / nb;
   chunk = (chunk + 15) & ~15LL;
