@@ -1075,8 +1075,7 @@ class KernelBuilder {
           tail << "  { const double r[" << ns << "] = {";
           for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
           tail << "};\n";
-          if (false) {
-          } else if (use_lds && !scalar_tpl) tail << "    iem_store_rows<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r, lds_wave); }\n";
+          if (use_lds && !scalar_tpl) tail << "    iem_store_rows<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r, lds_wave); }\n";
           else tail << "    iem_store_rows_direct<" << ns << ">(OUT, i" << o.pos_idx << ", " << g << ", r); }\n";
           break;
         }

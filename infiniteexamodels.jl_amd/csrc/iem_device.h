@@ -8,17 +8,20 @@
 //   * one wavefront LANE per discretisation support: lane q of a 64-wide wave owns
 //     grid point q, so x-slab reads  x[off_k + q]  are 512-byte coalesced loads;
 //   * COO blocks are item-major (position o + nslots*k + s — the layout ExaModels'
-//     jac_coord!/hess_coord! define).  iem_store_rows<NS> stages a wave's NS×64
-//     values in LDS and writes the wave's block — which is CONTIGUOUS in HBM — with
-//     NS fully coalesced 512-byte stores instead of 64 strided 8-byte stores per
-//     instruction; no atomics, no zero-fill pass;
+//     jac_coord!/hess_coord! define), so a workgroup's NS×TILE values are CONTIGUOUS in HBM.
+//     Default store path (store_mode 2): iem_stage<NS> parks the values of several templates
+//     in LDS, one barrier pair later iem_flush<NS> writes each block with 128-byte-ALIGNED,
+//     fully coalesced, non-temporal stores (COO offsets such as 9 would otherwise misalign
+//     every line: 4.5 vs 5.6 TB/s, profiles/r01_store_pattern_microbench.txt).  store_mode 1
+//     (iem_store_rows<NS>, wave-private LDS transpose, no barrier) and store_mode 0 (direct
+//     strided stores) remain for A/B runs.  No atomics, no zero-fill pass;
 //   * objective: wave shuffle reduction → LDS → one partial per workgroup; the last workgroup
 //     to finish sums the partials in a fixed order (bitwise reproducible, no second launch);
 //   * gradient entries shared by many items (finite / first-stage variables):
-//     wavefront reduction first, then one f64 atomic per wave.
+//     wavefront reduction first, then one f64 atomic per wave; entries nothing writes are
+//     zeroed by the kernel itself (iem_zero_fill) when no slot accumulates.
 //
-// wave = 64 lanes on CDNA4; blocks are 256 threads = 4 waves, each wave owns a
-// private LDS staging region, so no __syncthreads() is needed on the store path.
+// wave = 64 lanes on CDNA4; the generated kernels run IEM_TILE (default 512) lanes per workgroup.
 #ifndef IEM_DEVICE_H
 #define IEM_DEVICE_H
 
