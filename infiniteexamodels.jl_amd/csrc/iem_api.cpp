@@ -463,6 +463,7 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "no_fuse") == 0) { g_opt.no_fuse = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "split_small") == 0) { g_opt.split_small = (int)value; return IEM_OK; }
   if (std::strcmp(name, "fuse_groups") == 0) { g_opt.fuse_groups = (int)value; return IEM_OK; }
   if (std::strcmp(name, "fuse_zero") == 0) { g_opt.fuse_zero = (int)value; return IEM_OK; }
   if (std::strcmp(name, "hess_merge") == 0) { g_opt.hess_merge = (int)value; return IEM_OK; }

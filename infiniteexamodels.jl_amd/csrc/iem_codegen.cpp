@@ -17,6 +17,7 @@
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
 #include <tuple>
@@ -1281,7 +1282,9 @@ class KernelBuilder {
 // ---------------------------------------------------------------------------
 // grouping + validation
 // ---------------------------------------------------------------------------
-std::vector<Group> make_groups(const Model &m, bool no_fuse) {
+// `solo(ti)`: template ti gets a launch domain of its own (its item box) instead of joining the
+// lanes of its support grid
+std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)> &solo) {
   std::vector<Group> groups;
   std::map<std::pair<int64_t, int>, int> by_key;
   std::vector<int> scalars;
@@ -1292,7 +1295,7 @@ std::vector<Group> make_groups(const Model &m, bool no_fuse) {
       continue;
     }
     int gi;
-    if (t.grid_id > 0 && !no_fuse) {
+    if (t.grid_id > 0 && !solo(ti)) {
       auto key = std::make_pair(t.grid_id, t.nd);
       auto it = by_key.find(key);
       if (it == by_key.end()) {
@@ -1417,7 +1420,22 @@ void validate_indices(const Model &m) {
 Program generate(const Model &m, const Options &opt) {
   validate_indices(m);
   Program P;
-  std::vector<Group> groups = make_groups(m, opt.no_fuse != 0);
+  std::vector<Group> groups = make_groups(m, [&](size_t) { return opt.no_fuse != 0; });
+  if (!opt.no_fuse && opt.split_small > 0 && !opt.hess_merge) {   // the merged Hessian layout is defined on fused lanes
+    // A support grid that fills only a fraction of the chip (<= split_small workgroups) is
+    // latency-bound: one wave runs the whole fused lane program while most CUs idle.  Its
+    // templates then run side by side — one body each, all in the same launch (the workgroup-id
+    // dispatch below) — trading the cross-template CSE for parallelism.  Measured crossover on
+    // MI355X: 64 workgroups (32 768 supports at 512 lanes), profiles/r01_ab_small_grids.txt.
+    std::set<size_t> solo;
+    for (const Group &g : groups) {
+      if (g.grid_id <= 0 || g.tpls.size() < 2) continue;
+      const int64_t nb = g.flat ? (g.ext[0] * g.ext[1] * g.ext[2] + opt.block - 1) / opt.block
+                                : (g.ext[0] + opt.block - 1) / opt.block * g.ext[1] * g.ext[2];
+      if (nb <= opt.split_small) solo.insert(g.tpls.begin(), g.tpls.end());
+    }
+    if (!solo.empty()) groups = make_groups(m, [&](size_t ti) { return solo.count(ti) != 0; });
+  }
   std::ostringstream src;
   src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";
   static const char *kname[] = {"cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod"};
@@ -1545,7 +1563,7 @@ Program generate(const Model &m, const Options &opt) {
     std::vector<size_t> ks;
     for (size_t k = 0; k < descs.size(); ++k) if (descs[k].kind == kind) ks.push_back(k);
     if (ks.empty()) continue;
-    if (ks.size() == 1 || !opt.fuse_groups || opt.no_fuse) {
+    if (ks.size() == 1 || !opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2)) {   // fuse_groups = 2: experiments (one launch of per-template bodies)
       for (size_t k : ks) { src << builders[k]->emit(descs[k]); P.kernels.push_back(descs[k]); }
       continue;
     }

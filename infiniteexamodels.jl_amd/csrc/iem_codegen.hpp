@@ -39,6 +39,7 @@ struct Options {
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
   int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels
   int nt_stores = 1;   // 1: non-temporal stores for the streamed COO outputs
+  int split_small = 64; // support grids of at most this many workgroups run their templates side by side (0: never)
   int fuse_groups = 1; // 1: one launch per call even when its templates live on several support grids (workgroup-id dispatch)
   int fuse_zero = 1;   // 1: scatter kernels zero the untouched output entries themselves when nothing accumulates (no memset launch)
   int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)

@@ -105,6 +105,32 @@ def set_option(name: str, value: int):
     check(lib().iem_set_option(name.encode(), int(value)))
 
 
+# generator knobs and their defaults (csrc/iem_codegen.hpp: struct Options)
+OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=512, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
+                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64)
+
+
+class options:
+    """``with options(split_small=0): ...`` — generator knobs for the models created inside the
+    block, defaults restored on exit (the knobs are process-global in the library)."""
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(OPTION_DEFAULTS)
+        if unknown:
+            raise KeyError(f"unknown generator option(s): {sorted(unknown)}")
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, OPTION_DEFAULTS[k])
+        return False
+
+
 def emit_source(blob: bytes):
     """Generated HIP source of a model and its cache key (no device needed)."""
     L = lib()

@@ -21,3 +21,21 @@ def built():
     iemlib.build_library()
     pyoracle.build()
     return True
+
+
+@pytest.fixture
+def lane_fused(built):
+    """Force the lane-fused kernels (the path the headline sizes take) on small models: by default
+    a support grid of <= 64 workgroups runs its templates side by side (`split_small`)."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    with iemlib.options(split_small=0):
+        yield
+
+
+@pytest.fixture(params=["lane_fused", "templates_side_by_side"])
+def grid_mode(request, built):
+    """Both code shapes of a small model: lane-fused (what large grids use) and the default for
+    small grids (one body per template, all in one launch)."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    with iemlib.options(split_small=0 if request.param == "lane_fused" else 64):
+        yield request.param

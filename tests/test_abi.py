@@ -100,7 +100,7 @@ def test_generated_kernels_cross_compile_for_gfx950(built, tmp_path):
     assert "kernel iem_jac_" in plan and "kernel iem_hess_" in plan
 
 
-def test_launch_plan_reports_algorithmic_bytes(built):
+def test_launch_plan_reports_algorithmic_bytes(lane_fused):
     """Roofline bookkeeping: quadrotor jac reads 6 x-slabs + the stencil array, writes nnzj."""
     from infiniteexamodels.jl_amd import transcribe, workloads
     S = 4096

@@ -17,7 +17,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("name", list(cases.small_cases()))
-def test_emulated_kernels_match_oracle(name, built):
+def test_emulated_kernels_match_oracle(name, grid_mode):
     core = cases.build_core(name)
     blob = core.to_blob()
     om = OracleModel(blob)
@@ -40,7 +40,7 @@ def test_emulated_kernels_match_oracle(name, built):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_store_modes_emit_and_agree(mode, built):
+def test_store_modes_emit_and_agree(mode, grid_mode):
     core = cases.build_core("pandemic_20x3")
     blob = core.to_blob()
     om = OracleModel(blob)
@@ -55,13 +55,18 @@ def test_store_modes_emit_and_agree(mode, built):
 
 
 def test_generated_source_is_size_independent(built):
-    """One code object serves 10^2 and 10^6 supports: sizes are kernel arguments."""
+    """Sizes are kernel arguments: one code object serves every grid larger than `split_small`
+    workgroups (40 000 … 10^6 supports and beyond), a second one every smaller grid."""
     from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
-    keys = {iemlib.emit_source(transcribe.exa_core(workloads.quadrotor(S)).to_blob())[1] for S in (100, 1000, 4096)}
-    assert len(keys) == 1
+    key = lambda S: iemlib.emit_source(transcribe.exa_core(workloads.quadrotor(S)).to_blob())[1]
+    large = {key(S) for S in (40_000, 100_000)}
+    small = {key(S) for S in (100, 1000, 4096)}
+    assert len(large) == 1 and len(small) == 1 and large != small
+    with iemlib.options(split_small=0):
+        assert {key(100)} == large       # the lane-fused source is the same at any size
 
 
-def test_cross_template_cse(built):
+def test_cross_template_cse(lane_fused):
     """x7 feeds six templates: its load and its sincos appear once per lane in the fused kernel."""
     from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
     src, _ = iemlib.emit_source(transcribe.exa_core(workloads.quadrotor(100)).to_blob())
@@ -71,7 +76,7 @@ def test_cross_template_cse(built):
 
 
 @pytest.mark.parametrize("name", ["quadrotor_100", "pandemic_20x3", "opf_7", "operator_zoo", "irregular", "rosenbrock"])
-def test_merged_hessian_layout_is_equivalent(name, built):
+def test_merged_hessian_layout_is_equivalent(name, lane_fused):
     """Opt-in merged layout: fewer entries, same matrix (dense sums equal), lower triangular."""
     from helpers import coo_to_dense
     from infiniteexamodels.jl_amd import lib as iemlib
@@ -92,7 +97,7 @@ def test_merged_hessian_layout_is_equivalent(name, built):
     np.testing.assert_allclose(D, Do, rtol=1e-13, atol=1e-13 * max(1.0, np.abs(Do).max()))
 
 
-def test_long_second_grid_dimension_is_folded(built):
+def test_long_second_grid_dimension_is_folded(lane_fused):
     """A 2-D support grid whose second extent exceeds gridDim.y (65535) is folded over blockIdx.z;
     the overshoot blocks must neither load nor store."""
     from infiniteexamodels.jl_amd import transcribe, workloads
@@ -106,7 +111,7 @@ def test_long_second_grid_dimension_is_folded(built):
     assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
 
 
-def test_short_first_dimension_uses_flat_lanes(built):
+def test_short_first_dimension_uses_flat_lanes(lane_fused):
     """A box whose first dimension cannot fill a wave (12 x 70000 supports; the 2 x (S-1) box
     of an OrthogonalCollocation(3) derivative) is walked by one linear lane index."""
     from infiniteexamodels.jl_amd import transcribe, workloads
@@ -123,7 +128,7 @@ def test_short_first_dimension_uses_flat_lanes(built):
     assert _rel(em.hess_coord(x, y, 1.0, om.nnzh), om.hess_coord(x, y, 1.0)) <= 1e-14
 
 
-def test_gradient_zero_fill_is_fused_when_nothing_accumulates(built):
+def test_gradient_zero_fill_is_fused_when_nothing_accumulates(lane_fused):
     """grad!: 12 of the quadrotor's 22 slabs get no objective contribution.  Every gradient slot
     stores exclusively, so the kernel zeroes those slabs itself (no memset launch); with
     fuse_zero = 0 the launch plan lists the ranges for the runtime instead.  The emulator starts

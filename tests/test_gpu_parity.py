@@ -41,7 +41,7 @@ def _models(name, torch):
 
 
 @pytest.mark.parametrize("name", list(cases.small_cases()))
-def test_all_entry_points_match_oracle(name, torch_cuda):
+def test_all_entry_points_match_oracle(name, torch_cuda, grid_mode):
     torch = torch_cuda
     core, om, gm = _models(name, torch)
     assert (gm.meta.nvar, gm.meta.ncon, gm.meta.nnzj, gm.meta.nnzh) == (om.nvar, om.ncon, om.nnzj, om.nnzh)
@@ -97,7 +97,7 @@ def test_all_entry_points_match_oracle(name, torch_cuda):
 
 
 @pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "irregular", "test_problem_1"])
-def test_store_modes_agree(name, torch_cuda):
+def test_store_modes_agree(name, torch_cuda, grid_mode):
     """Direct strided stores (0), wave-level LDS-transposed stores (1) and the
     block-cooperative 128-byte-aligned stores (2) write identical bytes."""
     torch = torch_cuda
@@ -228,7 +228,7 @@ def test_quadrotor_1e6_headline_size(torch_cuda):
     gm.close()
 
 
-def test_eval_loop_is_graph_capturable(torch_cuda):
+def test_eval_loop_is_graph_capturable(torch_cuda, grid_mode):
     """The five-call evaluation loop captured into a HIP graph (torch.cuda.graph) and replayed
     on new inputs gives the same results as eager calls: no allocation / synchronisation
     hides in the launch path."""

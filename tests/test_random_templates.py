@@ -110,7 +110,7 @@ BIG_SEEDS = [100, 101, 102, 103]
 
 
 @pytest.mark.parametrize("seed", SEEDS)
-def test_random_model_oracle_vs_autograd_vs_generated(seed, built):
+def test_random_model_oracle_vs_autograd_vs_generated(seed, grid_mode):
     from emu import EmulatedModel
     core = random_core(seed)
     blob = core.to_blob()
@@ -145,7 +145,7 @@ def test_random_model_oracle_vs_autograd_vs_generated(seed, built):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS)
-def test_random_model_gpu(seed, built):
+def test_random_model_gpu(seed, grid_mode):
     import torch
     from infiniteexamodels.jl_amd.model import ExaModel
     from test_gpu_parity import _close

@@ -37,6 +37,11 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         iemlib.set_option(k, int(v))
+    print(json.dumps(measure(args)))
+
+
+def measure(args):
+    """One workload through the five-call loop; `args` needs workload, nt, nxi, supports, iters."""
     t0 = time.perf_counter()
     if args.workload == "pandemic":
         im = workloads.pandemic(args.nt, args.nxi)
@@ -119,7 +124,8 @@ def main():
         "ms": ms, "alg_bytes": bytes_,
         "GBps": {k: (bytes_[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else None) for k in ms},
     }
-    print(json.dumps(out))
+    gm.close()
+    return out
 
 
 if __name__ == "__main__":
