@@ -298,6 +298,7 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
       Node &nd = t.nodes[n];
       nd.op = (int)*p++; nd.a = (int)*p++; nd.b = (int)*p++; nd.imm = w2d(*p++);
       bool bin = IEM_OP_IS_BINARY(nd.op), un = IEM_OP_IS_UNARY(nd.op);
+      if (!bin && !un && (nd.op < IEM_OP_CONST || nd.op > IEM_OP_VAR)) throw std::runtime_error("unknown opcode " + std::to_string(nd.op));
       if ((bin || un) && (nd.a < 0 || nd.a >= n)) throw std::runtime_error("node child out of order");
       if (bin && (nd.b < 0 || nd.b >= n)) throw std::runtime_error("node child out of order");
       if ((nd.op == IEM_OP_VAR || nd.op == IEM_OP_PAR) && (nd.a < 0 || nd.a >= n_idx)) throw std::runtime_error("node index id out of range");
