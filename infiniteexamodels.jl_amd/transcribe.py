@@ -50,7 +50,7 @@ class ExaMappingData:
         self.param_alias: Dict[VariableRef, str] = {}
         self.group_alias: List[str] = []
         self.base_itrs: List[Items] = []
-        self.support_to_index: Dict[Tuple[int, tuple], int] = {}
+        self.support_to_index = _SupportIndex()
         self.semivar_info: Dict[VariableRef, tuple] = {}
         self.has_internal_supps: List[bool] = []
         self.support_labels: List[list] = []
@@ -65,6 +65,50 @@ def _supp_key(values) -> tuple:
     return tuple(float(v) for v in np.atleast_1d(values))
 
 
+class _SupportIndex:
+    """``(group index, support tuple) -> 1-based support index`` (``data.support_to_index`` of the
+    reference, a Dict filled support by support at transform.jl:24-29).  Looked up lazily: point
+    and semi-infinite variables ask for a handful of supports, a 10^6-entry Python dict per group
+    costs seconds.  Small groups are turned into a dict on first use, large ones are searched
+    with one vectorised comparison per (memoised) query."""
+
+    def __init__(self):
+        self._supports: Dict[int, np.ndarray] = {}
+        self._dicts: Dict[int, dict] = {}
+        self._memo: Dict[tuple, Optional[int]] = {}
+
+    def add_group(self, gindex: int, supports: np.ndarray) -> None:
+        self._supports[gindex] = np.asarray(supports, dtype=np.float64).reshape(len(supports), -1)
+
+    def get(self, key, default=None):
+        if key in self._memo:
+            hit = self._memo[key]
+            return default if hit is None else hit
+        g, supp = key
+        S = self._supports.get(g)
+        hit = None
+        if S is not None and len(supp) == S.shape[1]:
+            if S.shape[0] <= 4096:
+                d = self._dicts.get(g)
+                if d is None:
+                    d = self._dicts[g] = {tuple(float(v) for v in row): i + 1 for i, row in enumerate(S)}
+                hit = d.get(tuple(supp))
+            else:
+                rows = np.flatnonzero((S == np.asarray(supp, dtype=np.float64)).all(axis=1))
+                hit = int(rows[-1]) + 1 if rows.size else None      # a Dict keeps the last duplicate
+        self._memo[key] = hit
+        return default if hit is None else hit
+
+    def __getitem__(self, key):
+        hit = self.get(key)
+        if hit is None:
+            raise KeyError(key)
+        return hit
+
+    def __contains__(self, key):
+        return self.get(key) is not None
+
+
 # 1 ---------------------------------------------------------------------------
 def _build_base_iterators(data: ExaMappingData, m: InfiniteModel) -> None:
     raw = 0
@@ -75,8 +119,7 @@ def _build_base_iterators(data: ExaMappingData, m: InfiniteModel) -> None:
             data.param_alias[pref] = f"dp{raw}{pref.pos + 1}" if g.dependent else f"ip{raw}"
         itr_sym = f"group_idx{len(data.group_alias) + 1}"
         data.group_alias.append(itr_sym)
-        for i in range(g.num_supports):
-            data.support_to_index[(g.index, _supp_key(g.supports[i]))] = i + 1
+        data.support_to_index.add_group(g.index, g.supports)
         vals = {data.param_alias[p]: np.ascontiguousarray(g.supports[:, p.pos]) for p in g.prefs}
         data.base_itrs.append(Items.from_supports(itr_sym, g.num_supports, vals, group_id=g.index))
         data.has_internal_supps.append(bool(g.internal is not None and g.internal.any()))   # transform.jl:35
@@ -136,7 +179,10 @@ def _add_finite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel)
 
 
 def _add_infinite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> None:
-    for vref in list(m.infinite_variables) + list(m.derivatives):
+    vrefs = list(m.infinite_variables) + list(m.derivatives)
+    # one allocation for all slabs (the sizes are known before the first add_var)
+    core.reserve_vars(sum(int(np.prod([len(data.base_itrs[g - 1]) for g in v.group_idxs], dtype=np.int64)) for v in vrefs))
+    for vref in vrefs:
         group_idxs = vref.group_idxs
         dims = tuple(len(data.base_itrs[g - 1]) for g in group_idxs)
         lb, ub, start = _get_variable_bounds_and_start(vref.info, m, group_idxs, dims)
