@@ -503,19 +503,20 @@ def collocation_items(pref, base_itr: Items, supps: np.ndarray, internal: np.nda
     Items form the box (j fastest, element): integer fields = node index (the group alias),
     ``d_lb`` (lower-boundary index), ``d_n1..d_nn`` (the element's node indices); float fields
     ``d_arg1..d_argn`` = column j of Minvᵀ."""
+    cache = data.__dict__.setdefault("_collocation_items", {})
+    if pref in cache:                                       # every derivative w.r.t. `pref` shares the iterator
+        return cache[pref]
     n_tot = len(supps)
     lb_idx = np.nonzero(~internal)[0][:-1]                 # 0-based lower boundaries
     n = int(lb_idx[1] - lb_idx[0]) if len(lb_idx) > 1 else n_tot - 1
     assert np.all(np.diff(lb_idx) == n) and lb_idx[-1] + n == n_tot - 1
     ne = len(lb_idx)
-    coef = np.zeros((ne, n, n))                             # [element, j, k]
-    for e, L in enumerate(lb_idx):
-        tau = supps[L + 1:L + 1 + n] - supps[L]
-        kk = np.arange(1, n + 1)[:, None]
-        M1t = kk * tau[None, :] ** (kk - 1)
-        M2t = tau[None, :] ** kk
-        Minvt = np.linalg.solve(M1t, M2t)                   # [k, j]
-        coef[e] = Minvt.T
+    # all elements at once (batched LAPACK solve): [element, k, j]
+    tau = supps[lb_idx[:, None] + 1 + np.arange(n)[None, :]] - supps[lb_idx][:, None]
+    kk = np.arange(1, n + 1)[None, :, None]
+    M1t = kk * tau[:, None, :] ** (kk - 1)
+    M2t = tau[:, None, :] ** kk
+    coef = np.ascontiguousarray(np.linalg.solve(M1t, M2t).transpose(0, 2, 1))   # [element, j, k]
     alias = data.group_alias[pref.group.index - 1]
     p_alias = data.param_alias[pref]
     fields = {
@@ -528,7 +529,8 @@ def collocation_items(pref, base_itr: Items, supps: np.ndarray, internal: np.nda
         fields[f"d_arg{k + 1}"] = Field("float", "gather", 0, (1, n), np.ascontiguousarray(coef[:, :, k].reshape(-1)))
     # a virtual grid shared by every collocation template of this parameter → one fused kernel
     gi = pref.group.index
-    return Items((n, ne), fields, grid=((1000 + gi, 2000 + gi), (0, 0)))
+    cache[pref] = Items((n, ne), fields, grid=((1000 + gi, 2000 + gi), (0, 0)))
+    return cache[pref]
 
 
 def make_indexed_derivative_expr(dref, vref, pref, idx, data_src, data, method: tuple, d_args):
