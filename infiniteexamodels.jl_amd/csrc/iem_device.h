@@ -207,7 +207,8 @@ __device__ __forceinline__ void iem_block_partial(double v, double *__restrict__
     double tot = lds4[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) tot += lds4[w];
-    out[0] = tot;
+    // system scope: `out` may be mapped host memory that iem_obj polls for the value
+    __hip_atomic_store(out, tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
