@@ -467,6 +467,8 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "no_fuse") == 0) { g_opt.no_fuse = (int)value; return IEM_OK; }
   if (std::strcmp(name, "poll_obj") == 0) { g_opt_poll_obj = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "overlap") == 0) { g_opt.overlap = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "xcd_remap") == 0) { g_opt.xcd_remap = (int)value; return IEM_OK; }
   if (std::strcmp(name, "split_small") == 0) { g_opt.split_small = (int)value; return IEM_OK; }
   if (std::strcmp(name, "fuse_groups") == 0) { g_opt.fuse_groups = (int)value; return IEM_OK; }
   if (std::strcmp(name, "fuse_zero") == 0) { g_opt.fuse_zero = (int)value; return IEM_OK; }

@@ -1068,7 +1068,8 @@ class KernelBuilder {
             fl << "    const int v1 = " << (any ? "(" + gb.str() + ") ? " : "") << "iem_clamp256(" << ip(std::min(o.qhi[0], g_.ext[0])) << " - qb0)"
                << (any ? " : v0" : "") << ";\n";
             }
-            fl << "    iem_flush<" << ns << ">(OUT, pb, v0, v1, lds_blk + " << (batch_slots * opt_.block) << "); }\n";
+            fl << "    iem_flush<" << ns << ", " << qstep_str() << ">(OUT, pb, v0, v1, qb0 <= " << coefstr(g_.flat ? 0 : o.qlo[0]) << ", lds_blk + "
+               << (batch_slots * opt_.block) << "); }\n";
             pending_flush.push_back(fl.str());
             batch_slots += ns;
             break;
@@ -1112,12 +1113,12 @@ class KernelBuilder {
       head << "  }\n";
     }
     if (g_.flat) {
-      head << "  const long long q = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
+      head << "  const long long q = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
       head << "  const bool inb = q < " << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << ";\n";
       head << "  const long long q0 = q % " << ip(g_.ext[0]) << ", qr = q / " << ip(g_.ext[0]) << ";\n";
       head << "  const long long q1 = qr % " << ip(g_.ext[1]) << ", q2 = qr / " << ip(g_.ext[1]) << ";\n";
     } else {
-    head << "  const long long q0 = (long long)blockIdx.x * IEM_TILE + threadIdx.x;\n";
+    head << "  const long long q0 = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
     if (g_.nd == 2 && g_.ext[1] > 65535) {
       // second grid dimension longer than gridDim.y allows: fold it over blockIdx.z
       head << "  const long long q1 = (long long)blockIdx.y + (long long)gridDim.y * blockIdx.z, q2 = 0;\n";
@@ -1202,6 +1203,11 @@ class KernelBuilder {
     os << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; (void)AUX;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
+    if (opt_.xcd_remap) {
+      os << "  const long long GX_ = gridDim.x, GY_ = gridDim.y, GZ_ = gridDim.z;\n"
+         << "  const long long L_ = iem_xcd_remap((long long)blockIdx.x + GX_ * ((long long)blockIdx.y + GY_ * (long long)blockIdx.z), GX_ * GY_ * GZ_);\n"
+         << "  const long long BX_ = L_ % GX_, BY_ = (L_ / GX_) % GY_, BZ_ = L_ / (GX_ * GY_); (void)BY_; (void)BZ_; (void)GZ_;\n";
+    }
     }
     if (use_lds) {
       if (as_body) os << "  double* lds_all = lds_blk;\n";
@@ -1212,16 +1218,18 @@ class KernelBuilder {
     if (use_blk) {
       const int budget = stage_budget(max_ns);
       if (!as_body) os << "  __shared__ double lds_blk[" << (opt_.block * budget) << "];\n";
-      os << "  const long long qb0 = (long long)blockIdx.x * IEM_TILE;\n";
+      os << "  const long long qb0 = (long long)blockIdx.x * " << qstep_str() << ";\n";
       kd.lds_bytes = opt_.block * budget * 8;
     }
     if (kind_ == KK_OBJ && !as_body) os << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
     os << head.str() << tail.str() << "}\n\n";
-    if (as_body) {
-      // the body sees the workgroup coordinates of ITS OWN grid, decoded by the wrapper
+    if (as_body || opt_.xcd_remap) {
+      // the body sees LOGICAL workgroup coordinates: of its own grid, decoded by the wrapper
+      // (as_body), and/or remapped so that neighbours share an XCD (xcd_remap)
       std::string t = os.str();
+      const size_t keep = as_body ? 0 : t.find("(void)GZ_;\n");   // the remap prologue itself reads the hardware ids
       auto subst = [&](const std::string &from, const std::string &to) {
-        for (size_t pos = 0; (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
+        for (size_t pos = keep; (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
       };
       subst("blockIdx.x", "BX_"); subst("blockIdx.y", "BY_"); subst("blockIdx.z", "BZ_");
       subst("gridDim.x", "GX_"); subst("gridDim.y", "GY_"); subst("gridDim.z", "GZ_");
@@ -1234,6 +1242,15 @@ class KernelBuilder {
 
   // values per lane staged per barrier pair: `lds_slots` is quoted for 256-thread workgroups
   // (2 KB of LDS per slot) and scaled so the LDS per workgroup stays the same for other sizes
+  // Grid points per workgroup along the first dimension.  Kernels that write COO / row blocks
+  // through the block store overlap their tiles by 16 lanes: the halo items are computed twice so
+  // that every 128-byte line of a block is written WHOLE by one workgroup (iem_flush), instead
+  // of two workgroups each writing a part of the line at every seam.
+  int qstep() const {
+    const bool blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD) && opt_.store_mode == 2;
+    return (blk && opt_.overlap && opt_.block >= 256) ? opt_.block - 16 : opt_.block;
+  }
+  std::string qstep_str() const { return qstep() == opt_.block ? "IEM_TILE" : "(IEM_TILE - 16)"; }
   void set_n_partials(int64_t n) { n_partials_ = n; }
   void set_zero_fill(const std::vector<std::pair<int64_t, int64_t>> &ranges) { zero_fill_ = ranges; }
 
@@ -1460,8 +1477,9 @@ Program generate(const Model &m, const Options &opt) {
       kd.name = name;
       kd.kind = kind;
       kd.block = opt.block;
-      kd.grid[0] = (g.ext[0] + opt.block - 1) / opt.block; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
-      if (g.flat) { kd.grid[0] = (g.ext[0] * g.ext[1] * g.ext[2] + opt.block - 1) / opt.block; kd.grid[1] = kd.grid[2] = 1; }
+      const int64_t qs = kb->qstep();
+      kd.grid[0] = (g.ext[0] + qs - 1) / qs; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
+      if (g.flat) { kd.grid[0] = (g.ext[0] * g.ext[1] * g.ext[2] + qs - 1) / qs; kd.grid[1] = kd.grid[2] = 1; }
       if (!g.flat && g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
       kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
       if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
@@ -1614,7 +1632,8 @@ Program generate(const Model &m, const Options &opt) {
       const size_t e = dec + 4 * j;
       src << "  " << (j ? "else " : "");
       if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
-      src << "{\n    const long long lb = b - A.ip[" << e << "], gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
+      src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
+          << "    const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
           << "    " << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
           << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n  }\n";
     }

@@ -34,6 +34,17 @@
 __device__ __forceinline__ int iem_lane() { return (int)(threadIdx.x & (IEM_WAVE - 1)); }
 __device__ __forceinline__ int iem_wave() { return (int)(threadIdx.x >> 6); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one; observed, not promised).
+// Optional map (generator knob xcd_remap, default off) from hardware workgroup b to a logical
+// workgroup L such that CONSECUTIVE logical workgroups run on the same XCD.  Tried so that the two
+// partial writes of the 128-byte line at a block seam would merge in one L2: they do not
+// (profiles/r01_ab_overlap_xcd.txt: -1.5 %); the overlapped tiles of iem_flush remove the partial
+// lines instead.  Bijective for any nb.
+__device__ __forceinline__ long long iem_xcd_remap(long long b, long long nb) {
+  const long long p = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+  return x * p + (x < r ? x : r) + i;
+}
+
 // order LDS traffic of one wave: LDS executes a wave's instructions in issue order, so a
 // compiler-level fence plus lgkmcnt(0) is enough; no workgroup barrier.
 __device__ __forceinline__ void iem_wave_lds_sync() {
@@ -127,18 +138,32 @@ __device__ __forceinline__ void iem_stage(const double (&v)[NS], double *__restr
   for (int s = 0; s < NS; ++s) lds_reg[t * NS + s] = v[s];
 }
 
-template <int NS>
-__device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0, int v0, int v1,
+// P0 = position of lane 0 / slot 0 (virtual when the template's row starts inside the tile);
+// [v0, v1) = lanes of the tile that hold items of the template; `first` = the row's first item
+// is at or behind lane 0.  STRIDE = grid points per workgroup: with STRIDE = IEM_TILE - 16 the
+// tiles overlap by 16 lanes (the halo items are computed by both neighbours) and a workgroup
+// writes exactly the 128-byte lines that START inside its own STRIDE lanes — whole lines only,
+// except at the two ends of the row.  STRIDE = IEM_TILE: disjoint tiles, a partial line at
+// every seam (two workgroups write the two parts; costs ~10 % of the store rate).
+template <int NS, int STRIDE>
+__device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0, int v0, int v1, bool first,
                                           const double *__restrict__ lds_reg) {
   const int t = (int)threadIdx.x;
-  const int e0 = v0 * NS, e1 = v1 * NS;  // valid element interval of the workgroup's block
-  const int head = (int)((16 - ((P0 + e0) & 15)) & 15);
-  double *__restrict__ dst = out + P0;
-  if (t < head && e0 + t < e1) iem_stg(dst + e0 + t, lds_reg[e0 + t]);
+  const long long lo = P0 + (long long)v0 * NS, hi_all = P0 + (long long)v1 * NS;
+  long long own_lo = lo, own_hi = hi_all;
+  if (STRIDE < IEM_TILE) {
+    if (v0 >= STRIDE) return;   // the row starts in the halo: the next workgroup owns all of it
+    const int vu = v1 < STRIDE ? v1 : STRIDE;
+    const long long hi_u = P0 + (long long)vu * NS;   // end of the lanes only this workgroup computes
+    if (!first) own_lo = (lo + 15) & ~15LL;
+    own_hi = (hi_u + 15) & ~15LL;
+    if (own_hi > hi_all) own_hi = hi_all;
+  }
+  const long long e_al = own_lo & ~15LL;
 #pragma unroll
-  for (int j = 0; j < NS; ++j) {
-    const int e = e0 + head + t + j * IEM_TILE;
-    if (e < e1) iem_stg(dst + e, lds_reg[e]);
+  for (int j = 0; j <= NS; ++j) {
+    const long long e = e_al + t + (long long)j * IEM_TILE;
+    if (e >= own_lo && e < own_hi) iem_stg(out + e, lds_reg[e - P0]);
   }
 }
 
@@ -147,7 +172,7 @@ __device__ __forceinline__ void iem_store_block(double *__restrict__ out, long l
                                                 const double (&v)[NS], double *__restrict__ lds_blk) {
   iem_stage<NS>(v, lds_blk);
   __syncthreads();
-  iem_flush<NS>(out, P0, v0, v1, lds_blk);
+  iem_flush<NS, IEM_TILE>(out, P0, v0, v1, true, lds_blk);
   __syncthreads();
 }
 

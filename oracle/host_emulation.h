@@ -23,6 +23,10 @@
 struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };
 static thread_local emu_dim3 threadIdx, blockIdx, gridDim;
 
+inline long long iem_xcd_remap(long long b, long long nb) {
+  const long long p = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+  return x * p + (x < r ? x : r) + i;
+}
 inline int iem_lane() { return (int)(threadIdx.x & 63); }
 inline int iem_wave() { return (int)(threadIdx.x >> 6); }
 
@@ -46,10 +50,24 @@ inline void iem_stage(const double (&v)[NS], double *lds_reg) {
   const int t = (int)threadIdx.x;
   for (int s = 0; s < NS; ++s) lds_reg[t * NS + s] = v[s];
 }
-template <int NS>
-inline void iem_flush(double *out, long long P0, int v0, int v1, const double *lds_reg) {
+// same ownership rule as the device version (which lines a workgroup writes), lane by lane
+template <int NS, int STRIDE>
+inline void iem_flush(double *out, long long P0, int v0, int v1, bool first, const double *lds_reg) {
   const int t = (int)threadIdx.x;
-  if (t >= v0 && t < v1) for (int s = 0; s < NS; ++s) out[P0 + (long long)t * NS + s] = lds_reg[t * NS + s];
+  const long long lo = P0 + (long long)v0 * NS, hi_all = P0 + (long long)v1 * NS;
+  long long own_lo = lo, own_hi = hi_all;
+  if (STRIDE < IEM_TILE) {
+    if (v0 >= STRIDE) return;
+    const int vu = v1 < STRIDE ? v1 : STRIDE;
+    if (!first) own_lo = (lo + 15) & ~15LL;
+    own_hi = (P0 + (long long)vu * NS + 15) & ~15LL;
+    if (own_hi > hi_all) own_hi = hi_all;
+  }
+  if (t < v0 || t >= v1) return;
+  for (int s = 0; s < NS; ++s) {
+    const long long e = P0 + (long long)t * NS + s;
+    if (e >= own_lo && e < own_hi) out[e] = lds_reg[t * NS + s];
+  }
 }
 inline void __syncthreads() {}
 inline void iem_block_partial(double v, double *partials, long long slot, double *, long long n, double *out) {
