@@ -1,4 +1,5 @@
 mkdir -p gpurun_out
+# A/B recipe behind profiles/r01_ab_small_grids.txt: lane-fused vs templates side by side, 16k..512k supports (run through gpurun).
 for wl in quadrotor opf quadrotor_oc3 pandemic; do
 for n in 16000 32000 64000 128000 256000 512000; do
 for mode in "fuse_groups=1" "no_fuse=1 --opt fuse_groups=2"; do
