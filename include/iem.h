@@ -132,11 +132,22 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt);
 int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t **out_rows, int64_t **out_cols, int64_t *out_nnz);
 void iem_free(void *p);
 
-/* knobs (set BEFORE iem_create / iem_emit_*): "store_mode" 0 direct strided stores, 1 wave-level
- * LDS-transposed stores, 2 (default) workgroup-staged 128-B-aligned stores; "nt_stores";
- * "block" (workgroup size); "lds_slots"; "fp_contract"; "hess_merge" = 1 selects the opt-in
- * MERGED Hessian layout (duplicate (row,col) slots of one support summed in registers: fewer
- * nnzh, not ExaModels' COO layout — hess_structure!/hess_coord! stay mutually consistent). */
+/* knobs (process-global; set BEFORE iem_create / iem_emit_*; defaults in csrc/iem_codegen.hpp):
+ *   "store_mode"   0 direct strided stores, 1 wave-level LDS-transposed stores, 2 (default)
+ *                  workgroup-staged stores re-cut at 128-byte lines
+ *   "overlap"      1 (default): block-store kernels overlap their tiles by 16 lanes so that every
+ *                  128-byte line is written whole by one workgroup
+ *   "nt_stores", "block" (workgroup size, default 512), "lds_slots", "reorder", "min_waves"
+ *   "fp_contract"  0 (default): no FMA contraction — bit-comparable with the CPU oracle
+ *   "split_small"  support grids of at most this many workgroups (default 64) run their templates
+ *                  side by side in one launch instead of fused lane-wise (0: never)
+ *   "fuse_groups"  1 (default): one launch per call even across several support grids
+ *   "fuse_zero"    1 (default): scatter kernels zero untouched output entries themselves
+ *   "poll_obj"     1 (default): iem_obj polls the mapped host scalar instead of a stream sync
+ *   "xcd_remap"    0 (default); "no_fuse", "ablate": experiments / baselines only
+ *   "hess_merge"   1 selects the opt-in MERGED Hessian layout (duplicate (row,col) slots of one
+ *                  support summed in registers: fewer nnzh, not ExaModels' COO layout —
+ *                  hess_structure!/hess_coord! stay mutually consistent). */
 int iem_set_option(const char *name, int64_t value);
 
 /* per-kernel timing of the last jac/hess call pair, measured with HIP events on the
