@@ -19,3 +19,14 @@ for rep in range(2):
     for i in range(6):
         ms_j, ms_h = gm.time_kernels(xd, yd, jb[i], hb[i], iters=50)
         print(f"rep {rep} buffer {i}: jac {ms_j:.4f} ms @ {hex(jb[i].data_ptr())}   hess {ms_h:.4f} ms @ {hex(hb[i].data_ptr())}", flush=True)
+
+# second experiment: six output windows inside ONE allocation
+del jb, hb
+torch.cuda.empty_cache()
+stride = ((gm.meta.nnzj * 8 + (1 << 21) - 1) >> 21 << 21) // 8
+arena = torch.empty(6 * stride, dtype=torch.float64, device="cuda")
+hbuf = torch.empty(gm.meta.nnzh, dtype=torch.float64, device="cuda")
+for i in range(6):
+    j = arena[i * stride:i * stride + gm.meta.nnzj]
+    ms_j, ms_h = gm.time_kernels(xd, yd, j, hbuf, iters=50)
+    print(f"one arena, window {i}: jac {ms_j:.4f} ms @ {hex(j.data_ptr())}", flush=True)
