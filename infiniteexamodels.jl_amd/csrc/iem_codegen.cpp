@@ -1355,6 +1355,11 @@ std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)>
       int64_t v = groups[i].ext[0] * groups[i].ext[1] * groups[i].ext[2];
       if (v > vol) { vol = v; best = i; }
     }
+    if (vol <= 0) {   // every grid is empty (templates without items): the scalars need a launch of their own
+      groups.emplace_back();
+      best = groups.size() - 1;
+      groups[best].grid_id = 0;
+    }
     groups[best].scalars = scalars;
   }
   return groups;
