@@ -62,6 +62,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise IemError(f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the evaluation path)")
+    # One HIP runtime per process: torch (this binding's device-memory provider) ships its own
+    # libamdhip64; if libiem_hip.so pulled in the system one FIRST, the two runtimes coexist and
+    # the second to initialise sees no device.  Loading torch first makes libiem_hip bind to the
+    # runtime torch already loaded (same SONAME).  C / Julia hosts link one runtime and are not
+    # affected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
     L.iem_last_error.restype = C.c_char_p
