@@ -130,6 +130,9 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt);
 /* Hessian structure of a blob under the current options, computed on the host (tooling/tests;
  * arrays are malloc'ed, release with iem_free). */
 int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t **out_rows, int64_t **out_cols, int64_t *out_nnz);
+/* values of model array `id` as the library sees it after parsing — including the float columns it
+ * synthesises when it recovers a product lattice from a flat iterator (tooling/tests; malloc'ed) */
+int iem_blob_array(const void *blob, size_t nbytes, int id, double **out_vals, int64_t *out_n);
 void iem_free(void *p);
 
 /* knobs (process-global; set BEFORE iem_create / iem_emit_*; defaults in csrc/iem_codegen.hpp):

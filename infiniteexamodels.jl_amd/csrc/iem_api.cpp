@@ -532,6 +532,22 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
   }
 }
 
+int iem_blob_array(const void *blob, size_t nbytes, int id, double **out_vals, int64_t *out_n) {
+  if (!out_vals || !out_n) return fail(IEM_E_ARG, "null argument");
+  try {
+    iem::Model model;
+    iem::parse_blob(blob, nbytes, model);
+    if (id < 0 || id >= (int)model.arrs.size()) return fail(IEM_E_ARG, "array id out of range");
+    const iem::ArrayDesc &a = model.arrs[id];
+    double *v = (double *)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(a.n, 1));
+    for (int64_t j = 0; j < a.n; ++j) v[j] = a.f(j);
+    *out_vals = v; *out_n = a.n;
+    return IEM_OK;
+  } catch (const std::exception &e) {
+    return fail(IEM_E_BLOB, e.what());
+  }
+}
+
 int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t **out_rows, int64_t **out_cols, int64_t *out_nnz) {
   try {
     iem::Model model;

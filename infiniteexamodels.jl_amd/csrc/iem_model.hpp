@@ -17,6 +17,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../include/iem_blob.h"
@@ -94,6 +95,7 @@ struct Model {
   int arr_x0 = 0, arr_lvar = 0, arr_uvar = 0, arr_theta = 0;
   std::vector<ArrayDesc> arrs;
   std::vector<Template> tpl;
+  std::deque<std::vector<double>> synth;  // arrays created by recover_lattice (ArrayDesc::data points here)
 };
 
 inline double w2d(int64_t w) {
@@ -191,6 +193,84 @@ inline void analyse_template(Template &t) {
     t.comp2.push_back(s);
   }
   t.o2step = (int)t.slot2_i.size();
+}
+
+// A foreign producer (the Julia writer) sees a template's iterator as a flat list of records and
+// writes one explicit column per item field.  When the iterator was an Iterators.product of two
+// support sets (transform.jl:445: pandemic's t x xi), every integer column is affine on the
+// n0 x n1 lattice  k = k0 + n0*k1  and most float columns depend on one coordinate only.  This
+// pass recovers that structure: the template becomes a 2-D box with affine integer fields (no index
+// column is read at run time), float columns shrink to n0 or n1 values, and the template joins the
+// lane-fused kernel of its grid.  Item order — hence every COO position — is unchanged.
+inline void recover_lattice(Model &m, Template &t) {
+  if (t.nd != 1 || t.n_items < 4) return;
+  const int64_t n = t.n_items;
+  auto ival = [&](const FieldDesc &f, int64_t k) {
+    return f.mode == IEM_F_AFFINE ? f.base + f.step[0] * k : m.arrs[f.arr].i(f.base + f.step[0] * k);
+  };
+  auto fval = [&](const FieldDesc &f, int64_t k) { return m.arrs[f.arr].f(f.base + f.step[0] * k); };
+  int64_t n0 = 0;
+  for (const FieldDesc &f : t.ifields) {
+    if (f.mode != IEM_F_GATHER) continue;
+    const int64_t v0 = ival(f, 0), a = ival(f, 1) - v0;
+    for (int64_t k = 2; k < n; ++k)
+      if (ival(f, k) != v0 + a * k) { n0 = k; break; }
+    if (n0) break;
+  }
+  if (n0 < 2 || n % n0 != 0 || n / n0 < 2) return;
+  const int64_t n1 = n / n0;
+  std::vector<FieldDesc> nif(t.ifields.size());
+  int coord[2] = {-1, -1};
+  for (size_t i = 0; i < t.ifields.size(); ++i) {
+    const FieldDesc &f = t.ifields[i];
+    const int64_t v0 = ival(f, 0), a = ival(f, 1) - v0, b = ival(f, n0) - v0;
+    for (int64_t k = 0; k < n; ++k)
+      if (ival(f, k) != v0 + a * (k % n0) + b * (k / n0)) return;   // not a lattice: leave the template alone
+    nif[i].mode = IEM_F_AFFINE; nif[i].base = v0; nif[i].step[0] = a; nif[i].step[1] = b; nif[i].step[2] = 0; nif[i].arr = -1;
+    if (a == 1 && b == 0 && coord[0] < 0) coord[0] = (int)i;
+    if (a == 0 && b == 1 && coord[1] < 0) coord[1] = (int)i;
+  }
+  std::vector<FieldDesc> nff(t.ffields.size());
+  std::vector<std::pair<size_t, std::vector<double>>> fresh;   // (ffield, new array) — committed only on success
+  for (size_t i = 0; i < t.ffields.size(); ++i) {
+    const FieldDesc &f = t.ffields[i];
+    bool only0 = true, only1 = true;
+    for (int64_t k = 0; k < n && (only0 || only1); ++k) {
+      const double v = fval(f, k);
+      uint64_t bv, b0, b1;
+      const double v0 = fval(f, k % n0), v1 = fval(f, (k / n0) * n0);
+      std::memcpy(&bv, &v, 8); std::memcpy(&b0, &v0, 8); std::memcpy(&b1, &v1, 8);
+      if (bv != b0) only0 = false;
+      if (bv != b1) only1 = false;
+    }
+    nff[i] = f;
+    if (only0 || only1) {
+      std::vector<double> a(only0 ? n0 : n1);
+      for (int64_t j = 0; j < (int64_t)a.size(); ++j) a[j] = fval(f, only0 ? j : j * n0);
+      nff[i].base = 0; nff[i].step[0] = only0 ? 1 : 0; nff[i].step[1] = only0 ? 0 : 1; nff[i].step[2] = 0;
+      fresh.emplace_back(i, std::move(a));
+    } else {
+      nff[i].step[1] = f.step[0] * n0;
+    }
+  }
+  for (auto &pr : fresh) {
+    m.synth.push_back(std::move(pr.second));
+    ArrayDesc a;
+    a.kind = IEM_A_F64_DATA; a.n = (int64_t)m.synth.back().size(); a.data = m.synth.back().data();
+    nff[pr.first].arr = (int)m.arrs.size();
+    m.arrs.push_back(a);
+  }
+  t.ifields = nif; t.ffields = nff;
+  t.nd = 2; t.dims[0] = n0; t.dims[1] = n1; t.dims[2] = 1;
+  if (coord[0] >= 0 && coord[1] >= 0) {   // both grid coordinates are item fields: fusable on the recovered grid
+    t.grid_id = 2 * 4096 + 1;
+    t.origin[0] = nif[coord[0]].base - 1; t.origin[1] = nif[coord[1]].base - 1; t.origin[2] = 0;
+  } else {
+    // no coordinate fields (collocation rows: node/element boxes): templates over the same n0 x n1
+    // box share lanes from its corner — a scheduling hint only, like every grid id
+    t.grid_id = 3 * 4096 + 1 + (n0 & 1023);
+    t.origin[0] = t.origin[1] = t.origin[2] = 0;
+  }
 }
 
 inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
@@ -305,6 +385,7 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
       if (nd.op == IEM_OP_DATA && (nd.a < 0 || nd.a >= n_ff)) throw std::runtime_error("node field id out of range");
     }
     if (t.root < 0 || t.root >= n_nodes) throw std::runtime_error("bad root");
+    recover_lattice(m, t);
     analyse_template(t);
     t.o2 = o2; o2 += t.n_items * t.o2step;
     if (o2 > IEM_MAX_COUNT * 64 || o1 > IEM_MAX_COUNT * 64) throw std::runtime_error("nnz out of range");

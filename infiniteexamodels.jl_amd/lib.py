@@ -41,7 +41,7 @@ class KernelInfo(C.Structure):
 SYMBOLS = ["iem_create", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_last_error", "iem_version"]
 
 
@@ -161,6 +161,20 @@ def emit_launch_plan(blob: bytes) -> str:
     check(L.iem_emit_launch_plan(blob, len(blob), C.byref(p)))
     try:
         return C.string_at(p).decode()
+    finally:
+        L.iem_free(p)
+
+
+def blob_array(blob: bytes, array_id: int):
+    """Model array `array_id` as the library holds it after parsing (float64), including arrays it
+    synthesised itself (lattice recovery).  Tooling/tests."""
+    import numpy as np
+    L = lib()
+    L.iem_blob_array.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    p, n = C.c_void_p(), C.c_int64()
+    check(L.iem_blob_array(blob, len(blob), int(array_id), C.byref(p), C.byref(n)))
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(max(n.value, 1),))[:n.value].copy()
     finally:
         L.iem_free(p)
 
