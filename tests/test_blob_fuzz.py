@@ -17,7 +17,7 @@ from infiniteexamodels.jl_amd import lib as L
 rng = np.random.default_rng(11)
 ok = rej = 0
 for name in fg.NAMES:
-    w = np.frombuffer(cases.build_core(name).to_blob(), dtype=np.int64).copy()
+    w = np.frombuffer(fg.blob_of(name), dtype=np.int64).copy()
     for v in fg.mutations(w, rng, 40):
         b = v.tobytes()
         try:
@@ -30,12 +30,12 @@ for name in fg.NAMES:
             L.emit_source(w.tobytes()[:cut]); ok += 1
         except L.IemError:
             rej += 1
-print("FUZZ", ok, rej)
+print("FUZZ", len(fg.NAMES), ok, rej)
 """
 
 
 def test_mutated_blobs_never_crash_the_host():
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"child died ({r.returncode}):\n{r.stderr[-2000:]}"
-    ok, rej = (int(v) for v in r.stdout.strip().split()[-2:])
-    assert rej > 50 and ok + rej == 7 * 44
+    len_names, ok, rej = (int(v) for v in r.stdout.strip().split()[-3:])
+    assert rej > 50 and ok + rej == len_names * 44

@@ -10,7 +10,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 
-NAMES = ["quadrotor_5", "pandemic_20x3", "farmer_5", "opf_7", "operator_zoo", "irregular", "quadrotor_oc3_40"]
+NAMES = ["quadrotor_5", "pandemic_20x3", "farmer_5", "opf_7", "operator_zoo", "irregular", "quadrotor_oc3_40",
+         "foreign:pandemic_20x3", "foreign:quadrotor_oc3_40"]      # flat explicit iterators: exercises the lattice recovery
+
+
+def blob_of(name):
+    import cases
+    if name.startswith("foreign:"):
+        from test_foreign_producer import foreign_blob
+        return foreign_blob(cases.build_core(name.split(":", 1)[1]))[1]
+    return cases.build_core(name).to_blob()
 
 
 def mutations(words, rng, n):
@@ -36,14 +45,13 @@ def mutations(words, rng, n):
 
 
 def main():
-    import cases
     seed, n, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.makedirs(out, exist_ok=True)
     rng = np.random.default_rng(seed)
     for name in NAMES:
-        w = np.frombuffer(cases.build_core(name).to_blob(), dtype=np.int64).copy()
+        w = np.frombuffer(blob_of(name), dtype=np.int64).copy()
         for i, v in enumerate(mutations(w, rng, n)):
-            v.tofile(os.path.join(out, f"{name}_{i:04d}.bin"))
+            v.tofile(os.path.join(out, f"{name.replace(':', '_')}_{i:04d}.bin"))
 
 
 if __name__ == "__main__":
