@@ -36,8 +36,8 @@ template <class F> double timeit(F f, int iters) {
   hipEventRecord(a); for (int i = 0; i < iters; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); return ms / iters;
 }
-int main() {
-  const long n = 64L * 1000 * 1000;  // 512 MB of doubles
+int main(int argc, char** argv) {
+  const long n = (argc > 1 ? atol(argv[1]) : 64L) * 1000 * 1000;  // millions of doubles (default 512 MB)
   double *p, *q; CK(hipMalloc(&p, n * 8)); CK(hipMalloc(&q, n * 8)); CK(hipMemset(p, 0, n * 8)); CK(hipMemset(q, 0, n * 8));
   long g = (n + 255) / 256, g2 = (n / 2 + 255) / 256;
   auto rep = [&](const char* name, double ms, double bytes) { printf("%-12s %8.4f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); };
