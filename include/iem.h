@@ -147,7 +147,8 @@ void iem_free(void *p);
  *   "fuse_groups"  1 (default): one launch per call even across several support grids
  *   "fuse_zero"    1 (default): scatter kernels zero untouched output entries themselves
  *   "poll_obj"     1 (default): iem_obj polls the mapped host scalar instead of a stream sync
- *   "xcd_remap"    0 (default); "no_fuse", "ablate": experiments / baselines only
+ *   "xcd_remap", "wide_stores" (16-byte block stores): 0 (default), measured no gain;
+ *   "no_fuse", "ablate": experiments / baselines only
  *   "hess_merge"   1 selects the opt-in MERGED Hessian layout (duplicate (row,col) slots of one
  *                  support summed in registers: fewer nnzh, not ExaModels' COO layout —
  *                  hess_structure!/hess_coord! stay mutually consistent). */

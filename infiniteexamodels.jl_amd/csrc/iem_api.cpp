@@ -69,6 +69,7 @@ std::string full_source(const iem::Program &p) {
   s += "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += std::string("#define IEM_NT ") + (g_opt.nt_stores ? "1" : "0") + "\n";
   s += "#define IEM_TILE " + std::to_string(g_opt.block) + "\n";
+  s += std::string("#define IEM_WIDE_STORES ") + (g_opt.wide_stores ? "1" : "0") + "\n";
   if (g_opt.ablate) s += "#define IEM_ABLATE " + std::to_string(g_opt.ablate & 1) + "  // timing experiment, results are wrong\n";
   s += kDeviceHeader;
   s += "\n";
@@ -467,6 +468,7 @@ int iem_set_option(const char *name, int64_t value) {
   if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "no_fuse") == 0) { g_opt.no_fuse = (int)value; return IEM_OK; }
   if (std::strcmp(name, "poll_obj") == 0) { g_opt_poll_obj = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "wide_stores") == 0) { g_opt.wide_stores = (int)value; return IEM_OK; }
   if (std::strcmp(name, "overlap") == 0) { g_opt.overlap = (int)value; return IEM_OK; }
   if (std::strcmp(name, "xcd_remap") == 0) { g_opt.xcd_remap = (int)value; return IEM_OK; }
   if (std::strcmp(name, "split_small") == 0) { g_opt.split_small = (int)value; return IEM_OK; }

@@ -58,11 +58,24 @@ __device__ __forceinline__ void iem_wave_lds_sync() {
 #ifndef IEM_NT
 #define IEM_NT 0
 #endif
+#ifndef IEM_WIDE_STORES
+#define IEM_WIDE_STORES 0
+#endif
 __device__ __forceinline__ void iem_stg(double *p, double v) {
 #if IEM_NT
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
+#endif
+}
+
+typedef double iem_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void iem_stg2(double *p, double a, double b) {   // p 16-byte aligned
+  iem_dbl2 v = {a, b};
+#if IEM_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<iem_dbl2 *>(p));
+#else
+  *reinterpret_cast<iem_dbl2 *>(p) = v;
 #endif
 }
 
@@ -160,11 +173,25 @@ __device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0
     if (own_hi > hi_all) own_hi = hi_all;
   }
   const long long e_al = own_lo & ~15LL;
+#if IEM_WIDE_STORES
+  // 16 bytes per lane (a 16 GB fill runs at 7.0 TB/s with 16-byte stores, 6.6 with 8-byte ones):
+  // lane t owns the element pair (2t, 2t+1) of each 2*TILE-element round; pairs cut by own_lo /
+  // own_hi (only at the two ends of a row) fall back to single stores
+#pragma unroll
+  for (int j = 0; j < (NS + 3) / 2; ++j) {
+    const long long e = e_al + 2 * t + (long long)j * (2 * IEM_TILE);
+    const bool a = e >= own_lo && e < own_hi, b = e + 1 >= own_lo && e + 1 < own_hi;
+    if (a && b) iem_stg2(out + e, lds_reg[e - P0], lds_reg[e + 1 - P0]);
+    else if (a) iem_stg(out + e, lds_reg[e - P0]);
+    else if (b) iem_stg(out + e + 1, lds_reg[e + 1 - P0]);
+  }
+#else
 #pragma unroll
   for (int j = 0; j <= NS; ++j) {
     const long long e = e_al + t + (long long)j * IEM_TILE;
     if (e >= own_lo && e < own_hi) iem_stg(out + e, lds_reg[e - P0]);
   }
+#endif
 }
 
 template <int NS>
