@@ -3,6 +3,8 @@ would feed): random expression trees over the whole operator vocabulary, random 
 expressions (shifted, strided, multi-dimensional, gathered), shared finite variables, item
 data and θ.  For every seed:   oracle ≡ torch autograd   and   generated kernels (host
 emulation) ≡ oracle.  On the GPU the same models run through the C-ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,6 +109,11 @@ def random_core(seed: int) -> ExaCore:
 
 SEEDS = list(range(16))
 BIG_SEEDS = [100, 101, 102, 103]
+# soak runs: IEM_EXTRA_SEEDS="200:260" / IEM_EXTRA_BIG_SEEDS="300:330" widen the sweep (not part of the default suite)
+for _env, _lst in (("IEM_EXTRA_SEEDS", SEEDS), ("IEM_EXTRA_BIG_SEEDS", BIG_SEEDS)):
+    if os.environ.get(_env):
+        _a, _b = (int(v) for v in os.environ[_env].split(":"))
+        _lst.extend(range(_a, _b))
 
 
 @pytest.mark.parametrize("seed", SEEDS)
