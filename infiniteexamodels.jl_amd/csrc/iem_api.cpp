@@ -167,50 +167,63 @@ int upload_array(iem_model *m, int id, bool as_int) {
   return IEM_OK;
 }
 
+// hiprtc build of the model's kernels for the handle's device; stores the code object in the cache
+int jit_compile(iem_model *m, const std::string &src, const std::string &dir, const std::string &path, std::vector<char> &code) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, m->device));
+  std::string arch = prop.gcnArchName;
+  size_t colon = arch.find(':');
+  if (colon != std::string::npos) arch = arch.substr(0, colon);
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "iem_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail(IEM_E_COMPILE, "hiprtcCreateProgram failed");
+  std::string archopt = "--offload-arch=" + arch;
+  std::string cflag = contract_flag();
+  const char *opts[] = {archopt.c_str(), "-O3", cflag.c_str(), "-std=c++17"};
+  hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    return fail(IEM_E_COMPILE, "hiprtc: " + log);
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code.resize(n);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  m->jit = true;
+  mkdir(dir.c_str(), 0755);
+  // several ranks may compile the same key at once: private temp name, atomic rename
+  const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
+  std::ofstream f(tmp, std::ios::binary);
+  if (f) {
+    f.write(code.data(), (std::streamsize)code.size());
+    f.close();
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+  }
+  return IEM_OK;
+}
+
 int compile_or_load(iem_model *m) {
   const std::string src = full_source(m->prog);
   const uint64_t key = iem::fnv1a64(src);
   const std::string dir = cache_dir();
   const std::string path = dir + "/iem_" + key_hex(key) + ".hsaco";
   std::vector<char> code;
-  if (!read_file(path, code)) {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, m->device));
-    std::string arch = prop.gcnArchName;
-    size_t colon = arch.find(':');
-    if (colon != std::string::npos) arch = arch.substr(0, colon);
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "iem_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-      return fail(IEM_E_COMPILE, "hiprtcCreateProgram failed");
-    std::string archopt = "--offload-arch=" + arch;
-    std::string cflag = contract_flag();
-    const char *opts[] = {archopt.c_str(), "-O3", cflag.c_str(), "-std=c++17"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
-    if (r != HIPRTC_SUCCESS) {
-      size_t n = 0;
-      hiprtcGetProgramLogSize(prog, &n);
-      std::string log(n, '\0');
-      if (n) hiprtcGetProgramLog(prog, &log[0]);
-      hiprtcDestroyProgram(&prog);
-      return fail(IEM_E_COMPILE, "hiprtc: " + log);
-    }
-    size_t n = 0;
-    hiprtcGetCodeSize(prog, &n);
-    code.resize(n);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
-    m->jit = true;
-    mkdir(dir.c_str(), 0755);
-    // several ranks may compile the same key at once: private temp name, atomic rename
-    const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
-    std::ofstream f(tmp, std::ios::binary);
-    if (f) {
-      f.write(code.data(), (std::streamsize)code.size());
-      f.close();
-      if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
-    }
+  bool loaded = false;
+  if (read_file(path, code)) {
+    // a cached object that does not load (truncated file, built for another architecture) is rebuilt
+    loaded = hipModuleLoadData(&m->mod, code.data()) == hipSuccess;
+    if (!loaded) { m->mod = nullptr; (void)hipGetLastError(); }
   }
-  HIP_TRY(hipModuleLoadData(&m->mod, code.data()));
+  if (!loaded) {
+    int rc = jit_compile(m, src, dir, path, code);
+    if (rc) return rc;
+    HIP_TRY(hipModuleLoadData(&m->mod, code.data()));
+  }
   m->fns.resize(m->prog.kernels.size());
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));

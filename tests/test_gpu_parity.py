@@ -326,3 +326,30 @@ def test_folded_or_flat_grids_gpu(nt, nxi, torch_cuda):
     _close(gm.hess_coord(xd, yd, nanv(om.nnzh)).cpu().numpy(), om.hess_coord(x, y, 1.0), "hess")
     assert abs(gm.obj(xd) - om.obj(x)) <= 1e-10 * max(1.0, abs(om.obj(x)))
     gm.close()
+
+
+def test_corrupt_cached_code_object_is_rebuilt(torch_cuda, tmp_path, monkeypatch):
+    """A cached code object that does not load (truncated / foreign file) is recompiled by hiprtc
+    instead of failing the model."""
+    import os
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    monkeypatch.setenv("IEM_KERNEL_CACHE", str(cache))
+    core = cases.build_core("quadrotor_5")
+    blob = core.to_blob()
+    _, key = iemlib.emit_source(blob)
+    gm = ExaModel(core, device=0, blob=blob)          # JIT, populates the private cache
+    gm.close()
+    files = [f for f in os.listdir(cache) if f.endswith(".hsaco")]
+    assert len(files) == 1
+    (cache / files[0]).write_bytes(b"not a code object")
+    gm = ExaModel(core, device=0, blob=blob)
+    om = OracleModel(blob)
+    x, _ = cases.eval_point_for("quadrotor_5", om)
+    np.testing.assert_allclose(gm.jac_coord(torch.tensor(x, device="cuda")).cpu().numpy(), om.jac_coord(x), rtol=1e-12, atol=1e-12)
+    assert (cache / files[0]).stat().st_size > 1000   # rewritten
+    gm.close()
