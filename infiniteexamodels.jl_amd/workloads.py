@@ -231,3 +231,92 @@ def opf(num_supports: int = 100, seed: int = 0, backend=None, supports=None, net
         d = 0.1 * (gen[k]["qmax"] - gen[k]["qmin"])
         im.constraint_interval(qg0[k] - qg[k], -d, d)
     return im
+
+
+def hovercraft(num_supports: int = 101, collocation: int = 0, backend=None) -> InfiniteModel:
+    """``/root/reference/examples/hovercraft_example.jl:6-28`` — waypoint tracking: point variables at
+    interior times (25, 50 are not on the 101-point grid, so they become supports of their own) and
+    at the horizon's ends.  The example's last assignment selects backward finite differences;
+    ``collocation = 4`` gives its first (overwritten) choice, ``OrthogonalCollocation(4)`` with
+    ``constant_over_collocation.(u, t)``."""
+    xw = np.array([[1.0, 4.0, 6.0, 1.0], [1.0, 3.0, 0.0, 1.0]])
+    tw = [0.0, 25.0, 50.0, 60.0]
+    im = InfiniteModel(backend)
+    method = io.OrthogonalCollocation(collocation) if collocation else None
+    t = im.infinite_parameter("t", 0.0, 60.0, num_supports=num_supports, derivative_method=method)
+    im.add_supports(t, [v for v in tw if v not in (0.0, 60.0)])      # x[i](tw[j]) creates the supports 25, 50
+    x = [im.variable(f"x[{i + 1}]", t) for i in range(2)]
+    v = [im.variable(f"v[{i + 1}]", t) for i in range(2)]
+    u = [im.variable(f"u[{i + 1}]", t, start=0) for i in range(2)]
+    im.objective("min", im.integral(u[0] ** 2 + u[1] ** 2, t))
+    for i in range(2):
+        im.constraint(v[i](0) == 0)
+    for i in range(2):
+        im.constraint(im.deriv(x[i], t) == v[i])
+    for i in range(2):
+        im.constraint(im.deriv(v[i], t) == u[i])
+    for i in range(2):
+        for j, tj in enumerate(tw):
+            im.constraint(x[i](tj) == xw[i, j])
+    if collocation:
+        for ui in u:
+            im.constant_over_collocation(ui, t)
+    return im
+
+
+def three_node_design(num_supports: int = 1000, seed: int = 42, backend=None) -> InfiniteModel:
+    """``/root/reference/examples/3node_design.jl:6-31`` — stochastic design over a 3-dimensional
+    DEPENDENT parameter θ ~ MvNormal (synthetic draws: numpy's generator, not Julia's), an
+    expectation objective with MAX sense, finite design variables in infinite constraints."""
+    th_nom = np.array([0.0, 60.0, 10.0])
+    covar = np.diag([80.0, 80.0, 120.0])
+    c = np.ones(3) / np.sqrt(3.0)
+    c_max, U = 5.0, 10000.0
+    supp = np.random.default_rng(seed).multivariate_normal(th_nom, covar, size=num_supports)
+    im = InfiniteModel(backend)
+    th = im.dependent_parameters([f"θ[{i + 1}]" for i in range(3)], supp)
+    y = im.variable("y", *th, lb=0, ub=1)
+    z = [im.variable(f"z[{i + 1}]", *th) for i in range(3)]
+    d = [im.variable(f"d[{i + 1}]", lb=0) for i in range(3)]
+    im.objective("max", im.expect(1 - y, th))
+    im.constraint(-z[0] - 35 - d[0] <= y * U)
+    im.constraint(z[0] - 35 - d[0] <= y * U)
+    im.constraint(-z[1] - 50 - d[1] <= y * U)
+    im.constraint(z[0] - 50 - d[1] <= y * U)
+    im.constraint(-z[2] <= y * U)
+    im.constraint(z[2] - 100 - d[2] <= y * U)
+    im.constraint(z[0] - th[0] == 0)
+    im.constraint(-z[0] - z[1] + z[2] - th[1] == 0)
+    im.constraint(z[1] - th[2] == 0)
+    im.constraint(c[0] * d[0] + c[1] * d[1] + c[2] * d[2] <= c_max)
+    return im
+
+
+def kinetic_control(num_supports: int = 100, backend=None) -> InfiniteModel:
+    """``/root/reference/examples/kinetic_control.jl:6-31`` — batch-reactor temperature control:
+    ``OrthogonalCollocation(4)`` on a NON-uniform grid (seven extra supports near t = 0), a point
+    variable as the MAX objective, Arrhenius rates (exp of a quotient), ``constant_over_collocation``."""
+    A = [3.6362e6, 2.5212e16, 190.6879, 8.7409e24]
+    Ea = [10000.0, 25000.0, 5000.0, 40000.0]
+    R = 1.987
+    T_lower, T_upper = 273.0 + 40, 273.0 + 60
+    c0 = [1.0, 0.0, 0.0]
+    Tr = [273.0 + v for v in (30, 40, 50, 70)]
+    kr = [A[j] * np.exp(-Ea[j] / R / Tr[j]) for j in range(4)]
+    tf = 3.0
+    im = InfiniteModel(backend)
+    t = im.infinite_parameter("t", 0.0, tf, num_supports=num_supports, derivative_method=io.OrthogonalCollocation(4))
+    im.add_supports(t, [0.00001, 0.00005, 0.0001, 0.0005, 0.001, 0.01, 0.1])
+    c = [im.variable(f"c[{i + 1}]", t, lb=0, ub=1, start=c0[i]) for i in range(3)]
+    T = im.variable("T", t, lb=T_lower, ub=T_upper, start=T_upper)
+    im.objective("max", c[1](tf))
+    for i in range(3):
+        im.constraint(c[i](0) == c0[i])
+    k = [kr[j] * io.exp(Ea[j] / R * (1 / Tr[j] - 1 / T)) for j in range(4)]
+    r1 = c[0] * k[0] - c[1] * k[1]
+    r2 = c[0] * k[2] - c[2] * k[3]
+    im.constraint(im.deriv(c[0], t) == -r1 - r2)
+    im.constraint(im.deriv(c[1], t) == r1)
+    im.constraint(im.deriv(c[2], t) == r2)
+    im.constant_over_collocation(T, t)
+    return im

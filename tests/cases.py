@@ -116,6 +116,13 @@ def small_cases():
         "farmer_1000": lambda: workloads.farmer(1000),
         "opf_7": lambda: workloads.opf(7),
         "opf_600": lambda: workloads.opf(600),
+        # the remaining models of /root/reference/examples: interior waypoints (point variables at
+        # supports added for them), a 3-dimensional dependent parameter with a MAX expectation
+        # objective, collocation(4) on a non-uniform grid with a point-variable objective
+        "hovercraft": lambda: workloads.hovercraft(),
+        "hovercraft_oc4": lambda: workloads.hovercraft(21, collocation=4),
+        "three_node_50": lambda: workloads.three_node_design(50),
+        "kinetic_20": lambda: workloads.kinetic_control(20),
         "ode_5x5": ode_5x5,
         "test_problem_1": test_problem_1,
         "rosenbrock": lambda: rosenbrock()[0],
@@ -131,8 +138,10 @@ def eval_point_for(name, om, seed=0):
     """Seeded evaluation point kept inside every operator's domain."""
     rng = np.random.default_rng(seed)
     x = om.x0 + 0.1 * rng.standard_normal(om.nvar)
-    if name.startswith("quadrotor") or name.startswith("opf"):
+    if name.startswith(("quadrotor", "opf", "hovercraft")):
         pass
+    elif name.startswith("kinetic"):
+        x = om.x0 + 0.01 * rng.standard_normal(om.nvar) * np.maximum(1.0, np.abs(om.x0))   # T stays near 333 K
     elif name == "operator_zoo":
         n = om.nvar // 2
         x = np.concatenate([0.3 + 0.5 * rng.random(n), 1.3 + 0.6 * rng.random(om.nvar - n)])

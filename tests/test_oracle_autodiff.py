@@ -9,7 +9,7 @@ from helpers import TorchModel, coo_to_dense, lower_to_full
 from pyoracle import OracleModel
 
 SMALL = ["quadrotor_5", "quadrotor_oc3_40", "pandemic_20x3", "farmer_5", "ode_5x5", "test_problem_1", "rosenbrock", "pfun",
-         "irregular"]
+         "irregular", "hovercraft_oc4", "three_node_50", "kinetic_20"]
 
 
 @pytest.mark.parametrize("name", SMALL)

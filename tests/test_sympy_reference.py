@@ -104,7 +104,8 @@ class SympyModel:
         return f, np.array(c), g, np.array(J).reshape(len(c), n), H
 
 
-@pytest.mark.parametrize("name", ["quadrotor_5", "rosenbrock", "pfun", "operator_zoo", "opf_7", "farmer_5", "quadrotor_oc3_40", "pandemic_20x3", "irregular"])
+@pytest.mark.parametrize("name", ["quadrotor_5", "rosenbrock", "pfun", "operator_zoo", "opf_7", "farmer_5", "quadrotor_oc3_40", "pandemic_20x3", "irregular",
+                                  "hovercraft_oc4", "three_node_50", "kinetic_20"])
 def test_oracle_matches_symbolic_derivatives(name):
     core = cases.build_core(name)
     om = OracleModel(core.to_blob())
