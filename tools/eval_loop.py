@@ -52,6 +52,15 @@ def measure(args):
     elif args.workload == "farmer":
         im = workloads.farmer(args.supports)
         desc = f"two-stage farmer, {args.supports} scenarios"
+    elif args.workload == "hovercraft":
+        im = workloads.hovercraft(args.supports)
+        desc = f"hovercraft (examples/hovercraft_example.jl), {args.supports} supports"
+    elif args.workload == "three_node":
+        im = workloads.three_node_design(args.supports)
+        desc = f"3-node design (examples/3node_design.jl), {args.supports} scenarios"
+    elif args.workload == "kinetic":
+        im = workloads.kinetic_control(args.supports)
+        desc = f"kinetic control (examples/kinetic_control.jl), OrthogonalCollocation(4), {args.supports} public supports"
     elif args.workload == "quadrotor_oc3":
         im = workloads.quadrotor(args.supports, collocation=3)
         desc = f"quadrotor ESCAPE34 variant (OrthogonalCollocation(3), piecewise-constant controls), {args.supports} public supports"
@@ -63,7 +72,7 @@ def measure(args):
     t_build = time.perf_counter() - t0
     rng = np.random.default_rng(0)
     x0 = gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)
-    x = torch.tensor(x0 if args.workload in ("opf", "quadrotor", "quadrotor_oc3") else np.abs(x0) + 0.05, device="cuda")
+    x = torch.tensor(x0 if args.workload in ("opf", "quadrotor", "quadrotor_oc3", "hovercraft") else (gm.meta.x0 if args.workload == "kinetic" else np.abs(x0) + 0.05), device="cuda")
     y = torch.tensor(np.random.default_rng(1).standard_normal(gm.meta.ncon), device="cuda")
     g = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
     c = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
