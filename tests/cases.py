@@ -36,6 +36,66 @@ def test_problem_1():
     return m
 
 
+def test_problem_1_oc3():
+    """/root/reference/test/solve.jl:27-31 — the same model with OrthogonalCollocation(3) in t and
+    an extra variable held constant over the collocation nodes."""
+    m = test_problem_1()
+    t = m.groups[0].prefs[0]
+    m.set_derivative_method(t, io.OrthogonalCollocation(3))
+    u = m.variable("u", t)
+    m.constant_over_collocation(u, t)
+    return m
+
+
+def test_problem_2(objective: int = 0):
+    """/root/reference/test/solve.jl:46-90 — five objective forms over the same constraints
+    (0: the base objective, 1-4: the `objs` list exercising the measure heuristics)."""
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    x = m.infinite_parameter("x", -1, 1, num_supports=5)
+    y = m.variable("y", t, x, lb=0)
+    z = m.variable("z", start=10)
+    m.constraint(m.deriv(y, t) == io.sin(y) + z + 1.2)
+    m.constraint(y + z <= 42 + t)
+    m.constraint(m.deriv(y(0, x), x) == 5)
+    inner = m.integral(y ** 2, t)
+    objs = [lambda: m.integral(inner + 2 * z, x) + 2 * y(0, 1),
+            lambda: m.integral(inner + 2 * z ** 2, x) + 2 * y(0, 1),
+            lambda: m.integral(inner + io.sin(z ** 2), x),
+            lambda: m.integral(inner * io.cos(z), x),
+            lambda: m.integral(z * (inner + z ** 3), x)]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.objective("min", objs[objective]())
+    return m
+
+
+def pfun_full(ti=0.2):
+    """/root/reference/test/solve.jl:93-122 — the whole "Parameter Function Problem": a piecewise
+    parameter function of (t, s), a semi-infinite variable z(t, 2.5) and a measure of a parameter
+    function inside a constraint (c5)."""
+    def pf2f(t, s):
+        return np.where(t <= 0.5, np.cos(t) * s - ti, np.sin(t) * s + ti)
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, num_supports=5)
+    s = m.infinite_parameter("s", 2, 3, num_supports=5)
+    v = m.variable("v", t, lb=0, ub=100)
+    z = m.variable("z", t, s, lb=0, ub=100)
+    pf = m.parameter_function("pf", np.sin, t)
+    pf2 = m.parameter_function("pf2", pf2f, t, s)
+    m.constraint(v + pf <= 100, name="c1")
+    m.constraint(v * 2 + pf * pf2 <= 100, name="c2")
+    m.constraint(v >= 0.2 * pf2, name="c3")
+    m.constraint(z(t, 2.5) + pf2 * pf <= 40, name="c4")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.constraint(v * m.integral(pf2, s) <= 100, name="c5")
+    m.objective("min", m.integral(v * pf, t) + m.integral(m.integral(0.5 * z * pf2, t), s))
+    return m
+
+
 def rosenbrock(p1=100.0, p2=1.0):
     """/root/reference/test/solve.jl:134-143 — finite parameters p1, p2."""
     m = InfiniteModel()
@@ -125,6 +185,13 @@ def small_cases():
         "kinetic_20": lambda: workloads.kinetic_control(20),
         "ode_5x5": ode_5x5,
         "test_problem_1": test_problem_1,
+        "test_problem_1_oc3": test_problem_1_oc3,
+        "test_problem_2_obj0": lambda: test_problem_2(0),
+        "test_problem_2_obj1": lambda: test_problem_2(1),
+        "test_problem_2_obj2": lambda: test_problem_2(2),
+        "test_problem_2_obj3": lambda: test_problem_2(3),
+        "test_problem_2_obj4": lambda: test_problem_2(4),
+        "pfun_full": pfun_full,
         "rosenbrock": lambda: rosenbrock()[0],
         "pfun": lambda: pfun()[0],
         "operator_zoo": operator_zoo,

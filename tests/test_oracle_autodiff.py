@@ -9,7 +9,8 @@ from helpers import TorchModel, coo_to_dense, lower_to_full
 from pyoracle import OracleModel
 
 SMALL = ["quadrotor_5", "quadrotor_oc3_40", "pandemic_20x3", "farmer_5", "ode_5x5", "test_problem_1", "rosenbrock", "pfun",
-         "irregular", "hovercraft_oc4", "three_node_50", "kinetic_20"]
+         "irregular", "hovercraft_oc4", "three_node_50", "kinetic_20", "test_problem_1_oc3", "test_problem_2_obj2",
+         "test_problem_2_obj3", "test_problem_2_obj4", "pfun_full"]
 
 
 @pytest.mark.parametrize("name", SMALL)

@@ -105,7 +105,8 @@ class SympyModel:
 
 
 @pytest.mark.parametrize("name", ["quadrotor_5", "rosenbrock", "pfun", "operator_zoo", "opf_7", "farmer_5", "quadrotor_oc3_40", "pandemic_20x3", "irregular",
-                                  "hovercraft_oc4", "three_node_50", "kinetic_20"])
+                                  "hovercraft_oc4", "three_node_50", "kinetic_20", "test_problem_1_oc3",
+                                  "test_problem_2_obj1", "test_problem_2_obj3", "test_problem_2_obj4", "pfun_full"])
 def test_oracle_matches_symbolic_derivatives(name):
     core = cases.build_core(name)
     om = OracleModel(core.to_blob())

@@ -250,3 +250,24 @@ def test_objective_sense_travels_as_metadata(built):
     omin, omax = OracleModel(cmin.to_blob()), OracleModel(cmax.to_blob())
     assert omin.minimize and not omax.minimize
     assert omin.obj(omin.x0) == omax.obj(omax.x0) > 0
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 4])
+def test_problem_2_objective_forms_match_explicit_quadrature(k, built):
+    """test/solve.jl:46-90: whatever the objective heuristics do with nested measures and finite
+    terms (inner measure kept, product with a finite function, finite addend moved inside), the
+    transcribed objective must equal the double trapezoid rule written out by hand."""
+    from pyoracle import OracleModel
+    core = cases.build_core(f"test_problem_2_obj{k}")
+    om = OracleModel(core.to_blob())
+    rng = np.random.default_rng(k)
+    x = np.abs(om.x0 + rng.standard_normal(om.nvar)) + 0.1
+    z = x[0]
+    Y = x[1:26].reshape(5, 5)                 # Y[ix, it]: t runs fastest inside the slab
+    tw = np.array([0.125, 0.25, 0.25, 0.25, 0.125])        # trapezoid on 5 uniform supports of [0, 1]
+    xw = 2 * tw                                             # ... of [-1, 1]
+    inner = (Y ** 2) @ tw                                   # I(x) = ∫ y² dt
+    y01 = Y[4, 0]                                           # y(t = 0, x = 1)
+    want = [xw @ (inner + 2 * z) + 2 * y01, xw @ (inner + 2 * z ** 2) + 2 * y01, xw @ (inner + np.sin(z ** 2)),
+            xw @ (inner * np.cos(z)), xw @ (z * (inner + z ** 3))][k]
+    assert abs(om.obj(x) - want) <= 1e-12 * max(1.0, abs(want))
