@@ -8,9 +8,13 @@
 // visit order, same accumulation order as the CPU restatement), so
 //   * x[off_k + q] is loaded once per lane however many templates read it,
 //   * sin/cos/tan of a state are computed once per lane (sincos pairing),
-//   * a template's item block goes out through iem_store_rows<NS> (iem_device.h).
-// The emitted code is size-independent: slab offsets, extents and COO offsets are
-// kernel arguments, so one code object serves 10² and 10⁶ supports.
+//   * a template's item block goes out through the block store of iem_device.h
+//     (iem_stage / iem_flush: LDS staging, whole 128-byte lines, overlapped tiles).
+// One launch per call: grids that share a call become __device__ bodies behind one
+// workgroup-id dispatcher; a grid of <= split_small workgroups gets one body per template
+// (latency-bound regime), larger grids one lane-fused body (HBM-bound regime).
+// The emitted code is size-independent within a regime: slab offsets, extents and COO
+// offsets are kernel arguments, so one code object serves 10^5 and 10^7 supports.
 #include "iem_codegen.hpp"
 
 #include <algorithm>

@@ -15,7 +15,7 @@ struct KernelDesc {
   std::string name;
   int kind = 0;
   int64_t grid[3] = {1, 1, 1};  // workgroups
-  // argument block, in this order after the fixed head {x, th, y, v, out, w}:
+  // argument block, in this order after the fixed head {x, th, y, v, out, w, aux}:
   std::vector<int64_t> ip;  // long long ip[]
   std::vector<double> dp;   // double dp[]
   std::vector<int> fa;      // const double* fa[]  (model array ids, uploaded as f64)
