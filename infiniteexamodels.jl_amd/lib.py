@@ -196,9 +196,11 @@ def blob_hess_structure(blob: bytes, base: int = 0):
     return rows, cols
 
 
-def precompile(blob: bytes, arch: str = "gfx950", force: bool = False) -> str:
+def precompile(blob: bytes, arch: str = "gfx950", force: bool = False, defer: list = None) -> str:
     """Offline-compile a model's kernels into the in-tree code-object cache
-    (``hipcc --genco --offload-arch=gfx950``); returns the ``.hsaco`` path."""
+    (``hipcc --genco --offload-arch=gfx950``); returns the ``.hsaco`` path.  With ``defer`` (a
+    list) the source is generated now — under the CURRENT generator options — and the hipcc command
+    is appended to the list instead of being run: ``run_deferred`` compiles them in parallel."""
     src, key = emit_source(blob)
     os.makedirs(KERNEL_DIR, exist_ok=True)
     out = os.path.join(KERNEL_DIR, f"iem_{key:016x}.hsaco")
@@ -211,6 +213,23 @@ def precompile(blob: bytes, arch: str = "gfx950", force: bool = False) -> str:
     assert first.startswith("// iem-flags:"), first
     flags = first[len("// iem-flags:"):].split()
     cmd = [os.path.join(ROCM, "bin", "hipcc"), "--genco", f"--offload-arch={arch}", *flags, "-o", out + ".tmp", hip]
+    if defer is not None:
+        if not any(c[1] == out for c in defer):
+            defer.append((cmd, out))
+        return out
     subprocess.check_call(cmd)
     os.replace(out + ".tmp", out)
     return out
+
+
+def run_deferred(jobs: list, workers: int = 0) -> None:
+    """Run the hipcc commands collected by ``precompile(..., defer=jobs)`` on a small thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(job):
+        cmd, out = job
+        subprocess.check_call(cmd)
+        os.replace(out + ".tmp", out)
+    workers = workers or max(1, min(6, len(os.sched_getaffinity(0)) - 1))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(one, jobs))
