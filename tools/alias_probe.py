@@ -1,3 +1,5 @@
+"""In-process probe: does kernel time depend on the power of two dividing S, or on the output buffer?
+(profiles/r01_size_vs_placement_4e6.txt) — three model sizes, the same three output buffer pairs."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
