@@ -100,13 +100,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,size", [("farmer", 40), ("quadrotor", 50)])
-def test_obj_grad_allreduce_gloo_world2(name, size, built):
-    """world_size 2 over gloo: obj and replicated-gradient entries via ONE small all-reduce."""
+@pytest.mark.parametrize("name,size,world", [("farmer", 40, 2), ("quadrotor", 50, 2), ("farmer", 41, 4), ("quadrotor", 53, 3)])
+def test_obj_grad_allreduce_gloo_world2(name, size, world, built):
+    """world_size 2 (and 3, 4 with ragged shards) over gloo: obj and replicated-gradient entries via
+    ONE small all-reduce."""
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), name, str(size)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
