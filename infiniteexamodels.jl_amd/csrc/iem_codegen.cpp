@@ -956,6 +956,14 @@ class KernelBuilder {
     int max_ns = 1;
     for (auto &o : outs_)
       if ((kind_ == KK_JAC || kind_ == KK_HESS) && (int)o.vals.size() <= ns_cap) max_ns = std::max<int>(max_ns, (int)o.vals.size());
+    // values per lane this kernel ever stages: a body with one small template (the side-by-side
+    // shape of small grids) must not reserve the full staging batch — LDS decides how many
+    // workgroups share a CU, and those kernels are latency-bound
+    int total_ns = 0;
+    for (auto &o : outs_) {
+      const int ns = (kind_ == KK_JAC || kind_ == KK_HESS) ? (int)o.vals.size() : 1;
+      if (!o.scalar && ns <= ns_cap) total_ns += ns;
+    }
     bool use_lds = (kind_ == KK_JAC || kind_ == KK_HESS) && opt_.store_mode == 1;
     bool use_blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD) && opt_.store_mode == 2;
 
@@ -1008,7 +1016,7 @@ class KernelBuilder {
       for (size_t oi = 0; oi < outs_.size(); ++oi) order.push_back((int)oi);
     }
     int batch_slots = 0;
-    const int lds_budget = stage_budget(max_ns);
+    const int lds_budget = stage_budget(max_ns, total_ns);
     std::vector<std::string> pending_flush;
     auto flush_batch = [&]() {
       if (pending_flush.empty()) return;
@@ -1220,7 +1228,7 @@ class KernelBuilder {
       kd.lds_bytes = opt_.block * max_ns * 8;
     }
     if (use_blk) {
-      const int budget = stage_budget(max_ns);
+      const int budget = stage_budget(max_ns, total_ns);
       if (!as_body) os << "  __shared__ double lds_blk[" << (opt_.block * budget) << "];\n";
       os << "  const long long qb0 = (long long)blockIdx.x * " << qstep_str() << ";\n";
       kd.lds_bytes = opt_.block * budget * 8;
@@ -1258,8 +1266,9 @@ class KernelBuilder {
   void set_n_partials(int64_t n) { n_partials_ = n; }
   void set_zero_fill(const std::vector<std::pair<int64_t, int64_t>> &ranges) { zero_fill_ = ranges; }
 
-  int stage_budget(int max_ns) const {
+  int stage_budget(int max_ns, int total_ns) const {
     int b = std::max(1, opt_.lds_slots * 256 / opt_.block);
+    b = std::min(b, std::max(1, total_ns));   // never more than the kernel stages in total
     b = std::max(b, max_ns);
     if ((long long)b * opt_.block * 8 > 160 * 1024) throw std::runtime_error("internal: LDS staging budget exceeds a CU");
     return b;
