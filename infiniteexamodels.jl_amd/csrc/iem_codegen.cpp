@@ -1646,14 +1646,31 @@ Program generate(const Model &m, const Options &opt) {
     if (kind == KK_OBJ) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
     else src << "  double* lds4 = nullptr;\n";
     src << "  const long long b = blockIdx.x;\n";
+    auto call = [&](size_t j, const std::string &ind) {
+      std::ostringstream c;
+      c << ind << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
+        << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n";
+      return c.str();
+    };
+    if (ks.size() > 4) {
+      // many bodies (one per template on a small grid): binary search of the workgroup id in the
+      // table of first workgroups, then a jump table — a chain of 80 compares costs microseconds
+      src << "  int lo_ = 0, hi_ = " << ks.size() << ";\n"
+          << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n"
+          << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
+          << "  const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)"
+                                                          : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]") << ";\n"
+          << "  switch (lo_) {\n";
+      for (size_t j = 0; j < ks.size(); ++j) src << "    case " << j << ":\n" << call(j, "      ") << "      break;\n";
+      src << "  }\n";
+    } else
     for (size_t j = 0; j < ks.size(); ++j) {
       const size_t e = dec + 4 * j;
       src << "  " << (j ? "else " : "");
       if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
       src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
           << "    const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
-          << "    " << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
-          << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n  }\n";
+          << call(j, "    ") << "  }\n";
     }
     src << "}\n\n";
     P.kernels.push_back(F);
