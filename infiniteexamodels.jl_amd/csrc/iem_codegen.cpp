@@ -1631,9 +1631,14 @@ Program generate(const Model &m, const Options &opt) {
       F.ip.push_back(first); F.ip.push_back(d.grid[0]); F.ip.push_back(d.grid[1]); F.ip.push_back(d.grid[2]);
       first += d.n_blocks;
     }
+    const size_t tbl = F.ip.size();
+    if (ks.size() > 4 && F.grid[0] <= (1 << 18))
+      for (size_t j = 0; j < ks.size(); ++j) F.ip.insert(F.ip.end(), (size_t)descs[ks[j]].n_blocks, (int64_t)j);
     size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
     size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
-    F.tables_in_memory = (nip + ndp + nfa + nia) > 320;
+    // the workgroup->body table has one entry per workgroup: in device memory always, so that the
+    // argument struct (hence the source) does not depend on the launch size
+    F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > tbl;
     src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
     if (F.tables_in_memory)
       src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
@@ -1655,8 +1660,14 @@ Program generate(const Model &m, const Options &opt) {
     if (ks.size() > 4) {
       // many bodies (one per template on a small grid): binary search of the workgroup id in the
       // table of first workgroups, then a jump table — a chain of 80 compares costs microseconds
+      if (F.grid[0] <= (1 << 18)) {
+        // one load: workgroup -> body table behind the decode table (a binary search would be a chain
+        // of dependent scalar loads, ~0.4 us each when the tables live in device memory)
+        src << "  const int lo_ = (int)A.ip[" << tbl << " + b];\n";
+      } else
       src << "  int lo_ = 0, hi_ = " << ks.size() << ";\n"
-          << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n"
+          << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n";
+      src
           << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
           << "  const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)"
                                                           : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]") << ";\n"
