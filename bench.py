@@ -4,15 +4,23 @@ per second on the quadrotor transcription (examples/quadrotor.jl) at 10^6 suppor
 with the achieved fraction of the gfx950 HBM roofline and a CPU baseline timed in the
 same run.
 
-  python bench.py --gpus N --steps K --warmup W [--supports S] [--scaling weak|strong]
+  python bench.py --gpus N --steps K --warmup W [--supports S] [--scaling strong|weak]
 
 A "step" is one jac_coord! + one hess_coord! over the resident model (inputs already
 in HBM).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the time
 axis is sharded into contiguous support blocks (halo of one support for the
 finite-difference rows); jac_coord!/hess_coord! need no collective, so ranks only meet
-at the barriers that bracket the timed region.  Weak scaling (default): every rank owns
-S supports of an N*S-support horizon; value = (supports all ranks processed per second)
-/ 1e6, i.e. evaluation pairs per second normalised to the 10^6-support problem.
+at the barriers that bracket the timed region.
+
+Launch: under torchrun (RANK/WORLD_SIZE in the environment) the script is one rank; started
+plainly with --gpus N > 1 it spawns its N ranks itself — fresh child processes, created before
+this process makes any GPU call — and rank 0 prints the one JSON line.
+
+Scaling: STRONG by default (SURVEY.md §7 "Strong scaling to >= 6x"): the headline problem —
+10^6 supports in total — is cut into N shards of 10^6/N supports (+ halo); `value` = evaluation
+pairs per second of that fixed problem, so value(N)/value(1) is the speed-up.  For N > 1 the same
+run also measures the weak form (every rank a full 10^6-support shard of an N*10^6 horizon)
+outside the headline timed region and reports it under the key "weak".
 """
 from __future__ import annotations
 
@@ -30,6 +38,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_PROFILE = "r01_rocprof_quadrotor_1e6.json"   # committed rocprofv3 --pmc passes of this command (static, not live)
 
 
 def eval_point(nvar, ncon, x0, S_local, seed=0):
@@ -76,13 +85,47 @@ def cpu_baseline(sample_supports: int, seconds: float = 12.0):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """Plain `python bench.py --gpus N` (no RANK in the environment): start the N ranks as fresh
+    child processes — this parent has not touched the GPU and never does — and wait for them.
+    Rank 0 inherits stdout and prints the JSON line.  A rank that dies takes the others with it
+    (exact PIDs), so a failure cannot hang at a barrier."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in live:
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--supports", type=int, default=1_000_000, help="supports per rank (weak) / total (strong)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--supports", type=int, default=1_000_000, help="supports in total (strong) / per rank (weak)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling measurement")
     ap.add_argument("--store-mode", type=int, default=2)
     ap.add_argument("--nt", type=int, default=1)
     ap.add_argument("--fma", type=int, default=0)
@@ -93,9 +136,15 @@ def main():
                     help="gloo + --same-device rehearses the N>1 path with several ranks on ONE GPU")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--emulate-shard", default="", help="R/N: time shard R of an N-way sharded run on this GPU")
+    ap.add_argument("--graph", action="store_true", help="replay the jac+hess pair from a captured HIP graph instead of eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU, no evaluation, NOT a measurement: spawn / rendezvous / reduce only (CPU test of the N>1 launch path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -109,6 +158,17 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if args.same_device:
         local_rank = 0
+    if args.rehearse_launch:
+        # launch-path rehearsal for the CPU suite: the same spawn, environment, rendezvous and
+        # max-over-ranks reduction as a real run, nothing evaluated, nothing timed
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "max_rank_seen": int(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torchrun (RANK set) the process group is always created — also at world 1, so the
@@ -140,49 +200,66 @@ def main():
         k, v = kv.split("=")
         iemlib.set_option(k, int(v))
 
-    if args.scaling == "weak":
-        S_global, S_local = args.supports * world, args.supports
-    else:
-        S_global, S_local = args.supports, None
-    if args.emulate_shard:     # build shard R of N on this one GPU (no communication): "R/N"
-        er, ew = (int(v) for v in args.emulate_shard.split("/"))
-        core, S_local = shard.quadrotor_shard(args.supports * ew if args.scaling == "weak" else args.supports, er, ew)
-    elif world == 1:
-        core = transcribe.exa_core(workloads.quadrotor(S_global))
-        S_local = S_global
-    else:
-        core, S_local = shard.quadrotor_shard(S_global, rank, world)
-    blob = core.to_blob()
-    gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout)
-    del blob
-    x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22, seed=rank * 2)
-    xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
-    jac = torch.empty(gm.meta.nnzj, dtype=torch.float64, device=dev)
-    hess = torch.empty(gm.meta.nnzh, dtype=torch.float64, device=dev)
+    def measure(scaling: str, steps: int, warmup: int):
+        """Build this rank's shard for `scaling`, run `warmup` untimed + exactly `steps` timed
+        jac+hess pairs between barriers, return (max-over-ranks seconds, supports all ranks own, state)."""
+        if scaling == "weak":
+            S_global = args.supports * world
+        else:
+            S_global = args.supports
+        if args.emulate_shard:     # build shard R of N on this one GPU (no communication): "R/N"
+            er, ew = (int(v) for v in args.emulate_shard.split("/"))
+            core, S_local = shard.quadrotor_shard(args.supports * ew if scaling == "weak" else args.supports, er, ew)
+        elif world == 1:
+            core = transcribe.exa_core(workloads.quadrotor(S_global))
+            S_local = S_global
+        else:
+            core, S_local = shard.quadrotor_shard(S_global, rank, world)
+        blob = core.to_blob()
+        gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout)
+        del blob
+        x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22, seed=rank * 2)
+        xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
+        jac = torch.empty(gm.meta.nnzj, dtype=torch.float64, device=dev)
+        hess = torch.empty(gm.meta.nnzh, dtype=torch.float64, device=dev)
 
-    def step():
-        gm.jac_coord(xd, jac)
-        gm.hess_coord(xd, yd, hess, obj_weight=1.0)
+        def step():
+            gm.jac_coord(xd, jac)
+            gm.hess_coord(xd, yd, hess, obj_weight=1.0)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        sl = torch.tensor([float(S_local)], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(sl)
-        supports_total = float(sl.item())
-    else:
-        supports_total = float(S_local)
+        if args.graph:
+            eager = step
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                eager()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager()
+            step = graph.replay
+        for _ in range(warmup):
+            step()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            sl = torch.tensor([float(S_local)], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(sl)
+            supports_total = float(sl.item())
+        else:
+            supports_total = float(S_local)
+        return dt, supports_total, (gm, S_local, xd, yd, jac, hess, step)
+
+    dt, supports_total, (gm, S_local, xd, yd, jac, hess, step) = measure(args.scaling, args.steps, args.warmup)
 
     # distribution of single pairs (SURVEY §8(d) config 2: median, p10/p90), HIP events on the
     # launch stream, outside the timed region
@@ -194,6 +271,7 @@ def main():
     torch.cuda.synchronize()
     pair_ms = np.array([a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])])
 
+    line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = supports_total / 1e6 * args.steps / dt
@@ -207,16 +285,19 @@ def main():
         achieved = alg / (ms_dom * 1e-3) / 1e9
         pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())
         # HBM bytes per launch from the PMC counters cannot be collected inside this process
-        # (they need rocprofv3 passes of their own): taken from the committed profile of the
-        # same command and size (tools/profile_gpu.sh → profiles/), null otherwise.
+        # (they need rocprofv3 passes of their own): a STATIC figure read from the committed
+        # profile of the same command and size (tools/profile_gpu.sh → profiles/), null otherwise.
         traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, "profiles", "r01_rocprof_quadrotor_1e6.json")
+        prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
         if os.path.exists(prof) and S_local == 1_000_000 and world == 1:
             try:
-                traffic = json.load(open(prof))["pmc"][kd["name"]]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_rocprof_quadrotor_1e6.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                pj = json.load(open(prof))
+                traffic = pj["pmc"][kd["name"]]["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                               f"profiled at commit {pj.get('commit', 'n/a')})")
             except Exception:
                 traffic = None
+        par = f"support-sharded x{world}, {args.scaling} scaling" + (f", shard {args.emulate_shard} emulated on one GPU" if args.emulate_shard else "")
         line = {
             "metric": "jac_coord!+hess_coord! evals/sec, quadrotor 1e6 supports; % HBM roofline",
             "value": value, "unit": "jac+hess pairs/s (1e6-support quadrotor equivalent)",
@@ -226,15 +307,30 @@ def main():
             "config": {"workload": f"quadrotor (examples/quadrotor.jl), backward FD, {int(supports_total)} supports total, "
                                    f"{S_local} per GPU, jac_coord!+hess_coord! only, seed 0/1 inputs resident in HBM",
                        "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
-                       "store_mode": args.store_mode, "hess_layout": args.hess_layout, "parallelism": f"support-sharded x{world}"},
+                       "store_mode": args.store_mode, "hess_layout": args.hess_layout, "parallelism": par,
+                       "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
+                         "traffic_source": traffic_src,
                          "alg_bytes": alg, "kernel_ms": ms_dom,
                          "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
                          "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         line["pair_ms"] = {"median": float(np.median(pair_ms)), "p10": float(np.percentile(pair_ms, 10)),
                            "p90": float(np.percentile(pair_ms, 90)), "n": int(pair_ms.size)}
+    # secondary measurement, outside the headline timed region: the weak form of the same run
+    # (every rank a full `--supports` shard of an N-times longer horizon)
+    if world > 1 and args.scaling == "strong" and not args.no_weak and not args.emulate_shard:
+        del gm, xd, yd, jac, hess, step
+        torch.cuda.empty_cache()
+        wdt, wsupports, state = measure("weak", max(10, args.steps // 4), max(3, args.warmup // 4))
+        if rank == 0:
+            wsteps = max(10, args.steps // 4)
+            line["weak"] = {"value": wsupports / 1e6 * wsteps / wdt, "ms_per_step": wdt / wsteps * 1e3, "steps": wsteps,
+                            "supports_total": int(wsupports), "supports_per_gpu": int(state[1]),
+                            "note": "every rank owns a full shard; no data-path collective, so this is Nx by construction"}
+        del state
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line), flush=True)
