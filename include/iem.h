@@ -76,6 +76,15 @@ typedef struct iem_kernel_info_t {
  *              (infiniteopt_backend.jl:155-156; README.md:41 `backend = CUDABackend()`).
  *              `blob` is the transcribed model (include/iem_blob.h). */
 int iem_create(const void *blob, size_t nbytes, int device, iem_model **out);
+/* The same with per-HANDLE generator options: the process-wide defaults (iem_set_option) with
+ * `opts[0 .. n_opts)` applied on top, for this model only — two models with different layouts
+ * (e.g. a merged-Hessian one next to a default one) coexist in one process.  Option names as for
+ * iem_set_option. */
+typedef struct iem_option_t {
+  const char *name;
+  int64_t value;
+} iem_option_t;
+int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_option_t *opts, int n_opts, iem_model **out);
 int iem_destroy(iem_model *m);
 int iem_meta(const iem_model *m, iem_meta_t *out);
 int iem_template_info(const iem_model *m, int64_t i, iem_template_info_t *out);
@@ -135,7 +144,8 @@ int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t *
 int iem_blob_array(const void *blob, size_t nbytes, int id, double **out_vals, int64_t *out_n);
 void iem_free(void *p);
 
-/* knobs (process-global; set BEFORE iem_create / iem_emit_*; defaults in csrc/iem_codegen.hpp):
+/* knobs: iem_set_option changes the PROCESS DEFAULTS that iem_create and iem_emit_* read; per-handle
+ * values go through iem_create_opts (defaults in csrc/iem_codegen.hpp):
  *   "store_mode"   0 direct strided stores, 1 wave-level LDS-transposed stores, 2 (default)
  *                  workgroup-staged stores re-cut at 128-byte lines
  *   "overlap"      1 (default): block-store kernels overlap their tiles by 16 lanes so that every
@@ -151,7 +161,11 @@ void iem_free(void *p);
  *   "no_fuse", "ablate": experiments / baselines only
  *   "hess_merge"   1 selects the opt-in MERGED Hessian layout (duplicate (row,col) slots of one
  *                  support summed in registers: fewer nnzh, not ExaModels' COO layout —
- *                  hess_structure!/hess_coord! stay mutually consistent). */
+ *                  hess_structure!/hess_coord! stay mutually consistent).
+ *   "obj_wgs"      at most this many workgroups walk the objective's tiles (default 1024; fixed, so the
+ *                  summation order is — obj is bitwise reproducible)
+ *   "det_shared"   1 (default): gradient / J'v / Hv entries shared by many items are reduced in a fixed
+ *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs) */
 int iem_set_option(const char *name, int64_t value);
 
 /* per-kernel timing of the last jac/hess call pair, measured with HIP events on the

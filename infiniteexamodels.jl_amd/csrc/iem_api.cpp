@@ -59,18 +59,18 @@ struct DevGuard {
 
 int g_opt_poll_obj = 1;   // iem_set_option("poll_obj", 0): iem_obj always synchronises the stream
 
-std::string contract_flag() { return g_opt.fp_contract ? "-ffp-contract=fast" : "-ffp-contract=off"; }
+std::string contract_flag(const iem::Options &o) { return o.fp_contract ? "-ffp-contract=fast" : "-ffp-contract=off"; }
 
 // first line carries the compile flags so that an offline build (lib.precompile) and the
 // hiprtc path compile the same key with the same options
-std::string full_source(const iem::Program &p) {
+std::string full_source(const iem::Program &p, const iem::Options &o) {
   std::string s;
-  s += "// iem-flags: -O3 " + contract_flag() + " -std=c++17\n";
+  s += "// iem-flags: -O3 " + contract_flag(o) + " -std=c++17\n";
   s += "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
-  s += std::string("#define IEM_NT ") + (g_opt.nt_stores ? "1" : "0") + "\n";
-  s += "#define IEM_TILE " + std::to_string(g_opt.block) + "\n";
-  s += std::string("#define IEM_WIDE_STORES ") + (g_opt.wide_stores ? "1" : "0") + "\n";
-  if (g_opt.ablate) s += "#define IEM_ABLATE " + std::to_string(g_opt.ablate & 1) + "  // timing experiment, results are wrong\n";
+  s += std::string("#define IEM_NT ") + (o.nt_stores ? "1" : "0") + "\n";
+  s += "#define IEM_TILE " + std::to_string(o.block) + "\n";
+  s += std::string("#define IEM_WIDE_STORES ") + (o.wide_stores ? "1" : "0") + "\n";
+  if (o.ablate) s += "#define IEM_ABLATE " + std::to_string(o.ablate & 1) + "  // timing experiment, results are wrong\n";
   s += kDeviceHeader;
   s += "\n";
   s += p.source;
@@ -115,12 +115,15 @@ bool read_file(const std::string &path, std::vector<char> &out) {
 struct iem_model {
   iem::Model model;
   iem::Program prog;
+  iem::Options opt;     // this handle's generator options (process defaults + iem_create_opts overrides)
+  int poll_obj = 1;
   int device = 0;
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
   hipFunction_t fn_struct = nullptr, fn_csr = nullptr;
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
+  double *d_red[iem::KK_COUNT] = {};   // per scatter kind: parked shared-entry values + tickets (iem_shared_*)
   double *h_obj = nullptr;   // pinned + mapped host scalar
   double *d_hobj = nullptr;  // its device address
   std::map<int, void *> d_arrays;  // model array id -> device copy
@@ -178,7 +181,7 @@ int jit_compile(iem_model *m, const std::string &src, const std::string &dir, co
   if (hiprtcCreateProgram(&prog, src.c_str(), "iem_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return fail(IEM_E_COMPILE, "hiprtcCreateProgram failed");
   std::string archopt = "--offload-arch=" + arch;
-  std::string cflag = contract_flag();
+  std::string cflag = contract_flag(m->opt);
   const char *opts[] = {archopt.c_str(), "-O3", cflag.c_str(), "-std=c++17"};
   hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
   if (r != HIPRTC_SUCCESS) {
@@ -208,7 +211,7 @@ int jit_compile(iem_model *m, const std::string &src, const std::string &dir, co
 }
 
 int compile_or_load(iem_model *m) {
-  const std::string src = full_source(m->prog);
+  const std::string src = full_source(m->prog, m->opt);
   const uint64_t key = iem::fnv1a64(src);
   const std::string dir = cache_dir();
   const std::string path = dir + "/iem_" + key_hex(key) + ".hsaco";
@@ -475,38 +478,46 @@ const char *iem_version(void) { return "iem-hip 0.1 (gfx950)"; }
 
 void iem_free(void *p) { std::free(p); }
 
-int iem_set_option(const char *name, int64_t value) {
+static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_t value) {
   if (!name) return fail(IEM_E_ARG, "null option name");
-  if (std::strcmp(name, "store_mode") == 0) { g_opt.store_mode = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "nt_stores") == 0) { g_opt.nt_stores = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "no_fuse") == 0) { g_opt.no_fuse = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "poll_obj") == 0) { g_opt_poll_obj = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "wide_stores") == 0) { g_opt.wide_stores = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "overlap") == 0) { g_opt.overlap = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "xcd_remap") == 0) { g_opt.xcd_remap = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "split_small") == 0) { g_opt.split_small = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "fuse_groups") == 0) { g_opt.fuse_groups = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "fuse_zero") == 0) { g_opt.fuse_zero = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "hess_merge") == 0) { g_opt.hess_merge = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "ablate") == 0) { g_opt.ablate = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "store_mode") == 0) { o.store_mode = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "nt_stores") == 0) { o.nt_stores = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "no_fuse") == 0) { o.no_fuse = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "poll_obj") == 0) { poll_obj = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "wide_stores") == 0) { o.wide_stores = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "overlap") == 0) { o.overlap = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "xcd_remap") == 0) { o.xcd_remap = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "split_small") == 0) { o.split_small = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fuse_groups") == 0) { o.fuse_groups = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fuse_zero") == 0) { o.fuse_zero = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "hess_merge") == 0) { o.hess_merge = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "ablate") == 0) { o.ablate = (int)value; return IEM_OK; }
   if (std::strcmp(name, "block") == 0) {
     if (value < 64 || value > 1024 || value % 64) return fail(IEM_E_ARG, "block must be a multiple of 64 in 64..1024");
-    g_opt.block = (int)value;
+    o.block = (int)value;
     return IEM_OK;
   }
-  if (std::strcmp(name, "lds_slots") == 0) { g_opt.lds_slots = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "reorder") == 0) { g_opt.reorder = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "min_waves") == 0) { g_opt.min_waves = (int)value; return IEM_OK; }
-  if (std::strcmp(name, "fp_contract") == 0) { g_opt.fp_contract = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "lds_slots") == 0) { o.lds_slots = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "reorder") == 0) { o.reorder = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "min_waves") == 0) { o.min_waves = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fp_contract") == 0) { o.fp_contract = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "obj_wgs") == 0) {
+    if (value < 1 || value > 65536) return fail(IEM_E_ARG, "obj_wgs must be in 1..65536");
+    o.obj_wgs = (int)value;
+    return IEM_OK;
+  }
+  if (std::strcmp(name, "det_shared") == 0) { o.det_shared = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
+
+int iem_set_option(const char *name, int64_t value) { return apply_option(g_opt, g_opt_poll_obj, name, value); }
 
 int iem_emit_source(const void *blob, size_t nbytes, char **out_src, uint64_t *out_key) {
   try {
     iem::Model model;
     iem::parse_blob(blob, nbytes, model);
     iem::Program p = iem::generate(model, g_opt);
-    std::string s = full_source(p);
+    std::string s = full_source(p, g_opt);
     if (out_src) {
       *out_src = (char *)std::malloc(s.size() + 1);
       std::memcpy(*out_src, s.c_str(), s.size() + 1);
@@ -526,6 +537,8 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     std::ostringstream os;
     os.precision(17);
     os << "partials " << p.n_partials << "\n";
+    for (int kind = 0; kind < iem::KK_COUNT; ++kind)   // shared-entry reduction buffer of a scatter kind: values x workgroups (+ tickets)
+      if (p.red_values[kind] > 0) os << "reduce " << kind << " " << p.red_values[kind] << " " << p.red_wgs[kind] << "\n";
     for (int kind = 0; kind < iem::KK_COUNT; ++kind)   // ranges the runtime memsets before launching a scatter kind
       for (auto &z : p.zero_ranges[kind]) os << "zero " << kind << " " << z.first << " " << z.second << "\n";
     for (const iem::KernelDesc &kd : p.kernels) {
@@ -581,17 +594,30 @@ int iem_blob_hess_structure(const void *blob, size_t nbytes, int base, int64_t *
 }
 
 int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
-  if (!blob || !out) return fail(IEM_E_ARG, "null argument");
+  return iem_create_opts(blob, nbytes, device, nullptr, 0, out);
+}
+
+int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_option_t *opts, int n_opts, iem_model **out) {
+  if (!blob || !out || n_opts < 0 || (n_opts && !opts)) return fail(IEM_E_ARG, "null argument");
   *out = nullptr;
+  // the handle's options: the process defaults (iem_set_option) with this call's overrides on top
+  iem::Options hopt = g_opt;
+  int hpoll = g_opt_poll_obj;
+  for (int i = 0; i < n_opts; ++i) {
+    int rc = apply_option(hopt, hpoll, opts[i].name, opts[i].value);
+    if (rc) return rc;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(IEM_E_NODEVICE, "no HIP device visible: libiem_hip has no CPU path");
   if (device < 0 || device >= ndev) return fail(IEM_E_ARG, "device ordinal out of range");
   iem_model *m = new iem_model();
   m->device = device;
+  m->opt = hopt;
+  m->poll_obj = hpoll;
   try {
     iem::parse_blob(blob, nbytes, m->model);
-    m->prog = iem::generate(m->model, g_opt);
+    m->prog = iem::generate(m->model, m->opt);
   } catch (const std::exception &e) {
     delete m;
     return fail(IEM_E_BLOB, e.what());
@@ -613,6 +639,13 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
     const size_t words = np + 1 + (np + 31) / 32;
     if (hipMalloc((void **)&m->d_partials, words * 8) != hipSuccess || hipMemset(m->d_partials, 0, words * 8) != hipSuccess)
       return bail(fail(IEM_E_HIP, "hipMalloc partials"));
+  }
+  for (int kind = 0; kind < iem::KK_COUNT; ++kind) {
+    if (m->prog.red_values[kind] <= 0) continue;
+    const size_t nwg = (size_t)m->prog.red_wgs[kind];
+    const size_t words = (size_t)m->prog.red_values[kind] * nwg + 1 + (nwg + 31) / 32;
+    if (hipMalloc((void **)&m->d_red[kind], words * 8) != hipSuccess || hipMemset(m->d_red[kind], 0, words * 8) != hipSuccess)
+      return bail(fail(IEM_E_HIP, "hipMalloc shared-entry reduction buffer"));
   }
   if (hipMalloc((void **)&m->d_obj, 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc obj"));
   if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocMapped) != hipSuccess ||
@@ -652,6 +685,7 @@ int iem_destroy(iem_model *m) {
   if (m->d_theta) hipFree(m->d_theta);
   if (m->d_partials) hipFree(m->d_partials);
   if (m->d_obj) hipFree(m->d_obj);
+  for (double *r : m->d_red) if (r) hipFree(r);
   if (m->h_obj) hipHostFree(m->h_obj);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
   for (void *t : m->d_tables) if (t) hipFree(t);
@@ -770,7 +804,7 @@ int iem_obj(iem_model *m, const double *d_x, double *h_out) {
   int rc = iem_obj_device(m, d_x, m->d_hobj);
   if (rc) return rc;
   bool got = false;
-  if (g_opt_poll_obj) {
+  if (m->poll_obj) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int spin = 0;; ++spin) {
       if (*slot != kSentinel) { got = true; break; }
@@ -788,7 +822,7 @@ int iem_grad(iem_model *m, const double *d_x, double *d_g) {
   DevGuard dg_(m->device);
   for (auto &z : m->grad_zero)   // zero only what the kernels do not overwrite completely
     HIP_TRY(hipMemsetAsync(d_g + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
-  return launch_kind(m, iem::KK_GRAD, d_x, nullptr, d_g, 0.0);
+  return launch_kind(m, iem::KK_GRAD, d_x, nullptr, d_g, 0.0, nullptr, m->d_red[iem::KK_GRAD]);
 }
 
 /* NLPModels.jprod!(m, x, v, Jv) */
@@ -804,7 +838,7 @@ int iem_jtprod(iem_model *m, const double *d_x, const double *d_v, double *d_Jtv
   DevGuard dg_(m->device);
   for (auto &z : m->zero_ranges[iem::KK_JTPROD])
     HIP_TRY(hipMemsetAsync(d_Jtv + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
-  return launch_kind(m, iem::KK_JTPROD, d_x, nullptr, d_Jtv, 0.0, d_v);
+  return launch_kind(m, iem::KK_JTPROD, d_x, nullptr, d_Jtv, 0.0, d_v, m->d_red[iem::KK_JTPROD]);
 }
 
 /* NLPModels.hprod!(m, x, y, v, Hv; obj_weight) */
@@ -813,7 +847,7 @@ int iem_hprod(iem_model *m, const double *d_x, const double *d_y, const double *
   DevGuard dg_(m->device);
   for (auto &z : m->zero_ranges[iem::KK_HPROD])
     HIP_TRY(hipMemsetAsync(d_Hv + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
-  return launch_kind(m, iem::KK_HPROD, d_x, d_y, d_Hv, obj_weight, d_v);
+  return launch_kind(m, iem::KK_HPROD, d_x, d_y, d_Hv, obj_weight, d_v, m->d_red[iem::KK_HPROD]);
 }
 
 int iem_cons(iem_model *m, const double *d_x, double *d_c) {

@@ -155,6 +155,13 @@ class KernelBuilder {
     if (v >= -16 && v <= 16) return std::to_string(v) + "LL";
     return ip(v);
   }
+  // appends raw entries (no de-duplication) and returns the index of the first: tables the device
+  // code walks with a pointer (A.ip + start)
+  size_t ip_block(const std::vector<int64_t> &vals) {
+    const size_t start = ipv_.size();
+    ipv_.insert(ipv_.end(), vals.begin(), vals.end());
+    return start;
+  }
   int dp(double v) {
     uint64_t b; std::memcpy(&b, &v, 8);
     auto it = dp_ids_.find(b);
@@ -812,6 +819,47 @@ class KernelBuilder {
     outs_ = std::move(merged);
   }
 
+  // Deterministic shared-entry reduction of this kernel's kind (grad / jtprod / hprod; grad_mode 3):
+  // filled in by generate() once every slot of the kind is classified.
+  struct SharedInfo {
+    bool on = false;
+    std::vector<std::tuple<int, int, int>> mine;       // (output, slot, value id) parked by THIS kernel
+    int64_t nv_total = 0, n_wg = 0, red_off = 0;        // values / workgroups of the whole call; this kernel's first workgroup
+    std::vector<std::pair<int64_t, int64_t>> owner;     // per value id: {first workgroup, count} that park it
+    std::vector<std::pair<int64_t, std::vector<int>>> dests;   // destination entry (0-based) -> value ids summed into it
+  };
+  void set_shared(const SharedInfo &si) { shared_ = si; }
+  // LDS doubles the reduction needs: park uses NV_mine x waves, the last workgroup NV_total, + the flag
+  int shared_lds_doubles() const {
+    if (!shared_.on) return 0;
+    return (int)std::max<int64_t>((int64_t)shared_.mine.size() * (opt_.block / 64), shared_.nv_total) + 1;
+  }
+  // tables of the last workgroup's epilogue: {ticket offset, n_wg, offs[nv], first[nv], count[nv], ND x {dest, start, cnt}, value ids}
+  static std::vector<int64_t> shared_final_table(const SharedInfo &si) {
+    std::vector<int64_t> t;
+    t.push_back(si.nv_total * si.n_wg);   // ticket words sit behind the parked values
+    t.push_back(si.n_wg);
+    for (int64_t v = 0; v < si.nv_total; ++v) t.push_back(v * si.n_wg);
+    for (auto &o : si.owner) t.push_back(o.first);
+    for (auto &o : si.owner) t.push_back(o.second);
+    int64_t start = 0;
+    for (auto &d : si.dests) { t.push_back(d.first); t.push_back(start); t.push_back((int64_t)d.second.size()); start += (int64_t)d.second.size(); }
+    for (auto &d : si.dests) for (int v : d.second) t.push_back(v);
+    return t;
+  }
+  // `base`: text of the table's first element (e.g. "A.ip + 17"); `wg`: text of the workgroup's id within the call
+  static std::string shared_epilogue(const SharedInfo &si, const std::string &base, const std::string &wg, const std::string &lds, int lds_doubles) {
+    std::ostringstream e;
+    const int64_t nv = si.nv_total, nd = (int64_t)si.dests.size();
+    e << "  { const long long* st_ = " << base << ";\n"
+      << "    if (iem_shared_last(AUX + st_[0], " << wg << ", st_[1], " << lds << " + " << (lds_doubles - 1) << ")) {\n"
+      << "      iem_shared_totals(" << nv << ", AUX, st_ + 2, st_ + " << (2 + nv) << ", st_ + " << (2 + 2 * nv) << ", " << lds << ");\n"
+      << "      iem_shared_write(OUT, " << lds << ", st_ + " << (2 + 3 * nv) << ", st_ + " << (2 + 3 * nv + 3 * nd) << ", " << nd << ");\n"
+      << "    } }\n";
+    return e.str();
+  }
+  const SharedInfo &shared() const { return shared_; }
+
   // gradient store classification (needs every objective slot of the model)
   std::vector<Output> &outputs() { return outs_; }
   const std::vector<IdxVal> &idxvals() const { return idx_; }
@@ -1101,6 +1149,7 @@ class KernelBuilder {
         case KK_GRAD:
           for (size_t s = 0; s < o.vals.size(); ++s) {
             int mode = o.grad_mode[s];
+            if (mode == 3) continue;   // parked below (deterministic shared-entry reduction)
             if (mode == 0) tail << "  if (" << g << ") OUT[i" << o.grad_idx[s] << "] = v" << o.vals[s] << ";\n";
             else if (mode == 1) tail << "  iem_grad_wave_uniform(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
             else tail << "  iem_grad_atomic(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
@@ -1109,8 +1158,30 @@ class KernelBuilder {
       }
     }
     flush_batch();
-    if (kind_ == KK_OBJ)
-      tail << "  iem_block_partial(acc, OUT, A.ip[" << ip_index(kd.partial_off) << "] + (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * (long long)blockIdx.z), lds4, " << ip(n_partials_) << ", AUX);\n";
+    if (kind_ == KK_OBJ) {
+      if (!as_body) throw std::runtime_error("internal: objective bodies are always called from the tile-walking wrapper");
+      tail << "  return acc;\n";
+    }
+    const std::string wg_txt = "(long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * (long long)blockIdx.z)";
+    if (shared_.on && !shared_.mine.empty()) {
+      // this kernel's contributions to entries many items share: one value per lane each, reduced per
+      // workgroup in a fixed order and parked for the last workgroup of the call (iem_device.h)
+      std::vector<int64_t> offs;
+      tail << "  { const double sh_[" << shared_.mine.size() << "] = {";
+      bool first_v = true;
+      for (auto &mv : shared_.mine) {
+        const Output &o = outs_[std::get<0>(mv)];
+        tail << (first_v ? "" : ", ") << "g" << o.guard << " ? v" << o.vals[std::get<1>(mv)] << " : 0.0";
+        first_v = false;
+        offs.push_back((int64_t)std::get<2>(mv) * shared_.n_wg);
+      }
+      const size_t ob = ip_block(offs);
+      tail << "};\n    iem_shared_park<" << shared_.mine.size() << ">(sh_, AUX, A.ip + " << ob << ", " << ip(shared_.red_off) << " + " << wg_txt << ", lds_blk); }\n";
+    }
+    if (shared_.on && !as_body) {
+      const size_t tb = ip_block(shared_final_table(shared_));
+      tail << shared_epilogue(shared_, "A.ip + " + std::to_string(tb), ip(shared_.red_off) + " + " + wg_txt, "lds_blk", shared_lds_doubles());
+    }
 
     // head: coordinates, guards, integer loads, index values, loads
     std::ostringstream head;
@@ -1184,7 +1255,6 @@ class KernelBuilder {
       }
       kd.alg_bytes_read = 8 * (elems + (int64_t)iloads_.size() * g_.ext[0] * g_.ext[1] * g_.ext[2]);
       kd.alg_bytes_written = 8 * alg_w_;
-      if (kind_ == KK_OBJ) kd.alg_bytes_written = 8 * kd.n_blocks;
     }
 
     // assemble
@@ -1195,7 +1265,7 @@ class KernelBuilder {
     // struct carries pointers instead — `A.ip[i]` reads the same either way (uniform scalar loads)
     kd.tables_in_memory = (nip + ndp + nfa + nia) > 320;
     if (as_body) {
-      os << "__device__ __forceinline__ void " << name_ << "_body(const double* __restrict__ X, const double* __restrict__ TH, "
+      os << "__device__ __forceinline__ " << (kind_ == KK_OBJ ? "double " : "void ") << name_ << "_body(const double* __restrict__ X, const double* __restrict__ TH, "
          << "const double* __restrict__ Y, const double* __restrict__ V, double* __restrict__ OUT, const double w_, double* __restrict__ AUX,\n"
          << "    const long long* ip_, const double* dp_, const double* const* FA, const long long* const* IA, double* lds_blk, double* lds4,\n"
          << "    const long long BX_, const long long BY_, const long long BZ_, const long long GX_, const long long GY_, const long long GZ_) {\n";
@@ -1233,7 +1303,10 @@ class KernelBuilder {
       os << "  const long long qb0 = (long long)blockIdx.x * " << qstep_str() << ";\n";
       kd.lds_bytes = opt_.block * budget * 8;
     }
-    if (kind_ == KK_OBJ && !as_body) os << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
+    if (shared_.on) {
+      if (!as_body) os << "  __shared__ double lds_blk[" << shared_lds_doubles() << "];\n";
+      kd.lds_bytes = shared_lds_doubles() * 8;
+    }
     os << head.str() << tail.str() << "}\n\n";
     if (as_body || opt_.xcd_remap) {
       // the body sees LOGICAL workgroup coordinates: of its own grid, decoded by the wrapper
@@ -1263,7 +1336,6 @@ class KernelBuilder {
     return (blk && opt_.overlap && opt_.block >= 256) ? opt_.block - 16 : opt_.block;
   }
   std::string qstep_str() const { return qstep() == opt_.block ? "IEM_TILE" : "(IEM_TILE - 16)"; }
-  void set_n_partials(int64_t n) { n_partials_ = n; }
   void set_zero_fill(const std::vector<std::pair<int64_t, int64_t>> &ranges) { zero_fill_ = ranges; }
 
   int stage_budget(int max_ns, int total_ns) const {
@@ -1304,8 +1376,8 @@ class KernelBuilder {
   std::map<int, int> fa_ids_, ia_ids_;
   std::vector<int> fav_, iav_;
   int64_t alg_w_ = 0, alg_r_loads_ = 0;
-  int64_t n_partials_ = 1;  // KK_OBJ: workgroups of ALL objective kernels of the call (the last one to finish reduces)
   std::vector<std::pair<int64_t, int64_t>> zero_fill_;  // [lo, hi) ranges of OUT this kernel zeroes itself
+  SharedInfo shared_;
   std::map<int, std::vector<std::pair<int64_t, int64_t>>> ranges_;
 };
 
@@ -1456,6 +1528,11 @@ Program generate(const Model &m, const Options &opt) {
   validate_indices(m);
   Program P;
   std::vector<Group> groups = make_groups(m, [&](size_t) { return opt.no_fuse != 0; });
+  // The scatter kinds (grad, J'v, Hv) always keep the lane-fused groups: when several templates add
+  // into the same entry, ONE lane issues those adds in program order (deterministic); side by side
+  // they would come from different workgroups in arrival order.
+  const std::vector<Group> groups_fused = groups;
+  bool split = false;
   if (!opt.no_fuse && opt.split_small > 0 && !opt.hess_merge) {   // the merged Hessian layout is defined on fused lanes
     // A support grid that fills only a fraction of the chip (<= split_small workgroups) is
     // latency-bound: one wave runs the whole fused lane program while most CUs idle.  Its
@@ -1469,7 +1546,7 @@ Program generate(const Model &m, const Options &opt) {
                                 : (g.ext[0] + opt.block - 1) / opt.block * g.ext[1] * g.ext[2];
       if (nb <= opt.split_small) solo.insert(g.tpls.begin(), g.tpls.end());
     }
-    if (!solo.empty()) groups = make_groups(m, [&](size_t ti) { return solo.count(ti) != 0; });
+    if (!solo.empty()) { groups = make_groups(m, [&](size_t ti) { return solo.count(ti) != 0; }); split = true; }
   }
   std::ostringstream src;
   src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";
@@ -1481,12 +1558,14 @@ Program generate(const Model &m, const Options &opt) {
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
 
-  int64_t partial_off = 0;
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    const Group &g = groups[gi];
+  auto is_scatter = [](int kind) { return kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD; };
+  for (int pass = 0; pass < (split ? 2 : 1); ++pass)
+  for (size_t gi = 0; gi < (pass ? groups_fused.size() : groups.size()); ++gi) {
+    const Group &g = pass ? groups_fused[gi] : groups[gi];
     if (!g.flat && ((g.nd > 2 && g.ext[1] > 65535) || g.ext[2] > 65535 || g.ext[1] > 65535LL * 65535LL))
       throw std::runtime_error("support grid too large in dims 2/3 (limit 65535 per dimension for 3-D grids)");
     for (int kind = 0; kind < KK_COUNT; ++kind) {
+      if (split && is_scatter(kind) != (pass == 1)) continue;   // pass 1: the scatter kinds on the fused groups
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
       if (!kb->build(nullptr)) continue;
@@ -1500,7 +1579,6 @@ Program generate(const Model &m, const Options &opt) {
       if (g.flat) { kd.grid[0] = (g.ext[0] * g.ext[1] * g.ext[2] + qs - 1) / qs; kd.grid[1] = kd.grid[2] = 1; }
       if (!g.flat && g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
       kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
-      if (kind == KK_OBJ) { kd.partial_off = partial_off; partial_off += kd.n_blocks; }
       if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {
         auto &outs = kb->outputs();
         for (size_t oi = 0; oi < outs.size(); ++oi) {
@@ -1539,11 +1617,34 @@ Program generate(const Model &m, const Options &opt) {
       descs.push_back(kd);
     }
   }
-  for (auto &kb : builders) kb->set_n_partials(std::max<int64_t>(partial_off, 1));
   bool accumulates[KK_COUNT] = {};
+  // Entries MANY items share (one constant destination: finite / first-stage variables): when every
+  // slot of the kind that can reach the entry is such a constant slot, the entry is reduced
+  // deterministically (grad_mode 3) and written once by the last workgroup of the call.
+  std::vector<int> shared_dest(gslots.size(), 0);   // 1: slot i is a mode-3 slot
+  std::map<int64_t, std::vector<int>> dest_slots[KK_COUNT];
+  if (opt.det_shared)
+    for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
+      std::map<int64_t, std::vector<int>> cand;
+      for (size_t i = 0; i < gslots.size(); ++i)
+        if (gslots[i].kind == kind && gslots[i].pure && gslots[i].lo == gslots[i].hi) cand[gslots[i].lo].push_back((int)i);
+      for (auto &kv : cand) {
+        bool many = false, clean = true;
+        for (int i : kv.second) if (gslots[i].count > 1) many = true;
+        for (size_t j = 0; j < gslots.size() && clean; ++j) {
+          const GSlot &b = gslots[j];
+          if (b.kind != kind || (b.pure && b.lo == b.hi && b.lo == kv.first)) continue;
+          if (!(b.hi < kv.first || b.lo > kv.first)) clean = false;
+        }
+        if (!many || !clean) continue;
+        for (int i : kv.second) shared_dest[i] = 1;
+        dest_slots[kind][kv.first] = kv.second;
+      }
+    }
   // classify gradient slots: exclusive iff injective and its range meets no other slot's range
   for (size_t i = 0; i < gslots.size(); ++i) {
     GSlot &a = gslots[i];
+    if (shared_dest[i]) { builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = 3; continue; }
     int mode = 2;
     if (a.pure && a.injective) {
       bool clash = false;
@@ -1564,6 +1665,36 @@ Program generate(const Model &m, const Options &opt) {
     if (mode == 2 && a.pure && a.uniform0) mode = 1;
     builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;
     if (!(mode == 0 && a.hi - a.lo + 1 == a.count)) accumulates[a.kind] = true;
+  }
+  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
+    if (dest_slots[kind].empty()) continue;
+    KernelBuilder::SharedInfo si;
+    si.on = true;
+    std::map<int, int> vid;   // gslot -> value id
+    std::vector<int> kernel_of;
+    for (size_t i = 0; i < gslots.size(); ++i)
+      if (gslots[i].kind == kind && shared_dest[i]) { vid[(int)i] = (int)kernel_of.size(); kernel_of.push_back(gslots[i].kernel); }
+    si.nv_total = (int64_t)kernel_of.size();
+    std::map<int, int64_t> off_of;   // kernel -> first workgroup of the call
+    for (size_t k = 0; k < descs.size(); ++k)
+      if (descs[k].kind == kind) { off_of[(int)k] = si.n_wg; si.n_wg += descs[k].n_blocks; }
+    for (int k : kernel_of) si.owner.emplace_back(off_of[k], descs[k].n_blocks);
+    for (auto &kv : dest_slots[kind]) {
+      std::vector<int> ids;
+      for (int i : kv.second) ids.push_back(vid[i]);
+      si.dests.emplace_back(kv.first, ids);
+      P.covered[kind].emplace_back(kv.first, kv.first);   // written (not accumulated) by the last workgroup
+    }
+    for (auto &ko : off_of) {
+      KernelBuilder::SharedInfo mine = si;
+      mine.red_off = ko.second;
+      for (size_t i = 0; i < gslots.size(); ++i)
+        if (gslots[i].kind == kind && shared_dest[i] && gslots[i].kernel == ko.first)
+          mine.mine.emplace_back(gslots[i].out, gslots[i].slot, vid[(int)i]);
+      builders[ko.first]->set_shared(mine);
+    }
+    P.red_values[kind] = si.nv_total;
+    P.red_wgs[kind] = si.n_wg;
   }
   // Entries of the scatter outputs (g, Jᵀv, Hv) that no template overwrites completely must be
   // zero before the kernels run.  When NOTHING of a kind accumulates (every slot stores
@@ -1595,11 +1726,14 @@ Program generate(const Model &m, const Options &opt) {
   // (pandemic: t x xi and t; collocation: the node grids), the per-grid bodies become
   // __device__ functions and ONE kernel dispatches on the workgroup id (block-uniform branch,
   // shared LDS, largest grid first so that its workgroups start first).
+  // The objective always takes this form, with a wrapper of its own: at most `obj_wgs` workgroups
+  // WALK the tiles of every body, so there is one partial (and one ticket) per workgroup.
   for (int kind = 0; kind < KK_COUNT; ++kind) {
     std::vector<size_t> ks;
     for (size_t k = 0; k < descs.size(); ++k) if (descs[k].kind == kind) ks.push_back(k);
     if (ks.empty()) continue;
-    if (ks.size() == 1 || !opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2)) {   // fuse_groups = 2: experiments (one launch of per-template bodies)
+    const bool is_obj = kind == KK_OBJ;
+    if (!is_obj && (ks.size() == 1 || !opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2))) {   // fuse_groups = 2: experiments (one launch of per-template bodies)
       for (size_t k : ks) { src << builders[k]->emit(descs[k]); P.kernels.push_back(descs[k]); }
       continue;
     }
@@ -1622,7 +1756,7 @@ Program generate(const Model &m, const Options &opt) {
       F.alg_bytes_read += d.alg_bytes_read; F.alg_bytes_written += d.alg_bytes_written;
     }
     if (F.grid[0] > 2147483647LL) throw std::runtime_error("support grids too large for one launch");
-    F.n_blocks = F.grid[0];
+    const int64_t n_tiles = F.grid[0];
     // workgroup decode table: per body {first workgroup, gx, gy, gz} (launch-size dependent -> arguments)
     const size_t dec = F.ip.size();
     int64_t first = 0;
@@ -1631,8 +1765,31 @@ Program generate(const Model &m, const Options &opt) {
       F.ip.push_back(first); F.ip.push_back(d.grid[0]); F.ip.push_back(d.grid[1]); F.ip.push_back(d.grid[2]);
       first += d.n_blocks;
     }
+    // scatter kinds with shared entries: the last workgroup's tables, and each body's first workgroup of
+    // the call in the numbering the bodies park under (descs order, not the sorted one)
+    const KernelBuilder::SharedInfo *si = nullptr;
+    size_t sh_tbl = 0, sh_off = 0;
+    int sh_lds = 0;
+    for (size_t k : ks) if (builders[k]->shared().on) si = &builders[k]->shared();
+    if (si) {
+      sh_tbl = F.ip.size();
+      const std::vector<int64_t> t = KernelBuilder::shared_final_table(*si);
+      F.ip.insert(F.ip.end(), t.begin(), t.end());
+      sh_off = F.ip.size();
+      for (size_t k : ks) { F.ip.push_back(builders[k]->shared().red_off); sh_lds = std::max(sh_lds, builders[k]->shared_lds_doubles()); }
+      F.lds_bytes = std::max(F.lds_bytes, sh_lds * 8);
+    }
+    size_t nt_slot = 0;
+    if (is_obj) {
+      nt_slot = F.ip.size();
+      F.ip.push_back(n_tiles);
+      F.grid[0] = std::min<int64_t>(n_tiles, std::max(1, opt.obj_wgs));
+      F.alg_bytes_written = 8 * F.grid[0];
+      P.n_partials = F.grid[0];
+    }
+    F.n_blocks = F.grid[0];
     const size_t tbl = F.ip.size();
-    if (ks.size() > 4 && F.grid[0] <= (1 << 18))
+    if (!is_obj && ks.size() > 4 && F.grid[0] <= (1 << 18))
       for (size_t j = 0; j < ks.size(); ++j) F.ip.insert(F.ip.end(), (size_t)descs[ks[j]].n_blocks, (int64_t)j);
     size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
     size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
@@ -1648,15 +1805,36 @@ Program generate(const Model &m, const Options &opt) {
         << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
     if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
     else src << "  double* lds_blk = nullptr;\n";
-    if (kind == KK_OBJ) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
+    if (is_obj) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
     else src << "  double* lds4 = nullptr;\n";
-    src << "  const long long b = blockIdx.x;\n";
     auto call = [&](size_t j, const std::string &ind) {
       std::ostringstream c;
-      c << ind << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
+      c << ind << (is_obj ? "acc += " : "") << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
         << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n";
       return c.str();
     };
+    if (is_obj) {
+      // every lane adds the terms of its tiles b, b + gridDim.x, ... in that order; the body index only grows
+      src << "  double acc = 0.0;\n  int j_ = 0;\n"
+          << "  for (long long b = blockIdx.x; b < A.ip[" << nt_slot << "]; b += gridDim.x) {\n";
+      if (ks.size() > 1)
+        src << "    while (j_ + 1 < " << ks.size() << " && b >= A.ip[" << dec << " + 4 * (j_ + 1)]) ++j_;\n";
+      src << "    const long long gx = A.ip[" << dec << " + 4 * j_ + 1], gy = A.ip[" << dec << " + 4 * j_ + 2], gz = A.ip[" << dec << " + 4 * j_ + 3];\n"
+          << "    const long long lb = b - A.ip[" << dec << " + 4 * j_];\n";
+      if (ks.size() == 1) src << call(0, "    ");
+      else {
+        src << "    switch (j_) {\n";
+        for (size_t j = 0; j < ks.size(); ++j) src << "      case " << j << ":\n" << call(j, "        ") << "        break;\n";
+        src << "    }\n";
+      }
+      src << "  }\n"
+          << "  iem_block_partial(acc, A.out, blockIdx.x, lds4, gridDim.x, A.aux);\n";
+      src << "}\n\n";
+      P.kernels.push_back(F);
+      continue;
+    }
+    src << "  const long long b = blockIdx.x;\n";
+    if (si) src << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; long long wg_ = 0;\n";
     if (ks.size() > 4) {
       // many bodies (one per template on a small grid): binary search of the workgroup id in the
       // table of first workgroups, then a jump table — a chain of 80 compares costs microseconds
@@ -1670,8 +1848,9 @@ Program generate(const Model &m, const Options &opt) {
       src
           << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
           << "  const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)"
-                                                          : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]") << ";\n"
-          << "  switch (lo_) {\n";
+                                                          : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]") << ";\n";
+      if (si) src << "  wg_ = A.ip[" << sh_off << " + lo_] + lb;\n";
+      src << "  switch (lo_) {\n";
       for (size_t j = 0; j < ks.size(); ++j) src << "    case " << j << ":\n" << call(j, "      ") << "      break;\n";
       src << "  }\n";
     } else
@@ -1680,13 +1859,14 @@ Program generate(const Model &m, const Options &opt) {
       src << "  " << (j ? "else " : "");
       if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
       src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-          << "    const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
-          << call(j, "    ") << "  }\n";
+          << "    const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n";
+      if (si) src << "    wg_ = A.ip[" << (sh_off + j) << "] + lb;\n";
+      src << call(j, "    ") << "  }\n";
     }
+    if (si) src << KernelBuilder::shared_epilogue(*si, "A.ip + " + std::to_string(sh_tbl), "wg_", "lds_blk", sh_lds);
     src << "}\n\n";
     P.kernels.push_back(F);
   }
-  P.n_partials = partial_off;
   P.source = src.str();
   P.key = fnv1a64(P.source);
   return P;

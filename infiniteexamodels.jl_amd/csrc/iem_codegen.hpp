@@ -46,6 +46,8 @@ struct Options {
   int fuse_groups = 1; // 1: one launch per call even when its templates live on several support grids (workgroup-id dispatch)
   int fuse_zero = 1;   // 1: scatter kernels zero the untouched output entries themselves when nothing accumulates (no memset launch)
   int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)
+  int obj_wgs = 1024;  // obj: at most this many workgroups walk the tiles (one partial each; fixed, so the summation order is)
+  int det_shared = 1;  // 1: scatter entries shared by many items are reduced deterministically (iem_shared_*), 0: one f64 atomic per wave
 };
 
 // one block of the merged Hessian layout: `nslots` values per item, position o + nslots*k + s;
@@ -67,6 +69,10 @@ struct Program {
   std::vector<std::pair<int64_t, int64_t>> grad_covered;      // KK_GRAD
   std::vector<std::pair<int64_t, int64_t>> covered[KK_COUNT];  // per scatter kind (grad, jtprod, hprod)
   std::vector<std::pair<int64_t, int64_t>> zero_ranges[KK_COUNT];  // [lo, hi) the runtime must memset before launching the kind (empty when fused into a kernel)
+  // deterministic shared-entry reduction of a scatter kind (grad, jtprod, hprod): `red_values` per-lane
+  // values are parked per workgroup of the call (`red_wgs` of them) in a buffer of red_values*red_wgs
+  // doubles + ticket words (zeroed once), passed as the kind's `aux` argument
+  int64_t red_values[KK_COUNT] = {}, red_wgs[KK_COUNT] = {};
 };
 
 Program generate(const Model &m, const Options &opt);

@@ -15,11 +15,13 @@
 //     every line: 4.5 vs 5.6 TB/s, profiles/r01_store_pattern_microbench.txt).  store_mode 1
 //     (iem_store_rows<NS>, wave-private LDS transpose, no barrier) and store_mode 0 (direct
 //     strided stores) remain for A/B runs.  No atomics, no zero-fill pass;
-//   * objective: wave shuffle reduction → LDS → one partial per workgroup; the last workgroup
-//     to finish sums the partials in a fixed order (bitwise reproducible, no second launch);
-//   * gradient entries shared by many items (finite / first-stage variables):
-//     wavefront reduction first, then one f64 atomic per wave; entries nothing writes are
-//     zeroed by the kernel itself (iem_zero_fill) when no slot accumulates.
+//   * objective: a bounded number of workgroups walks the tiles; wave shuffle reduction → LDS → one
+//     partial per workgroup; the last workgroup to finish sums the partials in a fixed order
+//     (bitwise reproducible, no second launch);
+//   * gradient / J'v / Hv entries shared by many items (finite / first-stage variables): the same
+//     scheme per entry (iem_shared_park / iem_shared_totals) — deterministic, no atomics; atomics
+//     remain only for genuinely scattered index maps; entries nothing writes are zeroed by the
+//     kernel itself (iem_zero_fill) when no slot accumulates.
 //
 // wave = 64 lanes on CDNA4; the generated kernels run IEM_TILE (default 512) lanes per workgroup.
 #ifndef IEM_DEVICE_H
@@ -210,18 +212,41 @@ __device__ __forceinline__ double iem_wave_sum(double v) {
   return v;  // lane 0 holds the sum
 }
 
-// Objective: one partial per workgroup; the workgroup that finishes LAST sums all n partials in a
-// fixed order — thread t takes t, t+TILE, …, then the wave shuffle tree, then the waves in order
-// — and writes the scalar.  Which workgroup is last varies from run to run, the summation order
-// does not: bitwise reproducible, and no second launch.  "Last" is decided by two levels of
-// ticket counters behind the partials (T[0] = top, T[1+g] = group g of IEM_TICKET_GROUP
-// workgroups): a single counter serialises ~2000 same-address atomics at 10^6 supports.
-// `lds4` holds IEM_TILE/64 + 1 doubles (the extra one is the "I am last" flag).
+// "Which workgroup of this call finishes last?" — two levels of ticket counters (T[0] = top, T[1+g] =
+// group g of IEM_TICKET_GROUP workgroups; a single counter serialises ~2000 same-address atomics).
+// Called by ONE thread of the workgroup, after the workgroup's hand-off stores (agent-scope
+// write-through stores, each storing thread having waited `vmcnt(0)`, and a workgroup barrier behind
+// them — MI355X_MICROARCH.md "Valid forms", R1) have completed.  The counters reset themselves.
 #define IEM_TICKET_GROUP 32
+__device__ __forceinline__ bool iem_last_arrival(unsigned long long *__restrict__ T, long long slot, long long n) {
+  if (n <= IEM_TICKET_GROUP) {   // one level
+    const bool last = __hip_atomic_fetch_add(T, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n - 1);
+    if (last) __hip_atomic_store(T, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+    return last;
+  }
+  const long long g = slot / IEM_TICKET_GROUP, ng = (n + IEM_TICKET_GROUP - 1) / IEM_TICKET_GROUP;
+  const long long gsize = g + 1 < ng ? IEM_TICKET_GROUP : n - g * IEM_TICKET_GROUP;
+  bool last = false;
+  if (__hip_atomic_fetch_add(T + 1 + g, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(gsize - 1)) {
+    __hip_atomic_store(T + 1 + g, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = __hip_atomic_fetch_add(T, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(ng - 1);
+    if (last) __hip_atomic_store(T, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return last;
+}
+// words behind `n` partials that the tickets need
+#define IEM_TICKET_WORDS(n) (1 + ((n) + IEM_TICKET_GROUP - 1) / IEM_TICKET_GROUP)
+
+// Objective.  The launch has AT MOST a fixed number of workgroups (generator knob obj_wgs): a workgroup
+// walks the tiles b, b + gridDim.x, ... and every lane adds its tiles' terms in that order, so there is
+// ONE partial per workgroup and one block reduction per workgroup however large the model is.  The
+// workgroup that finishes LAST sums the n partials in a fixed order — thread t takes t, t+TILE, ...,
+// then the wave shuffle tree, then the waves in order — and writes the scalar.  Which workgroup is
+// last varies from run to run, the summation order does not: bitwise reproducible, no second launch.
+// `lds4` holds IEM_TILE/64 + 1 doubles (the extra one is the "I am last" flag).
 __device__ __forceinline__ void iem_block_partial(double v, double *__restrict__ partials, long long slot,
                                                   double *__restrict__ lds4, long long n, double *__restrict__ out) {
   constexpr int NW = IEM_TILE / IEM_WAVE;
-  unsigned long long *T = reinterpret_cast<unsigned long long *>(partials + n);
   v = iem_wave_sum(v);
   if (iem_lane() == 0) lds4[iem_wave()] = v;
   __syncthreads();
@@ -229,25 +254,23 @@ __device__ __forceinline__ void iem_block_partial(double v, double *__restrict__
     double acc = lds4[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) acc += lds4[w];
-    // Device-scope (write-through) store of the partial, completion waited for (vmcnt(0) — a
-    // workgroup-scope release fence; an agent-scope fence would write back and invalidate the
-    // whole L2 once per workgroup, measured 3.6x slower at 2000 workgroups), then the tickets.
-    __hip_atomic_store(partials + slot, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    const long long g = slot / IEM_TICKET_GROUP, ng = (n + IEM_TICKET_GROUP - 1) / IEM_TICKET_GROUP;
-    const long long gsize = g + 1 < ng ? IEM_TICKET_GROUP : n - g * IEM_TICKET_GROUP;
-    bool last = false;
-    if (__hip_atomic_fetch_add(T + 1 + g, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(gsize - 1)) {
-      __hip_atomic_store(T + 1 + g, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-      last = __hip_atomic_fetch_add(T, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(ng - 1);
-      if (last) __hip_atomic_store(T, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool last = true;
+    if (n > 1) {
+      // agent-scope (write-through) store of the partial, its completion waited for, then the ticket.
+      // (An agent-scope release FENCE would write back the whole L2 once per workgroup.)
+      __hip_atomic_store(partials + slot, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = iem_last_arrival(reinterpret_cast<unsigned long long *>(partials + n), slot, n);
+    } else {
+      // a one-workgroup launch: no hand-off at all
+      __hip_atomic_store(out, acc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      last = false;
     }
     lds4[NW] = last ? 1.0 : 0.0;
   }
   __syncthreads();
   if (lds4[NW] == 0.0) return;
-  // the partials are read with device-scope loads (they bypass this XCD's L2)
+  // the partials are read with agent-scope loads (they bypass this CU's L1)
   double acc = 0.0;
   for (long long i = threadIdx.x; i < n; i += IEM_TILE)
     acc += __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -261,6 +284,69 @@ __device__ __forceinline__ void iem_block_partial(double v, double *__restrict__
     for (int w = 1; w < NW; ++w) tot += lds4[w];
     // system scope: `out` may be mapped host memory that iem_obj polls for the value
     __hip_atomic_store(out, tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Deterministic sums for output entries that MANY items share (the gradient / J'v / Hv entries of
+// finite and first-stage variables: farmer 3, stochastic OPF 24): instead of one f64 atomic per wave
+// — whose arrival order, hence rounding, changes from run to run — every workgroup of the call
+// reduces its lanes' NV contributions in a fixed order and parks them in `red` (value s of global
+// workgroup w at red[off_s + w]); the workgroup that finishes last (iem_last_arrival) sums each
+// value's column in a fixed order (one wave per value: lane l takes l, l+64, ..., shuffle tree) and
+// leaves the NV totals in lds[0 .. NV) for the generated epilogue, which writes each destination
+// entry once.  Layout of `red`: values, then the ticket words.  `lds`: at least NV*(NW+1)+1 doubles.
+//   step 1 (every workgroup):  iem_shared_park<NV>(v, red, offs, wg, lds)
+//   step 2:                    if (iem_shared_last(red_tickets, wg, n_wg, lds_flag)) { iem_shared_totals<NV>(...); epilogue }
+template <int NV>
+__device__ __forceinline__ void iem_shared_park(const double (&v)[NV], double *__restrict__ red,
+                                                const long long *__restrict__ offs, long long wg,
+                                                double *__restrict__ lds) {
+  constexpr int NW = IEM_TILE / IEM_WAVE;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const double r = iem_wave_sum(v[s]);
+    if (iem_lane() == 0) lds[s * NW + iem_wave()] = r;
+  }
+  __syncthreads();
+  for (int s = (int)threadIdx.x; s < NV; s += IEM_TILE) {
+    double acc = lds[s * NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) acc += lds[s * NW + w];
+    __hip_atomic_store(red + offs[s] + wg, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing thread, before the barrier the ticket sits behind
+  __syncthreads();
+}
+__device__ __forceinline__ bool iem_shared_last(double *__restrict__ tickets, long long wg, long long n_wg,
+                                                double *__restrict__ lds_flag) {
+  if (threadIdx.x == 0)
+    *lds_flag = (n_wg <= 1 || iem_last_arrival(reinterpret_cast<unsigned long long *>(tickets), wg, n_wg)) ? 1.0 : 0.0;
+  __syncthreads();
+  return *lds_flag != 0.0;
+}
+// value s was parked by the workgroups [first[s], first[s] + count[s]) of the call
+__device__ __forceinline__ void iem_shared_totals(int nv, const double *__restrict__ red, const long long *__restrict__ offs,
+                                                  const long long *__restrict__ first, const long long *__restrict__ count,
+                                                  double *__restrict__ lds) {
+  constexpr int NW = IEM_TILE / IEM_WAVE;
+  for (int s = iem_wave(); s < nv; s += NW) {
+    const double *__restrict__ col = red + offs[s] + first[s];
+    double acc = 0.0;
+    for (long long i = iem_lane(); i < count[s]; i += IEM_WAVE)
+      acc += __hip_atomic_load(col + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = iem_wave_sum(acc);
+    if (iem_lane() == 0) lds[s] = acc;
+  }
+  __syncthreads();
+}
+// destination d = {entry, start, cnt}: OUT[entry] = lds[ids[start]] + ... + lds[ids[start + cnt - 1]], written once
+__device__ __forceinline__ void iem_shared_write(double *__restrict__ out, const double *__restrict__ lds,
+                                                 const long long *__restrict__ dst, const long long *__restrict__ ids, int nd) {
+  for (int d = (int)threadIdx.x; d < nd; d += IEM_TILE) {
+    const long long start = dst[3 * d + 1], cnt = dst[3 * d + 2];
+    double acc = lds[ids[start]];
+    for (long long j = 1; j < cnt; ++j) acc += lds[ids[start + j]];
+    out[dst[3 * d]] = acc;
   }
 }
 

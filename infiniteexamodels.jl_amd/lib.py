@@ -32,13 +32,17 @@ class TemplateInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("kind", "n_items", "o0", "o1", "o2", "o1step", "o2step")]
 
 
+class Option(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("value", C.c_int64)]
+
+
 class KernelInfo(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("kind", C.c_int32), ("jit", C.c_int32), ("grid", C.c_int64 * 3),
                 ("lds_bytes", C.c_int64), ("alg_bytes_read", C.c_int64), ("alg_bytes_written", C.c_int64)]
 
 
 # every symbol include/iem.h declares (tests check the export list against the header)
-SYMBOLS = ["iem_create", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
+SYMBOLS = ["iem_create", "iem_create_opts", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
@@ -76,6 +80,7 @@ def lib():
     L.iem_last_error.restype = C.c_char_p
     L.iem_version.restype = C.c_char_p
     L.iem_create.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(vp)]
+    L.iem_create_opts.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(Option), i32, C.POINTER(vp)]
     L.iem_destroy.argtypes = [vp]
     L.iem_meta.argtypes = [vp, C.POINTER(Meta)]
     L.iem_template_info.argtypes = [vp, i64, C.POINTER(TemplateInfo)]
@@ -116,12 +121,25 @@ def set_option(name: str, value: int):
 
 # generator knobs and their defaults (csrc/iem_codegen.hpp: struct Options)
 OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=512, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
-                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0)
+                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1)
+
+
+def option_array(opts: dict):
+    """``iem_option_t[]`` for ``iem_create_opts`` (per-handle generator options)."""
+    unknown = set(opts) - set(OPTION_DEFAULTS)
+    if unknown:
+        raise KeyError(f"unknown generator option(s): {sorted(unknown)}")
+    arr = (Option * max(1, len(opts)))()
+    for i, (k, v) in enumerate(opts.items()):
+        arr[i].name = k.encode()
+        arr[i].value = int(v)
+    return arr, len(opts)
 
 
 class options:
-    """``with options(split_small=0): ...`` — generator knobs for the models created inside the
-    block, defaults restored on exit (the knobs are process-global in the library)."""
+    """``with options(split_small=0): ...`` — PROCESS DEFAULTS of the generator knobs for the models
+    created inside the block, restored on exit.  One model only: ``ExaModel(core, options={...})``
+    (``iem_create_opts``), which leaves the defaults alone."""
 
     def __init__(self, **kw):
         unknown = set(kw) - set(OPTION_DEFAULTS)

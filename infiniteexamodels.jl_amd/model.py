@@ -43,16 +43,18 @@ class ExaModel:
     """Device-resident NLP model built from an :class:`ExaCore`."""
 
     @classmethod
-    def from_blob(cls, blob: bytes, device: int = 0, hess_layout: str = "exa") -> "ExaModel":
+    def from_blob(cls, blob: bytes, device: int = 0, hess_layout: str = "exa", options: Optional[dict] = None) -> "ExaModel":
         """Model from a blob written by any producer of include/iem_blob.h (e.g. the Julia
         writer in julia/MI355XBackend.jl) — no host-side core."""
-        return cls(None, device=device, blob=blob, hess_layout=hess_layout)
+        return cls(None, device=device, blob=blob, hess_layout=hess_layout, options=options)
 
     def __init__(self, core: Optional[ExaCore], device: Optional[int] = None, blob: Optional[bytes] = None,
-                 hess_layout: str = "exa"):
+                 hess_layout: str = "exa", options: Optional[dict] = None):
         """``hess_layout``: ``"exa"`` = ExaModels' COO layout (default, what parity is stated on);
         ``"merged"`` = opt-in layout in which duplicate ``(row, col)`` slots of one support are
-        summed in registers (smaller ``nnzh``; ``hess_structure``/``hess_coord`` stay consistent)."""
+        summed in registers (smaller ``nnzh``; ``hess_structure``/``hess_coord`` stay consistent).
+        ``options``: generator knobs for THIS handle only (``iem_create_opts``); the process
+        defaults (``lib.set_option`` / ``lib.options``) apply to whatever is not named."""
         import torch
 
         if device is None:
@@ -68,11 +70,10 @@ class ExaModel:
             raise ValueError(hess_layout)
         self.hess_layout = hess_layout
         h = C.c_void_p()
-        _lib.set_option("hess_merge", 1 if hess_layout == "merged" else 0)
-        try:
-            _lib.check(self._L.iem_create(blob, len(blob), device, C.byref(h)))
-        finally:
-            _lib.set_option("hess_merge", 0)
+        hopts = dict(options or {})
+        hopts["hess_merge"] = 1 if hess_layout == "merged" else 0
+        arr, n = _lib.option_array(hopts)
+        _lib.check(self._L.iem_create_opts(blob, len(blob), device, arr, n, C.byref(h)))
         self._h = h
         if core is not None:
             core._model = self

@@ -81,6 +81,34 @@ inline void iem_block_partial(double v, double *partials, long long slot, double
   out[0] = tot;
   ticket = 0.0;
 }
+// deterministic shared-entry reduction, one lane at a time: values accumulate in place (the test
+// driver hands a zeroed buffer), the LAST lane of a workgroup takes the ticket, and the workgroup
+// whose ticket completes the count does the whole epilogue from that one lane
+template <int NV>
+inline void iem_shared_park(const double (&v)[NV], double *red, const long long *offs, long long wg, double *) {
+  for (int s = 0; s < NV; ++s) red[offs[s] + wg] += v[s];
+}
+inline bool iem_shared_last(double *tickets, long long, long long n_wg, double *) {
+  if (threadIdx.x != IEM_TILE - 1) return false;
+  tickets[0] += 1.0;
+  if (tickets[0] < (double)n_wg) return false;
+  tickets[0] = 0.0;
+  return true;
+}
+inline void iem_shared_totals(int nv, const double *red, const long long *offs, const long long *first, const long long *count, double *lds) {
+  for (int s = 0; s < nv; ++s) {
+    double acc = 0.0;
+    for (long long i = 0; i < count[s]; ++i) acc += red[offs[s] + first[s] + i];
+    lds[s] = acc;
+  }
+}
+inline void iem_shared_write(double *out, const double *lds, const long long *dst, const long long *ids, int nd) {
+  for (int d = 0; d < nd; ++d) {
+    double acc = 0.0;
+    for (long long j = 0; j < dst[3 * d + 2]; ++j) acc += lds[ids[dst[3 * d + 1] + j]];
+    out[dst[3 * d]] = acc;
+  }
+}
 inline void iem_zero_fill(double *p, long long n, long long b, long long nb) {
   long long chunk = (n + nb - 1) / nb;
   chunk = (chunk + 15) & ~15LL;

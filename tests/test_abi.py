@@ -82,6 +82,15 @@ def test_null_arguments_do_not_crash(built):
     assert L.iem_obj(None, None, None) == -4
     assert L.iem_set_option(b"no_such_option", 1) == -4
     assert L.iem_destroy(None) == 0
+    # per-handle options are validated before anything else happens
+    blob = cases.build_core("quadrotor_5").to_blob()
+    h = C.c_void_p()
+    arr, n = iemlib.option_array({"store_mode": 1})
+    arr[0].name = b"no_such_option"
+    assert L.iem_create_opts(blob, len(blob), 0, arr, n, C.byref(h)) == -4 and not h.value
+    assert b"no_such_option" in L.iem_last_error()
+    with pytest.raises(KeyError):
+        iemlib.option_array({"nope": 1})
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")

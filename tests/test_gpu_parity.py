@@ -353,3 +353,43 @@ def test_corrupt_cached_code_object_is_rebuilt(torch_cuda, tmp_path, monkeypatch
     np.testing.assert_allclose(gm.jac_coord(torch.tensor(x, device="cuda")).cpu().numpy(), om.jac_coord(x), rtol=1e-12, atol=1e-12)
     assert (cache / files[0]).stat().st_size > 1000   # rewritten
     gm.close()
+
+
+def test_two_handles_with_different_options_coexist(torch_cuda):
+    """Per-handle options (iem_create_opts): a merged-Hessian model, a default one and one with the
+    wave-level store path live side by side in one process — no process-global knob decides what a
+    handle generates — and interleaved calls give each handle's own layout."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    core = cases.build_core("quadrotor_1000")
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for("quadrotor_1000", om, 2)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    merged = ExaModel(core, device=0, blob=blob, hess_layout="merged")
+    plain = ExaModel(core, device=0, blob=blob)
+    waves = ExaModel(core, device=0, blob=blob, options={"store_mode": 1, "split_small": 0, "obj_wgs": 3})
+    assert merged.meta.nnzh < plain.meta.nnzh == waves.meta.nnzh == om.nnzh
+    # the process defaults are untouched by any of this
+    src_before, key_before = iemlib.emit_source(blob)
+    for _ in range(2):
+        hm = merged.hess_coord(xd, yd, obj_weight=0.7).cpu().numpy()
+        hp = plain.hess_coord(xd, yd, obj_weight=0.7).cpu().numpy()
+        hw = waves.hess_coord(xd, yd, obj_weight=0.7).cpu().numpy()
+        assert hm.shape[0] == merged.meta.nnzh
+        _close(hp, om.hess_coord(x, y, 0.7), "hess (default handle)")
+        assert np.array_equal(hp, hw)
+        assert abs(waves.obj(xd) - om.obj(x)) <= 1e-10 * max(1.0, abs(om.obj(x)))
+        assert abs(plain.obj(xd) - om.obj(x)) <= 1e-10 * max(1.0, abs(om.obj(x)))
+    r, c = merged.hess_structure()
+    import scipy.sparse as sp
+    ro, co = om.hess_structure()
+    A = sp.coo_matrix((hm, (r, c)), shape=(om.nvar, om.nvar)).tocsr()
+    B = sp.coo_matrix((om.hess_coord(x, y, 0.7), (ro, co)), shape=(om.nvar, om.nvar)).tocsr()
+    d = abs(A - B)
+    assert (d.max() if d.nnz else 0.0) <= 1e-10 * max(1.0, abs(B).max())
+    assert iemlib.emit_source(blob)[1] == key_before
+    for m in (merged, plain, waves):
+        m.close()
