@@ -85,6 +85,62 @@ typedef struct iem_option_t {
   int64_t value;
 } iem_option_t;
 int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_option_t *opts, int n_opts, iem_model **out);
+
+/* ---- multi-GPU: one process (or one handle) per GPU ------------------------------------------
+ * The reference is single-device; its templates are embarrassingly parallel over the supports of
+ * an infinite parameter, so the path shards by support: rank r of `world` owns a
+ * contiguous block of the supports of parameter group `group` (the 1-based group id the blob's grid
+ * hints and slab table use: 1 = the first infinite parameter).  iem_create_sharded takes the GLOBAL
+ * blob — exactly what iem_create takes — and cuts the rank's window in C++ (csrc/iem_shard.hpp): local
+ * x = window slices of the sharded slabs (with the stencil's halo in front) + replicated slabs;
+ * cons!/jac_coord!/hess_coord! then need no communication at all.  Two exchanges remain:
+ *   iem_halo_exchange        before cons!/jac!/hess!: the stencil neighbours  x_k[a_r - 1]
+ *                            (transform.jl:535-557) from the left rank into the halo entries of x
+ *   iem_allreduce_obj_grad   after obj / grad!: the scalar objective and the gradient entries of
+ *                            replicated variables, summed over ranks in rank order (bitwise equal
+ *                            on every rank)
+ * Both are one small kernel that writes straight into the peers' mailboxes (HIP IPC; xGMI between
+ * GPUs) and waits on its own — asynchronous on the handle's stream, graph-replayable, every wait
+ * bounded (iem_comm_status reports a time-out).  Wiring: every rank calls iem_comm_export, the host
+ * all-gathers the IEM_COMM_HANDLE_BYTES-byte handles (MPI / torch.distributed / a pipe — like an
+ * ncclUniqueId), every rank calls iem_comm_connect with all of them in rank order. */
+typedef struct iem_shard_t {
+  int32_t group, rank, world, reserved;
+  int64_t n_global;            /* supports of the sharded group                       */
+  int64_t own_lo, own_n, halo; /* first owned support (global, 0-based), count, halo supports in front */
+  int64_t halo_reach, halo_doubles;
+  int64_t nvar_global, ncon_global, nnzj_global, nnzh_global;
+  int64_t nvar, ncon, nnzj, nnzh, n_templates; /* this rank's shard */
+  int64_t n_shared;            /* replicated variables = gradient entries the all-reduce sums */
+} iem_shard_t;
+/* a local template and where its items sit in the global model: local item coordinate k_d = global
+ * coordinate klo[d] + k_d of the box global_dims; global COO position of local slot s of item k:
+ * global_o1 + o1step * (global ordinal of k) + s  (likewise o2; rows: global_o0 + ordinal) */
+typedef struct iem_shard_template_t {
+  int64_t global_index, kind, n_items;
+  int64_t klo[3], dims[3], global_dims[3];
+  int64_t o0, o1, o2, global_o0, global_o1, global_o2;
+  int64_t o1step, o2step;
+} iem_shard_template_t;
+#define IEM_COMM_HANDLE_BYTES 128
+int iem_create_sharded(const void *blob, size_t nbytes, int device, int group, int rank, int world,
+                       const iem_option_t *opts, int n_opts, iem_model **out);
+int iem_shard_info(const iem_model *m, iem_shard_t *out);
+/* local variable -> global variable (0-based), and per local variable: bit 0 owned by this rank,
+ * bit 1 replicated on every rank, bit 2 halo copy of the left neighbour's variable (either may be NULL) */
+int iem_shard_var_map(const iem_model *m, int64_t *h_map, uint8_t *h_flag);
+int iem_shard_template_info(const iem_model *m, int64_t i, iem_shard_template_t *out);
+/* the cut without a device (tooling / tests): the rank's shard re-serialised as a blob of its own, plus
+ * the maps; every out array is malloc'ed (iem_free), any of the last four may be NULL */
+int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int world, void **out_blob, size_t *out_nbytes,
+                   iem_shard_t *out_info, int64_t **out_var_map, uint8_t **out_var_flag, iem_shard_template_t **out_tpl);
+int iem_comm_export(iem_model *m, void *out_handle /* IEM_COMM_HANDLE_BYTES */);
+int iem_comm_connect(iem_model *m, const void *all_handles /* world x IEM_COMM_HANDLE_BYTES, rank order */);
+int iem_halo_exchange(iem_model *m, double *d_x);
+int iem_allreduce_obj_grad(iem_model *m, double *d_obj /* device scalar, may be NULL */, double *d_g);
+/* synchronises the handle's stream; 0 = every exchange so far completed, else a bit mask of time-outs */
+int iem_comm_status(iem_model *m, int64_t *out_status);
+
 int iem_destroy(iem_model *m);
 int iem_meta(const iem_model *m, iem_meta_t *out);
 int iem_template_info(const iem_model *m, int64_t i, iem_template_info_t *out);

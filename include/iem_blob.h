@@ -12,7 +12,7 @@
  *   word 0            IEM_BLOB_MAGIC
  *   word 1            IEM_BLOB_VERSION
  *   word 2..9         nvar, npar, ncon, n_templates, n_arrays, minimize(0/1),
- *                     total_words, reserved
+ *                     total_words, slab_table_word_offset (0: none)
  *   word 10..13       array ids of x0, lvar, uvar, theta
  *   array table       n_arrays x 6 words {kind, n, data_word_offset, a, b, reserved}
  *                       kind F64_DATA : n doubles at data_word_offset
@@ -21,6 +21,11 @@
  *                       kind I64_RANGE: a + b*j, j = 0..n-1
  *   template table    n_templates x 1 word: word offset of each template record
  *   template records  see below
+ *   slab table        optional (header word 9): n_slabs, then n_slabs x 8 words
+ *                       {offset (0-based), nd, dims[3], group[3]} — the add_var slabs of x in order
+ *                       (transform.jl:113,154), tiling 0..nvar; group[a] = infinite-parameter group
+ *                       (1-based, the same ids the grid hints use) axis a runs over, 0 = none.  Only
+ *                       sharding reads it (iem_create_sharded cuts a rank's support window from it).
  *   array payloads
  *
  * Template record (all words):
@@ -55,6 +60,7 @@
 #define IEM_FIELD_WORDS 6
 #define IEM_NODE_WORDS 4
 #define IEM_TPL_FIXED_WORDS 21
+#define IEM_SLAB_WORDS 8
 
 enum { IEM_A_F64_DATA = 0, IEM_A_I64_DATA = 1, IEM_A_F64_FILL = 2, IEM_A_I64_RANGE = 3 };
 enum { IEM_T_OBJ = 0, IEM_T_CON = 1 };

@@ -135,6 +135,9 @@ class ExaCore:
         self.templates: List[_Template] = []
         self.ncon = 0
         self._model = None  # live device model, for set_parameter!
+        # (offset, dims, infinite-parameter group of each axis; 0 = none) of every add_var slab — the
+        # blob's slab table, from which iem_create_sharded cuts a rank's window (include/iem_blob.h)
+        self.slabs: List[Tuple[int, Tuple[int, ...], Tuple[int, ...]]] = []
 
     # the core buffers (views into the growable storage; element writes go through)
     x0 = property(lambda self: self._bufs["x0"].view)
@@ -157,10 +160,16 @@ class ExaCore:
         for k in ("x0", "lvar", "uvar"):
             self._bufs[k].reserve(int(n))
 
-    def add_var(self, *dims: int, start=0.0, lvar=-np.inf, uvar=np.inf) -> Variable:
+    def add_var(self, *dims: int, start=0.0, lvar=-np.inf, uvar=np.inf, groups=None) -> Variable:
+        """``groups``: the infinite-parameter group (1-based, as in the items' grid hint) each axis of the
+        slab runs over — bookkeeping for sharding only, no effect on evaluation."""
         dims = tuple(int(d) for d in dims) or (1,)
         n = int(np.prod(dims))
         var = Variable(dims, self.nvar)
+        groups = tuple(int(g) for g in groups) if groups is not None else (0,) * len(dims)
+        assert len(groups) == len(dims)
+        if len(dims) <= 3:
+            self.slabs.append((var.offset, dims, groups))
 
         def expand(v):
             a = np.asarray(v, dtype=np.float64)
@@ -376,6 +385,19 @@ class ExaCore:
         for w in tpl_words:
             tpl_off.append(pos)
             pos += len(w)
+        # slab table (optional section, header word 9): present when the recorded slabs tile 0..nvar
+        slab_words: List[int] = []
+        cover = 0
+        for off, dims, groups in self.slabs:
+            if off != cover:
+                break
+            cover += int(np.prod(dims))
+        if self.slabs and cover == self.nvar:
+            slab_words = [len(self.slabs)]
+            for off, dims, groups in self.slabs:
+                slab_words += [off, len(dims)] + list(dims) + [1] * (3 - len(dims)) + list(groups) + [0] * (3 - len(dims))
+        slab_off = pos if slab_words else 0
+        pos += len(slab_words)
         arr_off = []
         for kind, n, payload, a, b in arrays:
             arr_off.append(pos if payload is not None else 0)
@@ -384,12 +406,13 @@ class ExaCore:
         total = pos
 
         head = [BLOB_MAGIC, BLOB_VERSION, self.nvar, self.npar, self.ncon, n_tpl, n_arr,
-                1 if self.minimize else 0, total, 0] + core_ids
+                1 if self.minimize else 0, total, slab_off] + core_ids
         for (kind, n, payload, a, b), off in zip(arrays, arr_off):
             head += [kind, n, off, a, b, 0]
         head += tpl_off
         for w in tpl_words:
             head += w
+        head += slab_words
         parts = [np.asarray(head, dtype=np.int64).tobytes()]
         for kind, n, payload, a, b in arrays:
             if payload is not None:

@@ -25,6 +25,7 @@
 #include "../../include/iem.h"
 #include "iem_codegen.hpp"
 #include "iem_model.hpp"
+#include "iem_shard.hpp"
 
 static const char *kDeviceHeader =
 #include "iem_device_h.inc"
@@ -124,6 +125,18 @@ struct iem_model {
   hipFunction_t fn_struct = nullptr, fn_csr = nullptr;
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *d_red[iem::KK_COUNT] = {};   // per scatter kind: parked shared-entry values + tickets (iem_shared_*)
+  // multi-GPU (iem_create_sharded): what was cut, and the mailbox the peers push into
+  bool sharded = false;
+  iem::ShardInfo shard;
+  hipFunction_t fn_halo = nullptr, fn_reduce = nullptr;
+  unsigned long long *mailbox = nullptr;   // device memory, exported through HIP IPC
+  size_t mailbox_words = 0;
+  bool connected = false;
+  std::vector<unsigned long long *> peers; // peers[r]: rank r's mailbox as mapped here (peers[rank] = mailbox)
+  std::vector<void *> ipc_opened;          // what hipIpcCloseMemHandle must release
+  unsigned long long **d_peers = nullptr;
+  long long *d_halo_src = nullptr, *d_halo_dst = nullptr, *d_shared = nullptr;
+  int64_t n_shared = 0;
   double *h_obj = nullptr;   // pinned + mapped host scalar
   double *d_hobj = nullptr;  // its device address
   std::map<int, void *> d_arrays;  // model array id -> device copy
@@ -232,6 +245,8 @@ int compile_or_load(iem_model *m) {
     HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_allreduce_kernel"));
   return IEM_OK;
 }
 
@@ -472,6 +487,9 @@ void hess_structure_host(const iem::Model &m, int64_t *rows, int64_t *cols, int 
 }  // namespace
 
 extern "C" {
+static int create_impl(const void *blob, size_t nbytes, int device, const iem_option_t *opts, int n_opts, int shard_group,
+                       int rank, int world, iem_model **out);
+
 
 const char *iem_last_error(void) { return g_err.c_str(); }
 const char *iem_version(void) { return "iem-hip 0.1 (gfx950)"; }
@@ -598,6 +616,17 @@ int iem_create(const void *blob, size_t nbytes, int device, iem_model **out) {
 }
 
 int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_option_t *opts, int n_opts, iem_model **out) {
+  return create_impl(blob, nbytes, device, opts, n_opts, 0, 0, 1, out);
+}
+
+int iem_create_sharded(const void *blob, size_t nbytes, int device, int group, int rank, int world,
+                       const iem_option_t *opts, int n_opts, iem_model **out) {
+  if (group < 1) return fail(IEM_E_ARG, "iem_create_sharded: group must be >= 1");
+  return create_impl(blob, nbytes, device, opts, n_opts, group, rank, world, out);
+}
+
+static int create_impl(const void *blob, size_t nbytes, int device, const iem_option_t *opts, int n_opts, int shard_group,
+                       int rank, int world, iem_model **out) {
   if (!blob || !out || n_opts < 0 || (n_opts && !opts)) return fail(IEM_E_ARG, "null argument");
   *out = nullptr;
   // the handle's options: the process defaults (iem_set_option) with this call's overrides on top
@@ -617,6 +646,10 @@ int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_optio
   m->poll_obj = hpoll;
   try {
     iem::parse_blob(blob, nbytes, m->model);
+    if (shard_group > 0) {   // cut this rank's window out of the global model (iem_shard.hpp)
+      iem::shard_model(m->model, shard_group, rank, world, m->shard);
+      m->sharded = true;
+    }
     m->prog = iem::generate(m->model, m->opt);
   } catch (const std::exception &e) {
     delete m;
@@ -686,6 +719,12 @@ int iem_destroy(iem_model *m) {
   if (m->d_partials) hipFree(m->d_partials);
   if (m->d_obj) hipFree(m->d_obj);
   for (double *r : m->d_red) if (r) hipFree(r);
+  for (void *p : m->ipc_opened) hipIpcCloseMemHandle(p);
+  if (m->mailbox) hipFree(m->mailbox);
+  if (m->d_peers) hipFree(m->d_peers);
+  if (m->d_halo_src) hipFree(m->d_halo_src);
+  if (m->d_halo_dst) hipFree(m->d_halo_dst);
+  if (m->d_shared) hipFree(m->d_shared);
   if (m->h_obj) hipHostFree(m->h_obj);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
   for (void *t : m->d_tables) if (t) hipFree(t);
@@ -903,6 +942,240 @@ int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int6
   long long n = n_csr;
   void *args[] = {(void *)&d_seg, (void *)&d_perm, (void *)&d_coo, (void *)&d_csr, (void *)&n};
   HIP_TRY(hipModuleLaunchKernel(m->fn_csr, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
+  return IEM_OK;
+}
+
+
+/* ---- sharding (multi-GPU) ------------------------------------------------------------------- */
+namespace {
+
+void fill_shard_t(const iem::Model &M, const iem::ShardInfo &si, iem_shard_t *o) {
+  std::memset(o, 0, sizeof *o);
+  o->group = si.group; o->rank = si.rank; o->world = si.world;
+  o->n_global = si.n_global; o->own_lo = si.own_lo; o->own_n = si.own_n; o->halo = si.halo;
+  o->halo_reach = si.halo_reach; o->halo_doubles = si.halo_doubles;
+  o->nvar_global = si.nvar_global; o->ncon_global = si.ncon_global; o->nnzj_global = si.nnzj_global; o->nnzh_global = si.nnzh_global;
+  o->nvar = M.nvar; o->ncon = M.ncon; o->nnzj = M.nnzj; o->nnzh = M.nnzh; o->n_templates = (int64_t)M.tpl.size();
+  int64_t ns = 0;
+  for (unsigned char f : si.var_flag) ns += (f & 2) ? 1 : 0;
+  o->n_shared = ns;
+}
+
+void fill_shard_tpl(const iem::Model &M, const iem::ShardInfo &si, size_t i, iem_shard_template_t *o) {
+  const iem::ShardTpl &st = si.tpl[i];
+  const iem::Template &t = M.tpl[i];
+  o->global_index = st.gindex; o->n_items = t.n_items;
+  for (int d = 0; d < 3; ++d) { o->klo[d] = st.klo[d]; o->dims[d] = t.dims[d]; o->global_dims[d] = st.gdims[d]; }
+  o->o0 = t.o0; o->o1 = t.o1; o->o2 = t.o2; o->global_o0 = st.go0; o->global_o1 = st.go1; o->global_o2 = st.go2;
+  o->o1step = t.o1step; o->o2step = t.o2step; o->kind = t.kind;
+}
+
+// mailbox words: see iem_device.h
+size_t mailbox_words(int64_t W, int64_t NH, int64_t NR) { return (size_t)(8 + 2 * W + 2 * NH + 2 * W * NR); }
+
+struct CommHandle {   // what iem_comm_export writes (IEM_COMM_HANDLE_BYTES)
+  hipIpcMemHandle_t ipc;
+  int64_t pid, device, rank, world, words;
+  uint64_t local_ptr;
+};
+static_assert(sizeof(CommHandle) <= IEM_COMM_HANDLE_BYTES, "comm handle too large");
+
+}  // namespace
+
+int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int world, void **out_blob, size_t *out_nbytes,
+                   iem_shard_t *out_info, int64_t **out_var_map, uint8_t **out_var_flag, iem_shard_template_t **out_tpl) {
+  if (!blob || !out_blob || !out_nbytes) return fail(IEM_E_ARG, "null argument");
+  try {
+    iem::Model model;
+    iem::ShardInfo si;
+    iem::parse_blob(blob, nbytes, model);
+    iem::shard_model(model, group, rank, world, si);
+    std::vector<int64_t> w = iem::serialize_model(model);
+    void *b = std::malloc(w.size() * 8);
+    std::memcpy(b, w.data(), w.size() * 8);
+    *out_blob = b; *out_nbytes = w.size() * 8;
+    if (out_info) fill_shard_t(model, si, out_info);
+    if (out_var_map) {
+      *out_var_map = (int64_t *)std::malloc(sizeof(int64_t) * std::max<size_t>(si.var_map.size(), 1));
+      std::memcpy(*out_var_map, si.var_map.data(), si.var_map.size() * 8);
+    }
+    if (out_var_flag) {
+      *out_var_flag = (uint8_t *)std::malloc(std::max<size_t>(si.var_flag.size(), 1));
+      std::memcpy(*out_var_flag, si.var_flag.data(), si.var_flag.size());
+    }
+    if (out_tpl) {
+      *out_tpl = (iem_shard_template_t *)std::malloc(sizeof(iem_shard_template_t) * std::max<size_t>(si.tpl.size(), 1));
+      for (size_t i = 0; i < si.tpl.size(); ++i) fill_shard_tpl(model, si, i, *out_tpl + i);
+    }
+    return IEM_OK;
+  } catch (const std::exception &e) {
+    return fail(IEM_E_BLOB, e.what());
+  }
+}
+
+int iem_shard_info(const iem_model *m, iem_shard_t *out) {
+  if (!m || !out) return fail(IEM_E_ARG, "null argument");
+  if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
+  fill_shard_t(m->model, m->shard, out);
+  return IEM_OK;
+}
+
+int iem_shard_var_map(const iem_model *m, int64_t *h_map, uint8_t *h_flag) {
+  if (!m) return fail(IEM_E_ARG, "null argument");
+  if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
+  if (h_map) std::memcpy(h_map, m->shard.var_map.data(), m->shard.var_map.size() * 8);
+  if (h_flag) std::memcpy(h_flag, m->shard.var_flag.data(), m->shard.var_flag.size());
+  return IEM_OK;
+}
+
+int iem_shard_template_info(const iem_model *m, int64_t i, iem_shard_template_t *out) {
+  if (!m || !out) return fail(IEM_E_ARG, "null argument");
+  if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
+  if (i < 0 || i >= (int64_t)m->shard.tpl.size()) return fail(IEM_E_ARG, "bad template index");
+  fill_shard_tpl(m->model, m->shard, (size_t)i, out);
+  return IEM_OK;
+}
+
+/* ---- mailboxes: halo exchange + the small all-reduce ------------------------------------------ */
+int iem_comm_export(iem_model *m, void *out_handle) {
+  if (!m || !out_handle) return fail(IEM_E_ARG, "null argument");
+  if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
+  DevGuard dg_(m->device);
+  const iem::ShardInfo &si = m->shard;
+  if (si.halo_reach > 0)
+    for (int r = 0; r < si.world; ++r) {   // a stencil must not reach past the neighbouring rank
+      int64_t a, b;
+      iem::partition_block(si.n_global, si.world, r, a, b);
+      if (b - a < si.halo_reach) return fail(IEM_E_ARG, "a rank owns fewer supports than the stencil reaches");
+    }
+  if (!m->mailbox) {
+    int64_t ns = 0;
+    for (unsigned char f : si.var_flag) ns += (f & 2) ? 1 : 0;
+    m->n_shared = ns;
+    m->mailbox_words = mailbox_words(si.world, si.halo_doubles, 1 + ns);
+    void *p = nullptr;
+    // uncached (fine-grained) device memory when the runtime offers it for IPC, plain hipMalloc otherwise
+    if (hipExtMallocWithFlags(&p, m->mailbox_words * 8, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_TRY(hipMalloc(&p, m->mailbox_words * 8));
+    }
+    m->mailbox = (unsigned long long *)p;
+    HIP_TRY(hipMemset(m->mailbox, 0, m->mailbox_words * 8));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  CommHandle h;
+  std::memset(&h, 0, sizeof h);
+  hipError_t e = hipIpcGetMemHandle(&h.ipc, m->mailbox);
+  if (e != hipSuccess) {   // some runtimes refuse IPC on uncached allocations: fall back to a plain one
+    (void)hipGetLastError();
+    hipFree(m->mailbox);
+    m->mailbox = nullptr;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, m->mailbox_words * 8));
+    m->mailbox = (unsigned long long *)p;
+    HIP_TRY(hipMemset(m->mailbox, 0, m->mailbox_words * 8));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipIpcGetMemHandle(&h.ipc, m->mailbox));
+  }
+  h.pid = (int64_t)getpid(); h.device = m->device; h.rank = si.rank; h.world = si.world; h.words = (int64_t)m->mailbox_words;
+  h.local_ptr = (uint64_t)(uintptr_t)m->mailbox;
+  std::memset(out_handle, 0, IEM_COMM_HANDLE_BYTES);
+  std::memcpy(out_handle, &h, sizeof h);
+  return IEM_OK;
+}
+
+int iem_comm_connect(iem_model *m, const void *all_handles) {
+  if (!m || !all_handles) return fail(IEM_E_ARG, "null argument");
+  if (!m->sharded || !m->mailbox) return fail(IEM_E_ARG, "iem_comm_connect: call iem_comm_export on this handle first");
+  if (m->connected) return fail(IEM_E_ARG, "already connected");
+  DevGuard dg_(m->device);
+  const iem::ShardInfo &si = m->shard;
+  m->peers.assign((size_t)si.world, nullptr);
+  for (int r = 0; r < si.world; ++r) {
+    CommHandle h;
+    std::memcpy(&h, (const char *)all_handles + (size_t)r * IEM_COMM_HANDLE_BYTES, sizeof h);
+    if (h.rank != r || h.world != si.world || h.words != (int64_t)m->mailbox_words)
+      return fail(IEM_E_ARG, "iem_comm_connect: handle " + std::to_string(r) + " does not belong to this communicator");
+    if (r == si.rank) { m->peers[r] = m->mailbox; continue; }
+    if (h.pid == (int64_t)getpid()) {   // same process (one process driving several handles): the pointer itself
+      if ((int)h.device != m->device) {
+        hipError_t e = hipDeviceEnablePeerAccess((int)h.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(IEM_E_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+      m->peers[r] = (unsigned long long *)(uintptr_t)h.local_ptr;
+      continue;
+    }
+    void *p = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess));
+    m->ipc_opened.push_back(p);
+    m->peers[r] = (unsigned long long *)p;
+  }
+  HIP_TRY(hipMalloc((void **)&m->d_peers, sizeof(void *) * (size_t)si.world));
+  HIP_TRY(hipMemcpy(m->d_peers, m->peers.data(), sizeof(void *) * (size_t)si.world, hipMemcpyHostToDevice));
+  // halo positions: what goes to the right neighbour (my last `reach` owned supports of every sharded
+  // slab), where the left neighbour's arrive (my first `reach` window entries) — one canonical order
+  std::vector<long long> src, dst;
+  for (const iem::HaloSeg &sg : si.segs)
+    for (int64_t o = 0; o < sg.outer; ++o)
+      for (int64_t j = 0; j < si.halo_reach * sg.inner; ++j) {
+        src.push_back(sg.loff + o * sg.wn * sg.inner + (sg.wn - si.halo_reach) * sg.inner + j);
+        dst.push_back(sg.loff + o * sg.wn * sg.inner + j);
+      }
+  if ((int64_t)src.size() != si.halo_doubles) return fail(IEM_E_ARG, "internal: halo size mismatch");
+  if (!src.empty()) {
+    HIP_TRY(hipMalloc((void **)&m->d_halo_src, src.size() * 8));
+    HIP_TRY(hipMalloc((void **)&m->d_halo_dst, dst.size() * 8));
+    HIP_TRY(hipMemcpy(m->d_halo_src, src.data(), src.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_halo_dst, dst.data(), dst.size() * 8, hipMemcpyHostToDevice));
+  }
+  std::vector<long long> sh;
+  for (size_t i = 0; i < si.var_flag.size(); ++i) if (si.var_flag[i] & 2) sh.push_back((long long)i);
+  if (!sh.empty()) {
+    HIP_TRY(hipMalloc((void **)&m->d_shared, sh.size() * 8));
+    HIP_TRY(hipMemcpy(m->d_shared, sh.data(), sh.size() * 8, hipMemcpyHostToDevice));
+  }
+  m->connected = true;
+  return IEM_OK;
+}
+
+int iem_halo_exchange(iem_model *m, double *d_x) {
+  if (!m || !d_x) return fail(IEM_E_ARG, "null argument");
+  if (!m->connected) return fail(IEM_E_ARG, "iem_halo_exchange: not connected (iem_comm_connect)");
+  const iem::ShardInfo &si = m->shard;
+  if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;   // no stencil crosses the shard boundary
+  DevGuard dg_(m->device);
+  struct { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W; } A = {
+      d_x, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
+      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world};
+  size_t sz = sizeof A;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
+  return IEM_OK;
+}
+
+int iem_allreduce_obj_grad(iem_model *m, double *d_obj, double *d_g) {
+  if (!m) return fail(IEM_E_ARG, "null argument");
+  if (!m->connected) return fail(IEM_E_ARG, "iem_allreduce_obj_grad: not connected (iem_comm_connect)");
+  if (!d_g && m->n_shared) return fail(IEM_E_ARG, "null gradient but the model has replicated variables");
+  DevGuard dg_(m->device);
+  const iem::ShardInfo &si = m->shard;
+  struct { double *obj, *g; const long long *shared; unsigned long long *const *peers; long long NR, NH, W, rank; } A = {
+      d_obj, d_g, m->d_shared, m->d_peers, (long long)(1 + m->n_shared), (long long)si.halo_doubles, (long long)si.world, (long long)si.rank};
+  size_t sz = sizeof A;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_reduce, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
+  return IEM_OK;
+}
+
+int iem_comm_status(iem_model *m, int64_t *out_status) {
+  if (!m || !out_status) return fail(IEM_E_ARG, "null argument");
+  if (!m->mailbox) return fail(IEM_E_ARG, "no mailbox");
+  DevGuard dg_(m->device);
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  unsigned long long st = 0;
+  HIP_TRY(hipMemcpy(&st, m->mailbox, 8, hipMemcpyDeviceToHost));
+  *out_status = (int64_t)st;
   return IEM_OK;
 }
 

@@ -425,4 +425,138 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum(const
   csr[i] = acc;
 }
 
+// ---- multi-GPU: halo exchange and the one small all-reduce of the path --------------------------
+// One process per GPU; every rank owns a MAILBOX in its HBM that its peers map through HIP IPC
+// (iem_comm_export / iem_comm_connect).  Both kernels PUSH: a rank writes its few doubles straight
+// into the peer's mailbox (over xGMI when the peer is another GPU), then a sequence flag; the peer
+// spins on its OWN memory.  One-shot, latency-bound — never a ring (the payload is 8*(1+n_shared)
+// bytes for the all-reduce, 8*reach doubles per sharded slab for the halo).  All traffic is
+// system-scope (write-through stores, cache-bypassing loads); data is ordered before its flag by
+// vmcnt(0) on every storing thread, a workgroup barrier and a system release fence.  Every wait is
+// bounded (IEM_COMM_TIMEOUT ticks of the 100 MHz wall clock): on expiry the kernel records an error
+// in the mailbox's status word and RUNS ON — no wave ever spins forever.  Sequence numbers live in
+// the mailbox and are advanced by the kernels themselves, so both calls can be graph-replayed.
+//
+// mailbox words (8 bytes each):   [0] status  [1] halo seq  [2] all-reduce seq  [3] halo ack (from the right)
+//   [4,6) halo flags (from the left, one per parity)   [8, 8+2W) all-reduce flags [parity][peer]
+//   then halo data [2][NH] and all-reduce data [2][W][NR]     (W = world, NH, NR as passed)
+#define IEM_COMM_TIMEOUT 500000000LL   // 5 s
+#define IEM_MB_STATUS 0
+#define IEM_MB_HSEQ 1
+#define IEM_MB_RSEQ 2
+#define IEM_MB_HACK 3
+#define IEM_MB_HFLAG 4
+#define IEM_MB_RFLAG 8
+__device__ __forceinline__ long long iem_mb_hdata(long long W) { return IEM_MB_RFLAG + 2 * W; }
+__device__ __forceinline__ long long iem_mb_rdata(long long W, long long NH) { return IEM_MB_RFLAG + 2 * W + 2 * NH; }
+__device__ __forceinline__ unsigned long long iem_sys_load(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void iem_sys_store(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double iem_sys_loadd(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void iem_sys_stored(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// bounded wait until *p >= want; false (and the status bit set) on time-out
+__device__ __forceinline__ bool iem_wait_ge(const unsigned long long *p, unsigned long long want, unsigned long long *status,
+                                            unsigned long long err_bit) {
+  const long long t0 = wall_clock64();
+  while (iem_sys_load(p) < want) {
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - t0 > IEM_COMM_TIMEOUT) {
+      __hip_atomic_fetch_or(status, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+  }
+  return true;
+}
+// publish: every thread's data stores have been issued; make them visible, then raise the flags
+__device__ __forceinline__ void iem_publish_fence() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+struct IemHaloArgs {
+  double *x;
+  unsigned long long *mine, *left, *right;   // mailboxes (left / right: nullptr at the ends of the chain)
+  const long long *src, *dst;                // NH positions of x each: what goes right, where the left's arrive
+  long long NH, W;
+};
+// one workgroup: (1) my last `reach` owned supports of every sharded slab -> the right neighbour's
+// mailbox, (2) the left neighbour's -> the halo entries of my x (reference stencil:
+// /root/reference/src/transform.jl:535-557, index i-1 at :471-506)
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const IemHaloArgs A) {
+  const unsigned long long seq = iem_sys_load(A.mine + IEM_MB_HSEQ) + 1;
+  const long long par = (long long)(seq & 1);
+  __shared__ int ok_;
+  if (A.right != nullptr) {
+    if (threadIdx.x == 0)   // the slot of this parity was last used by seq - 2: the right neighbour must have consumed it
+      ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_HACK, seq - 2, A.mine + IEM_MB_STATUS, 1ULL);
+    __syncthreads();
+    double *data = reinterpret_cast<double *>(A.right + iem_mb_hdata(A.W)) + par * A.NH;
+    for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) iem_sys_stored(data + e, A.x[A.src[e]]);
+    iem_publish_fence();
+    if (threadIdx.x == 0) iem_sys_store(A.right + IEM_MB_HFLAG + par, seq);
+  }
+  if (A.left != nullptr) {
+    if (threadIdx.x == 0) {
+      ok_ = iem_wait_ge(A.mine + IEM_MB_HFLAG + par, seq, A.mine + IEM_MB_STATUS, 2ULL);
+      __threadfence_system();
+    }
+    __syncthreads();
+    const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_hdata(A.W)) + par * A.NH;
+    if (ok_)
+      for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.x[A.dst[e]] = iem_sys_loadd(data + e);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) iem_sys_store(A.left + IEM_MB_HACK, seq);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) iem_sys_store(A.mine + IEM_MB_HSEQ, seq);
+}
+
+struct IemReduceArgs {
+  double *obj, *g;                    // in/out: the scalar objective (device) and the gradient
+  const long long *shared;            // NR - 1 positions of g held by every rank (replicated variables)
+  unsigned long long *const *peers;   // W mailboxes, peers[rank] = mine
+  long long NR, NH, W, rank;
+};
+// one workgroup: my NR doubles -> slot [rank] of EVERY rank's mailbox; wait for the W flags in mine;
+// sum the W slots in rank order (the same order on every rank: identical bits everywhere) and write
+// the sums back.  SURVEY 8(e): "one small all-reduce per obj / grad!" — one-shot direct writes.
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_allreduce_kernel(const IemReduceArgs A) {
+  unsigned long long *mine = A.peers[A.rank];
+  const unsigned long long seq = iem_sys_load(mine + IEM_MB_RSEQ) + 1;
+  const long long par = (long long)(seq & 1);
+  const long long base = iem_mb_rdata(A.W, A.NH) + (par * A.W + A.rank) * A.NR;
+  for (long long e = threadIdx.x; e < A.NR; e += IEM_BLOCK) {
+    const double v = e == 0 ? (A.obj ? *A.obj : 0.0) : A.g[A.shared[e - 1]];
+    for (long long p = 0; p < A.W; ++p) iem_sys_stored(reinterpret_cast<double *>(A.peers[p] + base) + e, v);
+  }
+  iem_publish_fence();
+  if (threadIdx.x == 0)
+    for (long long p = 0; p < A.W; ++p) iem_sys_store(A.peers[p] + IEM_MB_RFLAG + par * A.W + A.rank, seq);
+  __shared__ int ok_;
+  if (threadIdx.x == 0) ok_ = 1;
+  __syncthreads();
+  for (long long p = threadIdx.x; p < A.W; p += IEM_BLOCK)
+    if (!iem_wait_ge(mine + IEM_MB_RFLAG + par * A.W + p, seq, mine + IEM_MB_STATUS, 4ULL)) ok_ = 0;
+  __threadfence_system();
+  __syncthreads();
+  if (ok_) {
+    const double *slots = reinterpret_cast<const double *>(mine + iem_mb_rdata(A.W, A.NH)) + par * A.W * A.NR;
+    for (long long e = threadIdx.x; e < A.NR; e += IEM_BLOCK) {
+      double acc = iem_sys_loadd(slots + e);
+      for (long long p = 1; p < A.W; ++p) acc += iem_sys_loadd(slots + p * A.NR + e);
+      if (e == 0) { if (A.obj) *A.obj = acc; } else A.g[A.shared[e - 1]] = acc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) iem_sys_store(mine + IEM_MB_RSEQ, seq);
+}
+
 #endif  // IEM_DEVICE_H

@@ -74,6 +74,7 @@ struct Template {
   int kind = 0, nd = 1;
   int64_t n_items = 0, dims[3] = {1, 1, 1};
   int64_t grid_id = -1, origin[3] = {0, 0, 0};
+  bool lattice_recovered = false;   // box and grid hint synthesised by recover_lattice (no real group ids)
   int root = 0;
   std::vector<FieldDesc> ifields, ffields;
   std::vector<IdxExpr> idx;
@@ -88,8 +89,17 @@ struct Template {
   std::vector<int> slot2_i, slot2_j;      // slot -> idx ids (unswapped)
 };
 
+// one add_var slab of x: `dims` (first index fastest) starting at 0-based `off`; `group[a]` = the
+// infinite-parameter group axis a runs over (0: none) — the blob's optional slab table (header word 9)
+struct Slab {
+  int64_t off = 0, dims[3] = {1, 1, 1};
+  int nd = 1, group[3] = {0, 0, 0};
+  int64_t length() const { return dims[0] * dims[1] * dims[2]; }
+};
+
 struct Model {
   std::vector<int64_t> blob;  // owned copy
+  std::vector<Slab> slabs;    // empty when the producer wrote no slab table
   int64_t nvar = 0, npar = 0, ncon = 0, nnzj = 0, nnzh = 0;
   int minimize = 1;
   int arr_x0 = 0, arr_lvar = 0, arr_uvar = 0, arr_theta = 0;
@@ -261,6 +271,7 @@ inline void recover_lattice(Model &m, Template &t) {
     m.arrs.push_back(a);
   }
   t.ifields = nif; t.ffields = nff;
+  t.lattice_recovered = true;
   t.nd = 2; t.dims[0] = n0; t.dims[1] = n1; t.dims[2] = 1;
   if (coord[0] >= 0 && coord[1] >= 0) {   // both grid coordinates are item fields: fusable on the recovered grid
     t.grid_id = 2 * 4096 + 1;
@@ -398,6 +409,28 @@ inline void parse_blob(const void *blob, size_t nbytes, Model &m) {
   }
   if (o0 != m.ncon) throw std::runtime_error("ncon does not match the constraint templates");
   m.nnzj = o1; m.nnzh = o2;
+  if (w[9] != 0) {   // optional slab table: n, then n x {off, nd, dims[3], group[3]}; must tile 0..nvar
+    if (w[9] < IEM_HDR_WORDS || w[9] >= total) throw std::runtime_error("slab table offset out of range");
+    const int64_t *sw = w + w[9];
+    const int64_t ns = sw[0];
+    if (ns < 0 || ns > total || w[9] + 1 + IEM_SLAB_WORDS * ns > total) throw std::runtime_error("slab table overruns blob");
+    int64_t cover = 0;
+    m.slabs.resize(ns);
+    for (int64_t i = 0; i < ns; ++i) {
+      const int64_t *q = sw + 1 + IEM_SLAB_WORDS * i;
+      Slab &sl = m.slabs[i];
+      sl.off = q[0]; sl.nd = (int)q[1];
+      if (q[1] < 1 || q[1] > 3) throw std::runtime_error("bad slab rank");
+      for (int d = 0; d < 3; ++d) {
+        sl.dims[d] = q[2 + d]; sl.group[d] = (int)q[5 + d];
+        if (sl.dims[d] < 0 || sl.dims[d] > IEM_MAX_COUNT || (d >= sl.nd && sl.dims[d] != 1) || q[5 + d] < 0 || q[5 + d] > 4094)
+          throw std::runtime_error("bad slab record");
+      }
+      if ((__int128)sl.dims[0] * sl.dims[1] * sl.dims[2] > (__int128)IEM_MAX_COUNT || sl.off != cover) throw std::runtime_error("slab table does not tile the variables");
+      cover += sl.length();
+    }
+    if (cover != m.nvar) throw std::runtime_error("slab table does not tile the variables");
+  }
 }
 
 }  // namespace iem

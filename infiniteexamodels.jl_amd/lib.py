@@ -36,13 +36,38 @@ class Option(C.Structure):
     _fields_ = [("name", C.c_char_p), ("value", C.c_int64)]
 
 
+class ShardT(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("group", "rank", "world", "reserved")] + \
+               [(n, C.c_int64) for n in ("n_global", "own_lo", "own_n", "halo", "halo_reach", "halo_doubles", "nvar_global",
+                                         "ncon_global", "nnzj_global", "nnzh_global", "nvar", "ncon", "nnzj", "nnzh",
+                                         "n_templates", "n_shared")]
+
+    def asdict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+class ShardTemplate(C.Structure):
+    _fields_ = [("global_index", C.c_int64), ("kind", C.c_int64), ("n_items", C.c_int64), ("klo", C.c_int64 * 3),
+                ("dims", C.c_int64 * 3), ("global_dims", C.c_int64 * 3)] + \
+               [(n, C.c_int64) for n in ("o0", "o1", "o2", "global_o0", "global_o1", "global_o2", "o1step", "o2step")]
+
+    def asdict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        return {k: (tuple(int(x) for x in v) if hasattr(v, "__len__") else int(v)) for k, v in d.items()}
+
+
+COMM_HANDLE_BYTES = 128
+
+
 class KernelInfo(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("kind", C.c_int32), ("jit", C.c_int32), ("grid", C.c_int64 * 3),
                 ("lds_bytes", C.c_int64), ("alg_bytes_read", C.c_int64), ("alg_bytes_written", C.c_int64)]
 
 
 # every symbol include/iem.h declares (tests check the export list against the header)
-SYMBOLS = ["iem_create", "iem_create_opts", "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
+SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_info", "iem_shard_var_map", "iem_shard_template_info",
+           "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_allreduce_obj_grad", "iem_comm_status",
+           "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
@@ -81,6 +106,17 @@ def lib():
     L.iem_version.restype = C.c_char_p
     L.iem_create.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(vp)]
     L.iem_create_opts.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(Option), i32, C.POINTER(vp)]
+    L.iem_create_sharded.argtypes = [C.c_char_p, C.c_size_t, i32, i32, i32, i32, C.POINTER(Option), i32, C.POINTER(vp)]
+    L.iem_shard_info.argtypes = [vp, C.POINTER(ShardT)]
+    L.iem_shard_var_map.argtypes = [vp, vp, vp]
+    L.iem_shard_template_info.argtypes = [vp, i64, C.POINTER(ShardTemplate)]
+    L.iem_shard_blob.argtypes = [C.c_char_p, C.c_size_t, i32, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(ShardT),
+                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.iem_comm_export.argtypes = [vp, vp]
+    L.iem_comm_connect.argtypes = [vp, vp]
+    L.iem_halo_exchange.argtypes = [vp, vp]
+    L.iem_allreduce_obj_grad.argtypes = [vp, vp, vp]
+    L.iem_comm_status.argtypes = [vp, C.POINTER(C.c_int64)]
     L.iem_destroy.argtypes = [vp]
     L.iem_meta.argtypes = [vp, C.POINTER(Meta)]
     L.iem_template_info.argtypes = [vp, i64, C.POINTER(TemplateInfo)]
@@ -212,6 +248,28 @@ def blob_hess_structure(blob: bytes, base: int = 0):
         L.iem_free(r)
         L.iem_free(c)
     return rows, cols
+
+
+def shard_blob(blob: bytes, group: int, rank: int, world: int):
+    """``iem_shard_blob``: rank ``rank``'s shard of a GLOBAL blob, cut in C++ without a device —
+    ``(local blob, info dict, var_map, var_flag, [template dicts])``."""
+    import numpy as np
+    L = lib()
+    ob, on, info = C.c_void_p(), C.c_size_t(), ShardT()
+    vm, vf, tp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(L.iem_shard_blob(blob, len(blob), group, rank, world, C.byref(ob), C.byref(on), C.byref(info),
+                           C.byref(vm), C.byref(vf), C.byref(tp)))
+    try:
+        local = C.string_at(ob, on.value)
+        n = int(info.nvar)
+        var_map = np.ctypeslib.as_array(C.cast(vm, C.POINTER(C.c_int64)), shape=(max(n, 1),))[:n].copy()
+        var_flag = np.ctypeslib.as_array(C.cast(vf, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+        tarr = C.cast(tp, C.POINTER(ShardTemplate))
+        tpl = [tarr[i].asdict() for i in range(int(info.n_templates))]
+    finally:
+        for p in (ob, vm, vf, tp):
+            L.iem_free(p)
+    return local, info.asdict(), var_map, var_flag, tpl
 
 
 def precompile(blob: bytes, arch: str = "gfx950", force: bool = False, defer: list = None) -> str:

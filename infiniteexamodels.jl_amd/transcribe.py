@@ -186,7 +186,7 @@ def _add_infinite_variables(core: ExaCore, data: ExaMappingData, m: InfiniteMode
         group_idxs = vref.group_idxs
         dims = tuple(len(data.base_itrs[g - 1]) for g in group_idxs)
         lb, ub, start = _get_variable_bounds_and_start(vref.info, m, group_idxs, dims)
-        data.infvar_mappings[vref] = core.add_var(*dims, start=start, lvar=lb, uvar=ub)
+        data.infvar_mappings[vref] = core.add_var(*dims, start=start, lvar=lb, uvar=ub, groups=group_idxs)
         data.infvar_slabs.append((data.infvar_mappings[vref], list(group_idxs)))
 
 

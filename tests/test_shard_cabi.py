@@ -1,0 +1,137 @@
+"""The sharded C-ABI on CPU: `iem_shard_blob` (the device-free face of `iem_create_sharded`) cuts a
+rank's shard out of the GLOBAL blob in C++ (csrc/iem_shard.hpp).  Checked two ways:
+
+* against the Python transcriber's shards (shard.py re-transcribes the model statement over the
+  rank's support window): the two local models must evaluate bit for bit alike — values, structure,
+  bounds, starts — and number their variables alike;
+* against the global model: shard results, placed with the maps the C-ABI itself reports
+  (`iem_shard_var_map`, `iem_shard_template_info`), reassemble the global cons / jac / hess bit for
+  bit, every row and COO slot owned exactly once.
+Evaluation by the CPU oracle: this tests the cut, not the kernels."""
+import numpy as np
+import pytest
+
+from infiniteexamodels.jl_amd import lib as iemlib
+from infiniteexamodels.jl_amd import shard, transcribe, workloads
+from pyoracle import OracleModel
+
+CASES = [("quadrotor", 37, 3, 1), ("quadrotor", 64, 2, 1), ("quadrotor", 11, 8, 1), ("farmer", 23, 4, 1),
+         ("pandemic", (9, 7), 3, 2), ("opf", 13, 8, 1), ("pandemic", (9, 7), 7, 2)]
+
+
+def _global(name, size):
+    mk = {"quadrotor": lambda: workloads.quadrotor(size), "farmer": lambda: workloads.farmer(size),
+          "opf": lambda: workloads.opf(size), "pandemic": lambda: workloads.pandemic(*size)}[name] if name != "pandemic" else \
+        (lambda: workloads.pandemic(*size))
+    data = transcribe.ExaMappingData()
+    return transcribe.exa_core(mk(), data), data
+
+
+def _py_shard(name, size, r, world):
+    if name == "quadrotor":
+        return shard.quadrotor_shard(size, r, world)[0]
+    if name == "farmer":
+        return shard.farmer_shard(size, r, world)[0]
+    if name == "opf":
+        return shard.opf_shard(size, r, world)[0]
+    return shard.pandemic_shard(size[0], size[1], r, world)[0]
+
+
+def _point(om, name, seed=0):
+    x = om.x0 + 0.1 * np.random.default_rng(seed).standard_normal(om.nvar)
+    if name not in ("quadrotor", "opf"):
+        x = np.abs(x) + 0.05
+    return x, np.random.default_rng(seed + 1).standard_normal(om.ncon)
+
+
+def _ordinals(t):
+    """global item ordinal of every local item of a shard template (item order)."""
+    k0, k1, k2 = (np.arange(n) for n in t["dims"])
+    g0, g1, g2 = t["global_dims"]
+    o = (t["klo"][0] + k0)[None, None, :] + g0 * ((t["klo"][1] + k1)[None, :, None] + g1 * (t["klo"][2] + k2)[:, None, None])
+    return o.reshape(-1)
+
+
+@pytest.mark.parametrize("name,size,world,group", CASES)
+def test_cxx_cut_equals_python_shards_and_reassembles(name, size, world, group, built):
+    gcore, gdata = _global(name, size)
+    gblob = gcore.to_blob()
+    G = OracleModel(gblob)
+    xg, yg = _point(G, name)
+    ref = dict(c=G.cons(xg), j=G.jac_coord(xg), h=G.hess_coord(xg, yg, 0.7), g=G.grad(xg), f=G.obj(xg))
+    jr, jc = G.jac_structure()
+    hr, hc = G.hess_structure()
+    c = np.full(G.ncon, np.nan); j = np.full(G.nnzj, np.nan); h = np.full(G.nnzh, np.nan)
+    seen_c = np.zeros(G.ncon, int); seen_j = np.zeros(G.nnzj, int); seen_h = np.zeros(G.nnzh, int)
+    owned = np.zeros(G.nvar, int)
+    f = 0.0
+    for r in range(world):
+        lblob, info, vmap, vflag, tpl = iemlib.shard_blob(gblob, group, r, world)
+        L = OracleModel(lblob)
+        assert (info["nvar"], info["ncon"], info["nnzj"], info["nnzh"]) == (L.nvar, L.ncon, L.nnzj, L.nnzh)
+        assert (info["nvar_global"], info["ncon_global"], info["nnzj_global"], info["nnzh_global"]) == (G.nvar, G.ncon, G.nnzj, G.nnzh)
+        # --- equal to the Python transcriber's shard, bit for bit -------------------------------
+        pcore = _py_shard(name, size, r, world)
+        P = OracleModel(pcore.to_blob())
+        assert (P.nvar, P.ncon, P.nnzj, P.nnzh) == (L.nvar, L.ncon, L.nnzj, L.nnzh)
+        maps = shard.ShardMaps(pcore, gcore, pcore._shard_spec, pcore._shard_data, gdata)
+        assert np.array_equal(maps.var_map, vmap)
+        assert np.array_equal(maps.replicated, (vflag & 2) != 0) and np.array_equal(maps.var_owned, (vflag & 1) != 0)
+        assert info["n_shared"] == int(maps.replicated.sum())
+        for arr in ("x0", "lvar", "uvar", "lcon", "ucon"):
+            np.testing.assert_array_equal(getattr(L, arr), getattr(P, arr))
+        x, y = xg[vmap], None
+        for a, b in ((L.jac_structure(), P.jac_structure()), (L.hess_structure(), P.hess_structure())):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # --- reassembly through the C-ABI's own maps ------------------------------------------------
+        row_map = np.full(L.ncon, -1)
+        jpos = np.full(L.nnzj, -1)
+        hpos = np.full(L.nnzh, -1)
+        for t in tpl:
+            k = _ordinals(t)
+            assert k.size == t["n_items"]
+            if t["kind"] == 1:
+                row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
+                if t["o1step"]:
+                    jpos[t["o1"]:t["o1"] + k.size * t["o1step"]] = (t["global_o1"] + t["o1step"] * k[:, None] + np.arange(t["o1step"])[None, :]).reshape(-1)
+            if t["o2step"]:
+                hpos[t["o2"]:t["o2"] + k.size * t["o2step"]] = (t["global_o2"] + t["o2step"] * k[:, None] + np.arange(t["o2step"])[None, :]).reshape(-1)
+        assert (row_map >= 0).all() and (jpos >= 0).all() and (hpos >= 0).all()
+        assert np.array_equal(row_map, maps.row_map)
+        y = yg[row_map]
+        assert np.array_equal(L.cons(x), P.cons(x)) and np.array_equal(L.jac_coord(x), P.jac_coord(x))
+        assert np.array_equal(L.hess_coord(x, y, 0.7), P.hess_coord(x, y, 0.7)) and np.array_equal(L.grad(x), P.grad(x))
+        assert L.obj(x) == P.obj(x)
+        c[row_map] = L.cons(x); seen_c[row_map] += 1
+        j[jpos] = L.jac_coord(x); seen_j[jpos] += 1
+        h[hpos] = L.hess_coord(x, y, 0.7); seen_h[hpos] += 1
+        f += L.obj(x)
+        owned[vmap[(vflag & 1) != 0]] += 1
+        lr, lc = L.jac_structure()
+        assert np.array_equal(row_map[lr], jr[jpos]) and np.array_equal(vmap[lc], jc[jpos])
+        lr, lc = L.hess_structure()
+        a, b = vmap[lr], vmap[lc]
+        assert np.array_equal(np.maximum(a, b), hr[hpos]) and np.array_equal(np.minimum(a, b), hc[hpos])
+    assert (seen_c == 1).all() and (seen_j == 1).all() and (seen_h == 1).all()
+    assert (owned == 1).all(), "every global variable is owned by exactly one rank"
+    assert np.array_equal(c, ref["c"]) and np.array_equal(j, ref["j"]) and np.array_equal(h, ref["h"])
+    assert abs(f - ref["f"]) <= 1e-12 * max(1.0, abs(ref["f"]))
+
+
+def test_unsupported_inputs_fail_loudly(built):
+    import cases
+    L = iemlib.lib()
+    g = cases.build_core("irregular").to_blob()          # explicit index columns on the sharded group
+    with pytest.raises(iemlib.IemError):
+        iemlib.shard_blob(g, 1, 0, 2)
+    q = cases.build_core("quadrotor_oc3_40").to_blob()   # collocation: stencil over element/node boxes, not backward differences
+    with pytest.raises(iemlib.IemError):
+        iemlib.shard_blob(q, 1, 1, 2)
+    q = cases.build_core("quadrotor_5").to_blob()
+    for bad in ((1, 2, 2), (1, -1, 2), (0, 0, 2), (7, 0, 2), (1, 0, 9)):   # rank/world/group out of range, more ranks than supports
+        with pytest.raises(iemlib.IemError):
+            iemlib.shard_blob(q, *bad)
+    w = np.frombuffer(bytearray(q), dtype=np.int64).copy()
+    w[9] = 0                                              # no slab table
+    with pytest.raises(iemlib.IemError):
+        iemlib.shard_blob(w.tobytes(), 1, 0, 2)
