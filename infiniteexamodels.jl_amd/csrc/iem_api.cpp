@@ -525,6 +525,7 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
     return IEM_OK;
   }
   if (std::strcmp(name, "det_shared") == 0) { o.det_shared = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "obj_unroll") == 0) { o.obj_unroll = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
 

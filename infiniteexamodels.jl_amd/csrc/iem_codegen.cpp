@@ -81,7 +81,7 @@ enum { U_SGN = 1000 };
 // ---------------------------------------------------------------------------
 // expression DAG
 // ---------------------------------------------------------------------------
-enum VOp { VC = 0, VDP = 1, VLD = 2, VUN = 3, VBIN = 4, VW = 5, VSEL = 6 };
+enum VOp { VC = 0, VDP = 1, VLD = 2, VUN = 3, VBIN = 4, VW = 5, VSEL = 6, VGUARD = 7 };   // VGUARD: guard[sub] ? a : 0
 
 struct VNode {
   int op, sub, a, b, c;
@@ -759,7 +759,76 @@ class KernelBuilder {
       for (int &v : o.vals) if (v < 0) v = C(0.0);
       outs_.push_back(std::move(o));
     }
+    if (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD) merge_scatter();
     return !outs_.empty();
+  }
+
+  // Scatter kinds: slots of DIFFERENT templates of this kernel that hit the same destination from
+  // the same lane (identical index value: x7[i] is read by six quadrotor templates) are summed in
+  // registers, in template order, and leave through ONE slot — the one whose item box contains
+  // the others (their values masked by their own guards).  One store or one atomic per lane and
+  // entry instead of several: what remains for an entry is at most the adds of DIFFERENT lanes
+  // (a backward-difference neighbour: two addends, whose order cannot change the sum).
+  void merge_scatter() {
+    std::map<int, std::vector<std::pair<int, int>>> by_dest;   // destination IdxVal id -> (output, slot)
+    for (size_t oi = 0; oi < outs_.size(); ++oi) {
+      if (outs_[oi].scalar) continue;
+      for (size_t s = 0; s < outs_[oi].grad_idx.size(); ++s)
+        if (idx_[outs_[oi].grad_idx[s]].ind.empty()) by_dest[outs_[oi].grad_idx[s]].emplace_back((int)oi, (int)s);
+    }
+    for (auto &kv : by_dest) {
+      auto &parts = kv.second;
+      if (parts.size() < 2) continue;
+      auto inside = [&](const Output &a, const Output &h) {
+        for (int d = 0; d < 3; ++d) if (a.qlo[d] < h.qlo[d] || a.qhi[d] > h.qhi[d]) return false;
+        return true;
+      };
+      int host = -1;   // the part whose box contains every other part's
+      for (size_t c = 0; c < parts.size() && host < 0; ++c) {
+        bool all = true;
+        for (auto &p : parts) if (!inside(outs_[p.first], outs_[parts[c].first])) all = false;
+        if (all) host = (int)c;
+      }
+      if (host < 0) continue;
+      const Output &H = outs_[parts[host].first];
+      int acc = -1;
+      for (auto &p : parts) {
+        const Output &o = outs_[p.first];
+        int v = o.vals[p.second];
+        if (o.guard != H.guard) v = mk(VGUARD, o.guard, v, -1, -1, 0);
+        acc = acc < 0 ? v : add(acc, v);
+      }
+      for (size_t c = 0; c < parts.size(); ++c) {
+        Output &o = outs_[parts[c].first];
+        if ((int)c == host) o.vals[parts[c].second] = acc;
+        else o.grad_mode[parts[c].second] = -1;   // folded into the host slot
+      }
+    }
+    // single-item templates (point constraints x_k(0) == 0) run on the lane of grid point 0: fold their
+    // contribution into the slot of that lane that hits the same entry
+    for (size_t oi = 0; oi < outs_.size(); ++oi) {
+      if (!outs_[oi].scalar) continue;
+      for (size_t s = 0; s < outs_[oi].grad_idx.size(); ++s) {
+        const IdxVal &iv = idx_[outs_[oi].grad_idx[s]];
+        if (!iv.ind.empty() || outs_[oi].grad_mode[s] < 0) continue;
+        for (size_t hj = 0; hj < outs_.size(); ++hj) {
+          Output &h = outs_[hj];
+          if (h.scalar) continue;
+          bool has0 = true;
+          for (int d = 0; d < 3; ++d) if (h.qlo[d] > 0 || h.qhi[d] < 1) has0 = false;
+          if (!has0) continue;
+          bool done_ = false;
+          for (size_t hs = 0; hs < h.grad_idx.size() && !done_; ++hs) {
+            const IdxVal &hv = idx_[h.grad_idx[hs]];
+            if (h.grad_mode[hs] < 0 || !hv.ind.empty() || hv.aff.c != iv.aff.c) continue;
+            h.vals[hs] = add(h.vals[hs], mk(VGUARD, outs_[oi].guard, outs_[oi].vals[s], -1, -1, 0));
+            outs_[oi].grad_mode[s] = -1;
+            done_ = true;
+          }
+          if (done_) break;
+        }
+      }
+    }
   }
 
   // Opt-in merged Hessian layout: templates of this kernel that cover the same lanes form a
@@ -905,7 +974,7 @@ class KernelBuilder {
       const VNode &c = v_[cur];
       if (phase == 0) {
         phase = 1;
-        if (c.op == VUN) { if (!done[c.a]) st.emplace_back(c.a, 0); }
+        if (c.op == VUN || c.op == VGUARD) { if (!done[c.a]) st.emplace_back(c.a, 0); }
         else if (c.op == VBIN) { if (!done[c.b]) st.emplace_back(c.b, 0); if (!done[c.a]) st.emplace_back(c.a, 0); }
         else if (c.op == VSEL) { if (!done[c.b]) st.emplace_back(c.b, 0); if (!done[c.a]) st.emplace_back(c.a, 0); }
         continue;
@@ -937,6 +1006,7 @@ class KernelBuilder {
       case VDP: os << "  const double " << nm << " = A.dp[" << n.sub << "];\n"; break;
       case VW: os << "  const double " << nm << " = A.w;\n"; break;
       case VLD: os << "  const double " << nm << " = l" << n.sub << ";\n"; break;
+      case VGUARD: os << "  const double " << nm << " = g" << n.sub << " ? v" << n.a << " : 0.0;\n"; break;
       case VSEL: {
         const auto &pr = sels_[n.sub];
         os << "  const double " << nm << " = (i" << pr.first << " == i" << pr.second << ") ? v" << n.a << " : v" << n.b << ";\n";
@@ -982,7 +1052,7 @@ class KernelBuilder {
       if (live[c]) continue;
       live[c] = 1;
       const VNode &n = v_[c];
-      if (n.op == VUN) st.push_back(n.a);
+      if (n.op == VUN || n.op == VGUARD) st.push_back(n.a);
       else if (n.op == VBIN || n.op == VSEL) { st.push_back(n.a); st.push_back(n.b); }
     }
   }
@@ -992,7 +1062,9 @@ class KernelBuilder {
   std::string emit(KernelDesc &kd, bool as_body = false) {
     std::ostringstream body;
     std::vector<char> live(v_.size(), 0), done(v_.size(), 0);
-    for (auto &o : outs_) for (int v : o.vals) mark_live(v, live);
+    for (auto &o : outs_)
+      for (size_t s = 0; s < o.vals.size(); ++s)
+        if (o.grad_mode.size() != o.vals.size() || o.grad_mode[s] >= 0) mark_live(o.vals[s], live);   // not the slots merge_scatter folded away
     // which idx values must exist as variables: load positions (all), output positions, grad idx, sel operands
     std::set<int> need_idx;
     for (auto &l : loads_) need_idx.insert(l.idxval);
@@ -1078,7 +1150,8 @@ class KernelBuilder {
       auto &o = outs_[oi];
       const Template &t = m_.tpl[o.tpl];
       tail << "  // template " << o.tpl << " (" << (t.kind == IEM_T_OBJ ? "objective" : "constraint") << ", " << o.vals.size() << " value(s))\n";
-      for (int v : o.vals) emit_val(v, tail, done, live);
+      for (size_t s = 0; s < o.vals.size(); ++s)
+        if (o.grad_mode.size() != o.vals.size() || o.grad_mode[s] >= 0) emit_val(o.vals[s], tail, done, live);
       std::string g = "g" + std::to_string(o.guard);
       switch (kind_) {
         case KK_JPROD:
@@ -1149,7 +1222,7 @@ class KernelBuilder {
         case KK_GRAD:
           for (size_t s = 0; s < o.vals.size(); ++s) {
             int mode = o.grad_mode[s];
-            if (mode == 3) continue;   // parked below (deterministic shared-entry reduction)
+            if (mode == 3 || mode < 0) continue;   // parked below (deterministic shared-entry reduction) / folded into another slot
             if (mode == 0) tail << "  if (" << g << ") OUT[i" << o.grad_idx[s] << "] = v" << o.vals[s] << ";\n";
             else if (mode == 1) tail << "  iem_grad_wave_uniform(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
             else tail << "  iem_grad_atomic(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
@@ -1585,6 +1658,7 @@ Program generate(const Model &m, const Options &opt) {
           const Template &t = m.tpl[outs[oi].tpl];
           bool scalar = std::find(g.scalars.begin(), g.scalars.end(), outs[oi].tpl) != g.scalars.end();
           for (size_t s = 0; s < outs[oi].grad_idx.size(); ++s) {
+            if (outs[oi].grad_mode[s] < 0) continue;   // folded into another slot (merge_scatter)
             const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
             GSlot gs{kind, (int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
             if (gs.pure) {
@@ -1821,7 +1895,17 @@ Program generate(const Model &m, const Options &opt) {
         src << "    while (j_ + 1 < " << ks.size() << " && b >= A.ip[" << dec << " + 4 * (j_ + 1)]) ++j_;\n";
       src << "    const long long gx = A.ip[" << dec << " + 4 * j_ + 1], gy = A.ip[" << dec << " + 4 * j_ + 2], gz = A.ip[" << dec << " + 4 * j_ + 3];\n"
           << "    const long long lb = b - A.ip[" << dec << " + 4 * j_];\n";
-      if (ks.size() == 1) src << call(0, "    ");
+      if (ks.size() == 1 && opt.obj_unroll > 1) {
+        // one body: two tiles per trip (b and b + gridDim.x) so that the second tile's loads are in flight
+        // while the first is summed; a tile index past the end decodes to a workgroup column outside the
+        // grid, where every lane's guard is false and the body adds 0
+        src << call(0, "    ")
+            << "    { const long long b2 = b + gridDim.x; const bool in2 = b2 < A.ip[" << nt_slot << "];\n"
+            << "      const long long lb2 = b2 - A.ip[" << dec << " + 4 * j_];\n"
+            << "      acc += " << descs[ks[0]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[0] << ", A.dp + " << odp[0] << ", A.fa + " << ofa[0]
+            << ", A.ia + " << oia[0] << ", lds_blk, lds4, in2 ? lb2 % gx : gx, in2 ? (lb2 / gx) % gy : 0, in2 ? lb2 / (gx * gy) : 0, gx, gy, gz);\n"
+            << "      b += gridDim.x; }\n";
+      } else if (ks.size() == 1) src << call(0, "    ");
       else {
         src << "    switch (j_) {\n";
         for (size_t j = 0; j < ks.size(); ++j) src << "      case " << j << ":\n" << call(j, "        ") << "        break;\n";

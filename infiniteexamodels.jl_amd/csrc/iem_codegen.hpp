@@ -47,6 +47,7 @@ struct Options {
   int fuse_zero = 1;   // 1: scatter kernels zero the untouched output entries themselves when nothing accumulates (no memset launch)
   int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)
   int obj_wgs = 1024;  // obj: at most this many workgroups walk the tiles (one partial each; fixed, so the summation order is)
+  int obj_unroll = 1;  // 2: the objective's tile walk takes two tiles per trip (single-body kernels)
   int det_shared = 1;  // 1: scatter entries shared by many items are reduced deterministically (iem_shared_*), 0: one f64 atomic per wave
 };
 

@@ -48,8 +48,17 @@ class ExaModel:
         writer in julia/MI355XBackend.jl) — no host-side core."""
         return cls(None, device=device, blob=blob, hess_layout=hess_layout, options=options)
 
+    @classmethod
+    def sharded(cls, blob: bytes, group: int, rank: int, world: int, device: int = 0, hess_layout: str = "exa",
+                options: Optional[dict] = None) -> "ExaModel":
+        """Rank ``rank``'s shard of the GLOBAL ``blob`` (``iem_create_sharded``): the window over the
+        supports of infinite-parameter group ``group`` is cut inside the library.  ``shard_info()``,
+        ``shard_var_map()`` and ``shard_templates()`` say what this rank holds; ``comm_export`` /
+        ``comm_connect`` wire the ranks' mailboxes for ``halo_exchange`` and ``allreduce_obj_grad``."""
+        return cls(None, device=device, blob=blob, hess_layout=hess_layout, options=options, _shard=(int(group), int(rank), int(world)))
+
     def __init__(self, core: Optional[ExaCore], device: Optional[int] = None, blob: Optional[bytes] = None,
-                 hess_layout: str = "exa", options: Optional[dict] = None):
+                 hess_layout: str = "exa", options: Optional[dict] = None, _shard=None):
         """``hess_layout``: ``"exa"`` = ExaModels' COO layout (default, what parity is stated on);
         ``"merged"`` = opt-in layout in which duplicate ``(row, col)`` slots of one support are
         summed in registers (smaller ``nnzh``; ``hess_structure``/``hess_coord`` stay consistent).
@@ -73,7 +82,10 @@ class ExaModel:
         hopts = dict(options or {})
         hopts["hess_merge"] = 1 if hess_layout == "merged" else 0
         arr, n = _lib.option_array(hopts)
-        _lib.check(self._L.iem_create_opts(blob, len(blob), device, arr, n, C.byref(h)))
+        if _shard is None:
+            _lib.check(self._L.iem_create_opts(blob, len(blob), device, arr, n, C.byref(h)))
+        else:
+            _lib.check(self._L.iem_create_sharded(blob, len(blob), device, _shard[0], _shard[1], _shard[2], arr, n, C.byref(h)))
         self._h = h
         if core is not None:
             core._model = self
@@ -258,6 +270,57 @@ class ExaModel:
 
     def synchronize(self):
         _lib.check(self._L.iem_synchronize(self._h))
+
+    # ---- sharding / multi-GPU ------------------------------------------------------
+    def shard_info(self) -> dict:
+        t = _lib.ShardT()
+        _lib.check(self._L.iem_shard_info(self._h, C.byref(t)))
+        return t.asdict()
+
+    def shard_var_map(self):
+        """``(local -> global variable, flags)``; flag bit 0 owned here, bit 1 replicated, bit 2 halo copy."""
+        vm = np.zeros(max(self.meta.nvar, 1), dtype=np.int64)
+        vf = np.zeros(max(self.meta.nvar, 1), dtype=np.uint8)
+        _lib.check(self._L.iem_shard_var_map(self._h, vm.ctypes.data, vf.ctypes.data))
+        return vm[:self.meta.nvar], vf[:self.meta.nvar]
+
+    def shard_templates(self):
+        out = []
+        for i in range(self.meta.n_templates):
+            t = _lib.ShardTemplate()
+            _lib.check(self._L.iem_shard_template_info(self._h, i, C.byref(t)))
+            out.append(t.asdict())
+        return out
+
+    def comm_export(self) -> bytes:
+        buf = C.create_string_buffer(_lib.COMM_HANDLE_BYTES)
+        _lib.check(self._L.iem_comm_export(self._h, buf))
+        return buf.raw
+
+    def comm_connect(self, handles: bytes) -> None:
+        """``handles``: every rank's ``comm_export()`` concatenated in rank order."""
+        _lib.check(self._L.iem_comm_connect(self._h, handles))
+
+    def halo_exchange(self, x):
+        """Fill the halo entries of the local ``x`` from the left neighbour (and send mine right);
+        asynchronous on the current stream."""
+        self._chk(x, self.meta.nvar, "x")
+        self._sync_stream()
+        _lib.check(self._L.iem_halo_exchange(self._h, _ptr(x)))
+        return x
+
+    def allreduce_obj_grad(self, obj_dev, g):
+        """Sum the device scalar ``obj_dev`` and the replicated entries of ``g`` over the ranks, in place."""
+        if g is not None:
+            self._chk(g, self.meta.nvar, "g")
+        self._sync_stream()
+        _lib.check(self._L.iem_allreduce_obj_grad(self._h, _ptr(obj_dev), _ptr(g)))
+        return obj_dev, g
+
+    def comm_status(self) -> int:
+        st = C.c_int64()
+        _lib.check(self._L.iem_comm_status(self._h, C.byref(st)))
+        return int(st.value)
 
     def time_kernels(self, x, y, jac, hess, iters: int = 20):
         """Average device time (ms) of one jac_coord! and one hess_coord! call, HIP events

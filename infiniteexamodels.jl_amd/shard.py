@@ -242,6 +242,19 @@ def replicated_indices(core: ExaCore) -> np.ndarray:
     return np.concatenate(out).astype(np.int64) if out else np.zeros(0, dtype=np.int64)
 
 
+def connect_mailboxes(gm, dist=None) -> None:
+    """Wire the ranks' mailboxes (``iem_comm_export`` → all-gather of the 128-byte handles over the
+    host process group, like an ncclUniqueId → ``iem_comm_connect``); afterwards
+    ``gm.halo_exchange`` / ``gm.allreduce_obj_grad`` run without torch.distributed."""
+    if dist is None:
+        import torch.distributed as dist
+    mine = gm.comm_export()
+    handles = [None] * dist.get_world_size()
+    dist.all_gather_object(handles, mine)
+    gm.comm_connect(b"".join(handles))
+    dist.barrier()
+
+
 def allreduce_obj_grad_device(obj_dev, grad_dev, shared_idx_dev, buf, dist=None):
     """Device-resident form of :func:`allreduce_obj_grad` (no host round trip, stream-ordered):
     ``obj_dev`` is a 1-element tensor (``ExaModel.obj_device``), ``buf`` a preallocated

@@ -1,0 +1,148 @@
+"""Worker of tests/test_gpu_comm.py: one process per rank, all ranks on cuda:0 (the one-GPU
+rehearsal of the multi-GPU path).  Each rank owns only its slice of a DISTRIBUTED x: halo entries
+arrive through iem_halo_exchange, the objective and the replicated gradient entries are summed by
+iem_allreduce_obj_grad (mailboxes over HIP IPC, no torch.distributed on the data path — gloo only
+moves the 128-byte handles and gathers results for checking)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from infiniteexamodels.jl_amd import shard, transcribe, workloads
+from infiniteexamodels.jl_amd.model import ExaModel
+
+
+def build_global(name, size):
+    if name == "quadrotor":
+        return transcribe.exa_core(workloads.quadrotor(size[0]))
+    if name == "farmer":
+        return transcribe.exa_core(workloads.farmer(size[0]))
+    if name == "opf":
+        return transcribe.exa_core(workloads.opf(size[0]))
+    return transcribe.exa_core(workloads.pandemic(size[0], size[1]))
+
+
+def ordinals(t):
+    k0, k1, k2 = (np.arange(n) for n in t["dims"])
+    g0, g1, _ = t["global_dims"]
+    o = (t["klo"][0] + k0)[None, None, :] + g0 * ((t["klo"][1] + k1)[None, :, None] + g1 * (t["klo"][2] + k2)[:, None, None])
+    return o.reshape(-1)
+
+
+def main():
+    name, group = sys.argv[1], int(sys.argv[2])
+    size = tuple(int(v) for v in sys.argv[3].split("x"))
+    use_graph = len(sys.argv) > 4 and sys.argv[4] == "graph"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    opts = {"split_small": 0}
+    gcore = build_global(name, size)
+    gblob = gcore.to_blob()
+    gm = ExaModel.sharded(gblob, group, rank, world, device=0, options=opts)
+    info = gm.shard_info()
+    assert (info["rank"], info["world"]) == (rank, world)
+    shard.connect_mailboxes(gm, dist)
+    vm, vf = gm.shard_var_map()
+    halo, repl, owned = (vf & 4) != 0, (vf & 2) != 0, (vf & 1) != 0
+    tpl = gm.shard_templates()
+    row_map = np.full(gm.meta.ncon, -1)
+    jpos = np.full(gm.meta.nnzj, -1)
+    hpos = np.full(gm.meta.nnzh, -1)
+    for t in tpl:
+        k = ordinals(t)
+        if t["kind"] == 1:
+            row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
+            if t["o1step"]:
+                jpos[t["o1"]:t["o1"] + k.size * t["o1step"]] = (t["global_o1"] + t["o1step"] * k[:, None] + np.arange(t["o1step"])[None, :]).reshape(-1)
+        if t["o2step"]:
+            hpos[t["o2"]:t["o2"] + k.size * t["o2step"]] = (t["global_o2"] + t["o2step"] * k[:, None] + np.arange(t["o2step"])[None, :]).reshape(-1)
+    if rank == 0:
+        from pyoracle import OracleModel
+        G = ExaModel(gcore, device=0, blob=gblob, options=opts)      # the unsharded model on the same GPU
+        O = OracleModel(gblob)
+    nvg, ncg = info["nvar_global"], info["ncon_global"]
+    xd = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    yd = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
+    f = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    c = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
+    jv = torch.empty(gm.meta.nnzj, dtype=torch.float64, device="cuda")
+    hv = torch.empty(gm.meta.nnzh, dtype=torch.float64, device="cuda")
+    fpre = torch.zeros(1, dtype=torch.float64, device="cuda")
+    gpre = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+
+    def loop():
+        gm.halo_exchange(xd)
+        gm.cons(xd, c); gm.jac_coord(xd, jv); gm.hess_coord(xd, yd, hv, obj_weight=0.7)
+        gm.obj_device(xd, f); gm.grad(xd, g)
+        fpre.copy_(f); gpre.copy_(g)
+        gm.allreduce_obj_grad(f, g)
+
+    graph = None
+    for it in range(5):
+        rng = np.random.default_rng(100 + it)
+        xg = np.concatenate([np.zeros(0), 0.3 + 0.1 * rng.standard_normal(nvg)])
+        if name not in ("quadrotor", "opf"):
+            xg = np.abs(xg) + 0.05
+        yg = np.random.default_rng(200 + it).standard_normal(ncg)
+        xl = xg[vm].copy()
+        xl[halo] = np.nan                                  # this rank does NOT hold its neighbour's values
+        xd.copy_(torch.tensor(xl)); yd.copy_(torch.tensor(yg[row_map]))
+        for out in (c, jv, hv, g):
+            out.fill_(float("nan"))
+        if use_graph and it >= 2:
+            if graph is None:                              # iterations 0, 1 ran eagerly (warm-up); capture once, replay after
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    loop()
+            graph.replay()
+        else:
+            loop()
+        torch.cuda.synchronize()
+        assert gm.comm_status() == 0, "a mailbox wait timed out"
+        assert np.array_equal(xd.cpu().numpy(), xg[vm]), "halo entries did not arrive"
+        res = dict(c=c.cpu().numpy(), j=jv.cpu().numpy(), h=hv.cpu().numpy(), fpre=fpre.item(), fpost=f.item(),
+                   gpre=gpre.cpu().numpy()[repl], gpost=g.cpu().numpy()[repl], gown=g.cpu().numpy()[owned & ~repl],
+                   own_idx=vm[owned & ~repl], repl_idx=vm[repl], row_map=row_map, jpos=jpos, hpos=hpos)
+        allres = [None] * world if rank == 0 else None
+        dist.gather_object(res, allres, dst=0)
+        if rank == 0:
+            xgd, ygd = torch.tensor(xg, device="cuda"), torch.tensor(yg, device="cuda")
+            cg, jg, hg = (np.full(n, np.nan) for n in (G.meta.ncon, G.meta.nnzj, G.meta.nnzh))
+            gg = np.full(nvg, np.nan)
+            for r in allres:
+                cg[r["row_map"]] = r["c"]; jg[r["jpos"]] = r["j"]; hg[r["hpos"]] = r["h"]
+                gg[r["own_idx"]] = r["gown"]
+                gg[r["repl_idx"]] = r["gpost"]
+            # the reassembled shard results ARE the one-GPU results, bit for bit
+            assert np.array_equal(cg, G.cons(xgd).cpu().numpy()), "cons"
+            assert np.array_equal(jg, G.jac_coord(xgd).cpu().numpy()), "jac"
+            assert np.array_equal(hg, G.hess_coord(xgd, ygd, obj_weight=0.7).cpu().numpy()), "hess"
+            # ... and agree with the oracle on the GLOBAL model
+            for got, ref, what in ((cg, O.cons(xg), "cons"), (jg, O.jac_coord(xg), "jac"), (hg, O.hess_coord(xg, yg, 0.7), "hess"), (gg, O.grad(xg), "grad")):
+                scale = np.maximum(np.abs(ref), 1e-10 * max(1.0, np.abs(ref).max() if ref.size else 1.0))
+                assert ref.size == 0 or (np.abs(got - ref) / scale).max() <= 1e-10, what
+            # all-reduce: rank-order sums, identical bits on every rank
+            fsum = allres[0]["fpre"]
+            gsum = allres[0]["gpre"].copy()
+            for r in allres[1:]:
+                fsum = fsum + r["fpre"]
+                gsum = gsum + r["gpre"]
+            for r in allres:
+                assert r["fpost"] == fsum and np.array_equal(r["gpost"], gsum), "all-reduce result differs from the rank-order sum"
+            assert abs(fsum - O.obj(xg)) <= 1e-10 * max(1.0, abs(O.obj(xg)))
+        dist.barrier()
+    if rank == 0:
+        print("OK", name, world, info["halo_doubles"], info["n_shared"], "graph" if graph is not None else "eager")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
