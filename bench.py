@@ -207,16 +207,21 @@ def main():
             S_global = args.supports * world
         else:
             S_global = args.supports
+        # N > 1: every rank holds the GLOBAL blob — what a host that knows nothing about sharding has —
+        # and iem_create_sharded cuts this rank's window of the time axis (group 1) inside the library
+        er, ew = rank, world
         if args.emulate_shard:     # build shard R of N on this one GPU (no communication): "R/N"
             er, ew = (int(v) for v in args.emulate_shard.split("/"))
-            core, S_local = shard.quadrotor_shard(args.supports * ew if scaling == "weak" else args.supports, er, ew)
-        elif world == 1:
-            core = transcribe.exa_core(workloads.quadrotor(S_global))
+            S_global = args.supports * ew if scaling == "weak" else args.supports
+        core = transcribe.exa_core(workloads.quadrotor(S_global))
+        blob = core.to_blob()
+        if ew == 1:
+            gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout)
             S_local = S_global
         else:
-            core, S_local = shard.quadrotor_shard(S_global, rank, world)
-        blob = core.to_blob()
-        gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout)
+            del core
+            gm = ExaModel.sharded(blob, 1, er, ew, device=local_rank, hess_layout=args.hess_layout)
+            S_local = gm.shard_info()["own_n"]
         del blob
         x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22, seed=rank * 2)
         xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)

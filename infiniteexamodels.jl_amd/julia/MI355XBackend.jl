@@ -276,7 +276,14 @@ function _chain(head)
     return out
 end
 
-function to_blob(core)::Vector{UInt8}
+# `slabs`  (optional, needed by iem_create_sharded): one `(offset0, dims, groups)` per `add_var` slab in
+#          creation order — what `data.infvar_mappings` / `finvar_mappings` hold (`Variable.offset/.size`,
+#          src/infiniteopt_backend.jl:476-479) plus the parameter-group index of each axis (0 = none);
+# `template_groups` (optional): the parameter-group index of each template's (1-D) iterator in
+#          add_obj/add_con call order, 0 = none — becomes the grid hint the window cut keys on.
+# UNEXECUTED like the rest of this file.  Product iterators (pandemic's t x xi) reach the library as
+# flat lists and are recovered as lattices without group ids: sharding them needs the Python producer.
+function to_blob(core; slabs = nothing, template_groups = nothing)::Vector{UInt8}
     A = _Arrays(NTuple{5,Any}[], Dict{Any,Int}())
     core_ids = [_add_array!(A, Array(core.x0)), _add_array!(A, Array(core.lvar)),
                 _add_array!(A, Array(core.uvar)), _add_array!(A, Array(core.θ))]
@@ -296,6 +303,9 @@ function to_blob(core)::Vector{UInt8}
         root = _walk!(T, t.f.f)
         n = length(items)
         gid, origin = T.first_ap === nothing ? (n == 1 ? (0, 0) : (-1, 0)) : (4096 + 1, T.first_ap)
+        if template_groups !== nothing && T.first_ap !== nothing && template_groups[length(tpls) + 1] > 0
+            gid = template_groups[length(tpls) + 1] + 1          # one digit, base 4096: (group + 1)
+        end
         w = UInt64[_w(kind), _w(n), _w(1), _w(n), _w(1), _w(1), _w(gid), _w(origin), _w(0), _w(0),
                    _w(length(T.ifields)), _w(length(T.ffields)), _w(length(T.idx)), _w(length(T.nodes)), _w(root)]
         if kind == 1
@@ -312,11 +322,22 @@ function to_blob(core)::Vector{UInt8}
     narr, ntpl = length(A.recs), length(tpls)
     pos = 14 + 6 * narr + ntpl
     tpl_off = Int[]; for w in tpls; push!(tpl_off, pos); pos += length(w); end
+    slab_words = UInt64[]
+    if slabs !== nothing                                       # include/iem_blob.h: n, then n x {off, nd, dims[3], group[3]}
+        push!(slab_words, _w(length(slabs)))
+        for (off, dims, groups) in slabs
+            nd = length(dims)
+            append!(slab_words, _w.([off, nd, dims..., ones(Int, 3 - nd)..., groups..., zeros(Int, 3 - nd)...]))
+        end
+    end
+    slab_off = isempty(slab_words) ? 0 : pos
+    pos += length(slab_words)
     arr_off = Int[]; for r in A.recs; push!(arr_off, r[3] === nothing ? 0 : pos); r[3] === nothing || (pos += r[2]); end
     head = UInt64[_w(0x31424f4c424d4549), _w(1), _w(core.nvar), _w(core.npar), _w(core.ncon), _w(ntpl), _w(narr),
-                  _w(core.minimize ? 1 : 0), _w(pos), _w(0), _w.(core_ids)...]
+                  _w(core.minimize ? 1 : 0), _w(pos), _w(slab_off), _w.(core_ids)...]
     for (r, off) in zip(A.recs, arr_off); append!(head, [_w(r[1]), _w(r[2]), _w(off), r[4], r[5], _w(0)]); end
     append!(head, _w.(tpl_off)); foreach(w -> append!(head, w), tpls)
+    append!(head, slab_words)
     for r in A.recs
         r[3] === nothing || append!(head, reinterpret(UInt64, r[3]))
     end

@@ -461,7 +461,7 @@ def _add_constraints(core: ExaCore, data: ExaMappingData, m: InfiniteModel) -> N
         data_src = N.DataSource()
         em_expr = _finalize_expr(_exafy(expr, data_src, data))
         cref.mapping = core.add_con(em_expr, itr, lcon=cref.lb, ucon=cref.ub)
-        core.templates[-1].tag = ("con", m.constraints.index(cref) if False else id_index(m.constraints, cref))
+        core.templates[-1].tag = ("con", id_index(m.constraints, cref))
         data.constraint_mappings[cref] = cref.mapping
 
 
