@@ -38,7 +38,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_PROFILE = "r01_rocprof_quadrotor_1e6.json"   # committed rocprofv3 --pmc passes of this command (static, not live)
+PMC_PROFILE = "r02_rocprof_quadrotor_1e6.json"   # committed rocprofv3 --pmc passes of this command (static, not live)
 
 
 def eval_point(nvar, ncon, x0, S_local, seed=0):
@@ -85,7 +85,7 @@ def cpu_baseline(sample_supports: int, seconds: float = 12.0):
     }
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, script: str = None) -> int:
     """Plain `python bench.py --gpus N` (no RANK in the environment): start the N ranks as fresh
     child processes — this parent has not touched the GPU and never does — and wait for them.
     Rank 0 inherits stdout and prints the JSON line.  A rank that dies takes the others with it
@@ -100,7 +100,7 @@ def spawn_ranks(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     live = list(procs)

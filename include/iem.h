@@ -206,7 +206,9 @@ void iem_free(void *p);
  *                  workgroup-staged stores re-cut at 128-byte lines
  *   "overlap"      1 (default): block-store kernels overlap their tiles by 16 lanes so that every
  *                  128-byte line is written whole by one workgroup
- *   "nt_stores", "block" (workgroup size, default 512), "lds_slots", "reorder", "min_waves"
+ *   "nt_stores", "lds_slots", "reorder", "min_waves"
+ *   "block"        workgroup size; 0 (default) = per model: 512, or 256 when that wastes > 2 % fewer
+ *                  lanes on the rows of a 2-D / 3-D support grid (5 000 x 100: 11 tiles of 496 vs 21 of 240)
  *   "fp_contract"  0 (default): no FMA contraction — bit-comparable with the CPU oracle
  *   "split_small"  support grids of at most this many workgroups (default 64) run their templates
  *                  side by side in one launch instead of fused lane-wise (0: never)

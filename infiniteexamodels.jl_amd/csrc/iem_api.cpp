@@ -69,7 +69,7 @@ std::string full_source(const iem::Program &p, const iem::Options &o) {
   s += "// iem-flags: -O3 " + contract_flag(o) + " -std=c++17\n";
   s += "#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += std::string("#define IEM_NT ") + (o.nt_stores ? "1" : "0") + "\n";
-  s += "#define IEM_TILE " + std::to_string(o.block) + "\n";
+  s += "#define IEM_TILE " + std::to_string(p.block) + "\n";
   s += std::string("#define IEM_WIDE_STORES ") + (o.wide_stores ? "1" : "0") + "\n";
   if (o.ablate) s += "#define IEM_ABLATE " + std::to_string(o.ablate & 1) + "  // timing experiment, results are wrong\n";
   s += kDeviceHeader;
@@ -511,7 +511,7 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "hess_merge") == 0) { o.hess_merge = (int)value; return IEM_OK; }
   if (std::strcmp(name, "ablate") == 0) { o.ablate = (int)value; return IEM_OK; }
   if (std::strcmp(name, "block") == 0) {
-    if (value < 64 || value > 1024 || value % 64) return fail(IEM_E_ARG, "block must be a multiple of 64 in 64..1024");
+    if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(IEM_E_ARG, "block must be 0 (chosen per model) or a multiple of 64 in 64..1024");
     o.block = (int)value;
     return IEM_OK;
   }

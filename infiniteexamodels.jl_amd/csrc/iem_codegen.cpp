@@ -1597,9 +1597,34 @@ void validate_indices(const Model &m) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
-Program generate(const Model &m, const Options &opt) {
+// Workgroup size when the caller leaves it open (block = 0).  512 lanes halve the partial cache lines
+// at block seams — but on a grid of two or more dimensions every ROW ends in a partly
+// filled workgroup: 5 000 time supports are 10.08 tiles of 496 (the 11th workgroup of each row runs
+// 8 % full: +9 % lanes) but 20.8 tiles of 240 (+0.8 %).  Pick the size that wastes fewer lanes, 512
+// unless 256 saves more than 2 % (measured on pandemic 5000 x 100: cons! 13.9 -> 13.2 us,
+// jac_coord! 21.6 -> 20.6 us, profiles/r02_ab_pandemic_tiles.txt).
+static int choose_block(const Model &m, const Options &opt) {
+  const bool overlap = opt.store_mode == 2 && opt.overlap;
+  double lanes[2] = {0.0, 0.0}, items = 0.0;
+  const int cand[2] = {512, 256};
+  for (const Template &t : m.tpl) {
+    if (t.nd < 2 || t.grid_id <= 0 || t.dims[0] < 64 || t.n_items == 0) continue;
+    items += (double)t.n_items;
+    for (int c = 0; c < 2; ++c) {
+      const int64_t step = overlap ? cand[c] - 16 : cand[c];
+      lanes[c] += (double)((t.dims[0] + step - 1) / step * step) * (double)(t.n_items / t.dims[0]);
+    }
+  }
+  if (items == 0.0) return 512;
+  return lanes[1] < lanes[0] - 0.02 * items ? 256 : 512;
+}
+
+Program generate(const Model &m, const Options &opt_in) {
   validate_indices(m);
+  Options opt = opt_in;
+  if (opt.block == 0) opt.block = choose_block(m, opt);
   Program P;
+  P.block = opt.block;
   std::vector<Group> groups = make_groups(m, [&](size_t) { return opt.no_fuse != 0; });
   // The scatter kinds (grad, J'v, Hv) always keep the lane-fused groups: when several templates add
   // into the same entry, ONE lane issues those adds in program order (deterministic); side by side

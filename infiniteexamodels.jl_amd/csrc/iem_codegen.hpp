@@ -31,7 +31,8 @@ struct KernelDesc {
 
 struct Options {
   int store_mode = 2;  // 0 direct strided stores, 1 wave-level LDS-transposed stores, 2 block-cooperative 128-B-aligned stores
-  int block = 512;     // workgroup size of the fused kernels (multiple of 64); 512 halves the partial cache lines at block seams
+  int block = 0;       // workgroup size of the fused kernels (multiple of 64); 0 = chosen per model: 512 (halves the partial cache
+                       // lines at block seams) unless 256-lane tiles waste > 2 % fewer lanes on the rows of a 2-D/3-D grid
   int lds_slots = 24;  // store_mode 2: values per lane staged per barrier pair (LDS = 2 KB x this per workgroup)
   int reorder = 1;     // 1: emit cheap templates first so the store stream starts early
   int no_fuse = 0;     // 1: one kernel per template (the reference design's launch structure; baseline/ablation only)
@@ -61,6 +62,7 @@ struct HessClass {
 
 struct Program {
   std::string source;
+  int block = 512;       // the workgroup size the kernels were generated for (Options::block resolved)
   uint64_t key = 0;
   std::vector<KernelDesc> kernels;
   int64_t n_partials = 0;

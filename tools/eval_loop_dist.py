@@ -7,9 +7,14 @@ gradient entries of replicated (first-stage / non-sharded) variables.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       tools/eval_loop_dist.py --workload farmer|opf|pandemic|quadrotor --supports S_PER_RANK
 
-Weak scaling: every rank owns S_PER_RANK scenarios (supports) of an N*S_PER_RANK problem.
-Rehearsal on ONE GPU: --dist-backend gloo --same-device (the collective then runs on host
-copies).  Prints one JSON line (rank 0): loops/s, per-call ms, collective ms and bytes.
+Weak scaling: every rank owns S_PER_RANK scenarios (supports) of an N*S_PER_RANK problem.  Every
+rank builds the GLOBAL blob and iem_create_sharded cuts its window (the C-ABI path a Julia host
+would take).  The collective is the library's own one-shot mailbox all-reduce by default
+(`--allreduce own`: iem_allreduce_obj_grad, preceded by iem_halo_exchange where a stencil crosses
+the shard boundary); `--allreduce rccl` runs torch.distributed's instead, for comparison.
+Rehearsal on ONE GPU: `--gpus N --same-device` spawns N ranks on cuda:0 (gloo moves only the
+mailbox handles and the timing reductions).  Prints one JSON line (rank 0): loops/s, per-call ms,
+collective ms and bytes.
 """
 import argparse
 import json
@@ -37,7 +42,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--allreduce", default="own", choices=("own", "rccl"))
+    ap.add_argument("--gpus", type=int, default=0, help="spawn this many ranks (no torchrun needed)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import bench
+        sys.exit(bench.spawn_ranks(args.gpus, script=os.path.abspath(__file__)))
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -51,24 +61,29 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     nccl = args.dist_backend == "nccl"
 
+    from infiniteexamodels.jl_amd import transcribe, workloads
     n_glob = args.supports * world
     t0 = time.perf_counter()
+    group = 1
     if args.workload == "farmer":
-        core, own = shard.farmer_shard(n_glob, rank, world)
+        gcore = transcribe.exa_core(workloads.farmer(n_glob))
     elif args.workload == "opf":
-        core, own = shard.opf_shard(n_glob, rank, world)
+        gcore = transcribe.exa_core(workloads.opf(n_glob))
     elif args.workload == "pandemic":
-        core, own = shard.pandemic_shard(args.nt, n_glob, rank, world)
-        own *= args.nt + 10
+        gcore, group = transcribe.exa_core(workloads.pandemic(args.nt, n_glob)), 2
     else:
-        core, own = shard.quadrotor_shard(n_glob, rank, world)
-    m = ExaModel(core, device=local_rank)
+        gcore = transcribe.exa_core(workloads.quadrotor(n_glob))
+    m = ExaModel.sharded(gcore.to_blob(), group, rank, world, device=local_rank)
+    del gcore
+    info = m.shard_info()
+    own = info["own_n"] * ((args.nt + 10) if args.workload == "pandemic" else 1)
+    shard.connect_mailboxes(m, dist)
     build_s = time.perf_counter() - t0
     meta = m.meta
     rng = np.random.default_rng(rank)
     x = torch.tensor(np.abs(meta.x0 + 0.1 * rng.standard_normal(meta.nvar)) + 0.05, device=dev)
     y = torch.tensor(rng.standard_normal(meta.ncon), device=dev)
-    shared = torch.tensor(shard.replicated_indices(core), device=dev)
+    shared = torch.tensor(np.nonzero(m.shard_var_map()[1] & 2)[0], device=dev)
     buf = torch.zeros(1 + shared.numel(), dtype=torch.float64, device=dev)
     hbuf = torch.zeros(1 + shared.numel(), dtype=torch.float64)          # gloo rehearsal: host copy
     f = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -78,7 +93,9 @@ def main():
     hv = torch.empty(meta.nnzh, dtype=torch.float64, device=dev)
 
     def collective():
-        if nccl:
+        if args.allreduce == "own":
+            m.allreduce_obj_grad(f, g)
+        elif nccl:
             shard.allreduce_obj_grad_device(f, g, shared, buf, dist)
         else:
             buf[0:1] = f
@@ -90,7 +107,7 @@ def main():
             if shared.numel():
                 g[shared] = buf[1:]
 
-    calls = [("obj", lambda: m.obj_device(x, f)), ("grad", lambda: m.grad(x, g)), ("allreduce", collective),
+    calls = [("halo", lambda: m.halo_exchange(x)), ("obj", lambda: m.obj_device(x, f)), ("grad", lambda: m.grad(x, g)), ("allreduce", collective),
              ("cons", lambda: m.cons(x, c)), ("jac_coord", lambda: m.jac_coord(x, jv)),
              ("hess_coord", lambda: m.hess_coord(x, y, hv, obj_weight=1.0))]
 
@@ -120,13 +137,15 @@ def main():
     red = torch.tensor([dt, float(own)], dtype=torch.float64, device=dev if nccl else "cpu")
     tmax = red.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tot = red.clone(); dist.all_reduce(tot)
-    fglob = float(buf[0].item())
+    torch.cuda.synchronize()
+    assert m.comm_status() == 0, "a mailbox wait timed out"
+    fglob = float(f.item()) if args.allreduce == "own" else float(buf[0].item())
     if rank == 0:
         dt = float(tmax[0].item())
         print(json.dumps({
             "workload": f"{args.workload}, {int(tot[1].item())} supports over {world} rank(s) ({own} on rank 0), full loop "
                         "obj+grad!+allreduce+cons!+jac_coord!+hess_coord!",
-            "n_gpus": world, "dist_backend": args.dist_backend, "same_device": bool(args.same_device), "scaling": "weak",
+            "n_gpus": world, "dist_backend": args.dist_backend, "allreduce": args.allreduce, "halo_doubles": info["halo_doubles"], "same_device": bool(args.same_device), "scaling": "weak",
             "nvar_rank0": meta.nvar, "ncon_rank0": meta.ncon, "nnzj_rank0": meta.nnzj, "nnzh_rank0": meta.nnzh,
             "loop_ms": dt / args.iters * 1e3, "loops_per_s": args.iters / dt,
             "supports_per_s": float(tot[1].item()) * args.iters / dt,
