@@ -972,7 +972,12 @@ void fill_shard_tpl(const iem::Model &M, const iem::ShardInfo &si, size_t i, iem
 }
 
 // mailbox words: see iem_device.h
-size_t mailbox_words(int64_t W, int64_t NH, int64_t NR) { return (size_t)(8 + 2 * W + 2 * NH + 2 * W * NR); }
+// the all-reduce runs on G workgroups, each on its own chunk of the NR doubles (one per 1 024, at most 64)
+int64_t reduce_chunks(int64_t NR) { return std::min<int64_t>(64, std::max<int64_t>(1, (NR + 1023) / 1024)); }
+size_t mailbox_words(int64_t W, int64_t NH, int64_t NR) {
+  const int64_t G = reduce_chunks(NR);
+  return (size_t)(8 + G + 2 * W * G + 2 * NH + 2 * W * NR);
+}
 
 struct CommHandle {   // what iem_comm_export writes (IEM_COMM_HANDLE_BYTES)
   hipIpcMemHandle_t ipc;
@@ -1146,9 +1151,9 @@ int iem_halo_exchange(iem_model *m, double *d_x) {
   const iem::ShardInfo &si = m->shard;
   if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;   // no stencil crosses the shard boundary
   DevGuard dg_(m->device);
-  struct { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W; } A = {
+  struct { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G; } A = {
       d_x, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
-      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world};
+      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared)};
   size_t sz = sizeof A;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
@@ -1161,11 +1166,12 @@ int iem_allreduce_obj_grad(iem_model *m, double *d_obj, double *d_g) {
   if (!d_g && m->n_shared) return fail(IEM_E_ARG, "null gradient but the model has replicated variables");
   DevGuard dg_(m->device);
   const iem::ShardInfo &si = m->shard;
-  struct { double *obj, *g; const long long *shared; unsigned long long *const *peers; long long NR, NH, W, rank; } A = {
-      d_obj, d_g, m->d_shared, m->d_peers, (long long)(1 + m->n_shared), (long long)si.halo_doubles, (long long)si.world, (long long)si.rank};
+  const long long G = (long long)reduce_chunks(1 + m->n_shared);
+  struct { double *obj, *g; const long long *shared; unsigned long long *const *peers; long long NR, NH, W, rank, G; } A = {
+      d_obj, d_g, m->d_shared, m->d_peers, (long long)(1 + m->n_shared), (long long)si.halo_doubles, (long long)si.world, (long long)si.rank, G};
   size_t sz = sizeof A;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_TRY(hipModuleLaunchKernel(m->fn_reduce, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
+  HIP_TRY(hipModuleLaunchKernel(m->fn_reduce, (unsigned)G, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
   return IEM_OK;
 }
 

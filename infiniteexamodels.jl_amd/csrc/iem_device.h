@@ -437,18 +437,19 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum(const
 // in the mailbox's status word and RUNS ON — no wave ever spins forever.  Sequence numbers live in
 // the mailbox and are advanced by the kernels themselves, so both calls can be graph-replayed.
 //
-// mailbox words (8 bytes each):   [0] status  [1] halo seq  [2] all-reduce seq  [3] halo ack (from the right)
-//   [4,6) halo flags (from the left, one per parity)   [8, 8+2W) all-reduce flags [parity][peer]
-//   then halo data [2][NH] and all-reduce data [2][W][NR]     (W = world, NH, NR as passed)
+// mailbox words (8 bytes each):   [0] status  [1] halo seq  [3] halo ack (from the right)
+//   [4,6) halo flags (from the left, one per parity)   [8, 8+G) all-reduce seq per chunk
+//   [8+G, 8+G+2WG) all-reduce flags [parity][peer][chunk]
+//   then halo data [2][NH] and all-reduce data [2][W][NR]     (W = world, G = chunks, NH, NR as passed)
 #define IEM_COMM_TIMEOUT 500000000LL   // 5 s
 #define IEM_MB_STATUS 0
 #define IEM_MB_HSEQ 1
-#define IEM_MB_RSEQ 2
 #define IEM_MB_HACK 3
 #define IEM_MB_HFLAG 4
-#define IEM_MB_RFLAG 8
-__device__ __forceinline__ long long iem_mb_hdata(long long W) { return IEM_MB_RFLAG + 2 * W; }
-__device__ __forceinline__ long long iem_mb_rdata(long long W, long long NH) { return IEM_MB_RFLAG + 2 * W + 2 * NH; }
+#define IEM_MB_RSEQ 8
+__device__ __forceinline__ long long iem_mb_rflag(long long G) { return IEM_MB_RSEQ + G; }
+__device__ __forceinline__ long long iem_mb_hdata(long long W, long long G) { return IEM_MB_RSEQ + G + 2 * W * G; }
+__device__ __forceinline__ long long iem_mb_rdata(long long W, long long G, long long NH) { return iem_mb_hdata(W, G) + 2 * NH; }
 __device__ __forceinline__ unsigned long long iem_sys_load(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -484,7 +485,7 @@ struct IemHaloArgs {
   double *x;
   unsigned long long *mine, *left, *right;   // mailboxes (left / right: nullptr at the ends of the chain)
   const long long *src, *dst;                // NH positions of x each: what goes right, where the left's arrive
-  long long NH, W;
+  long long NH, W, G;
 };
 // one workgroup: (1) my last `reach` owned supports of every sharded slab -> the right neighbour's
 // mailbox, (2) the left neighbour's -> the halo entries of my x (reference stencil:
@@ -497,7 +498,7 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const Ie
     if (threadIdx.x == 0)   // the slot of this parity was last used by seq - 2: the right neighbour must have consumed it
       ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_HACK, seq - 2, A.mine + IEM_MB_STATUS, 1ULL);
     __syncthreads();
-    double *data = reinterpret_cast<double *>(A.right + iem_mb_hdata(A.W)) + par * A.NH;
+    double *data = reinterpret_cast<double *>(A.right + iem_mb_hdata(A.W, A.G)) + par * A.NH;
     for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) iem_sys_stored(data + e, A.x[A.src[e]]);
     iem_publish_fence();
     if (threadIdx.x == 0) iem_sys_store(A.right + IEM_MB_HFLAG + par, seq);
@@ -508,7 +509,7 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const Ie
       __threadfence_system();
     }
     __syncthreads();
-    const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_hdata(A.W)) + par * A.NH;
+    const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_hdata(A.W, A.G)) + par * A.NH;
     if (ok_)
       for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.x[A.dst[e]] = iem_sys_loadd(data + e);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -523,40 +524,43 @@ struct IemReduceArgs {
   double *obj, *g;                    // in/out: the scalar objective (device) and the gradient
   const long long *shared;            // NR - 1 positions of g held by every rank (replicated variables)
   unsigned long long *const *peers;   // W mailboxes, peers[rank] = mine
-  long long NR, NH, W, rank;
+  long long NR, NH, W, rank, G;
 };
-// one workgroup: my NR doubles -> slot [rank] of EVERY rank's mailbox; wait for the W flags in mine;
-// sum the W slots in rank order (the same order on every rank: identical bits everywhere) and write
-// the sums back.  SURVEY 8(e): "one small all-reduce per obj / grad!" — one-shot direct writes.
+// G workgroups, each on its own chunk of the NR doubles and with flags of its own (no cross-workgroup
+// step): my chunk -> slot [rank] of EVERY rank's mailbox; wait for the W flags of the chunk in mine; sum
+// the W slots in rank order (the same order on every rank: identical bits everywhere) and write the sums
+// back.  SURVEY 8(e): "one small all-reduce per obj / grad!" — one-shot direct writes, never a ring.
 extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_allreduce_kernel(const IemReduceArgs A) {
   unsigned long long *mine = A.peers[A.rank];
-  const unsigned long long seq = iem_sys_load(mine + IEM_MB_RSEQ) + 1;
+  const long long c = blockIdx.x, G = A.G;
+  const long long per = (A.NR + G - 1) / G, e0 = c * per, e1 = e0 + per < A.NR ? e0 + per : A.NR;
+  const unsigned long long seq = iem_sys_load(mine + IEM_MB_RSEQ + c) + 1;
   const long long par = (long long)(seq & 1);
-  const long long base = iem_mb_rdata(A.W, A.NH) + (par * A.W + A.rank) * A.NR;
-  for (long long e = threadIdx.x; e < A.NR; e += IEM_BLOCK) {
+  const long long base = iem_mb_rdata(A.W, G, A.NH) + (par * A.W + A.rank) * A.NR;
+  for (long long e = e0 + threadIdx.x; e < e1; e += IEM_BLOCK) {
     const double v = e == 0 ? (A.obj ? *A.obj : 0.0) : A.g[A.shared[e - 1]];
     for (long long p = 0; p < A.W; ++p) iem_sys_stored(reinterpret_cast<double *>(A.peers[p] + base) + e, v);
   }
   iem_publish_fence();
   if (threadIdx.x == 0)
-    for (long long p = 0; p < A.W; ++p) iem_sys_store(A.peers[p] + IEM_MB_RFLAG + par * A.W + A.rank, seq);
+    for (long long p = 0; p < A.W; ++p) iem_sys_store(A.peers[p] + iem_mb_rflag(G) + (par * A.W + A.rank) * G + c, seq);
   __shared__ int ok_;
   if (threadIdx.x == 0) ok_ = 1;
   __syncthreads();
   for (long long p = threadIdx.x; p < A.W; p += IEM_BLOCK)
-    if (!iem_wait_ge(mine + IEM_MB_RFLAG + par * A.W + p, seq, mine + IEM_MB_STATUS, 4ULL)) ok_ = 0;
+    if (!iem_wait_ge(mine + iem_mb_rflag(G) + (par * A.W + p) * G + c, seq, mine + IEM_MB_STATUS, 4ULL)) ok_ = 0;
   __threadfence_system();
   __syncthreads();
   if (ok_) {
-    const double *slots = reinterpret_cast<const double *>(mine + iem_mb_rdata(A.W, A.NH)) + par * A.W * A.NR;
-    for (long long e = threadIdx.x; e < A.NR; e += IEM_BLOCK) {
+    const double *slots = reinterpret_cast<const double *>(mine + iem_mb_rdata(A.W, G, A.NH)) + par * A.W * A.NR;
+    for (long long e = e0 + threadIdx.x; e < e1; e += IEM_BLOCK) {
       double acc = iem_sys_loadd(slots + e);
       for (long long p = 1; p < A.W; ++p) acc += iem_sys_loadd(slots + p * A.NR + e);
       if (e == 0) { if (A.obj) *A.obj = acc; } else A.g[A.shared[e - 1]] = acc;
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) iem_sys_store(mine + IEM_MB_RSEQ, seq);
+  if (threadIdx.x == 0) iem_sys_store(mine + IEM_MB_RSEQ + c, seq);
 }
 
 #endif  // IEM_DEVICE_H
