@@ -135,3 +135,53 @@ def test_unsupported_inputs_fail_loudly(built):
     w[9] = 0                                              # no slab table
     with pytest.raises(iemlib.IemError):
         iemlib.shard_blob(w.tobytes(), 1, 0, 2)
+
+
+@pytest.mark.parametrize("name,size,group", [("quadrotor", 23, 1), ("pandemic", (8, 5), 2), ("pandemic", (8, 5), 1), ("opf", 9, 1)])
+def test_world_one_is_the_identity(name, size, group, built):
+    """A one-rank "shard" is the whole model: same numbering, same results, no halo, every variable owned."""
+    gcore, _ = _global(name, size)
+    gblob = gcore.to_blob()
+    lblob, info, vmap, vflag, tpl = iemlib.shard_blob(gblob, group, 0, 1)
+    G, L = OracleModel(gblob), OracleModel(lblob)
+    assert (L.nvar, L.ncon, L.nnzj, L.nnzh) == (G.nvar, G.ncon, G.nnzj, G.nnzh)
+    assert info["halo"] == 0 and info["own_lo"] == 0 and info["own_n"] == info["n_global"]
+    assert np.array_equal(vmap, np.arange(G.nvar)) and ((vflag & 1) != 0).all() and not (vflag & 4).any()
+    x, y = _point(G, name)
+    assert np.array_equal(L.cons(x), G.cons(x)) and np.array_equal(L.jac_coord(x), G.jac_coord(x))
+    assert np.array_equal(L.hess_coord(x, y, 0.3), G.hess_coord(x, y, 0.3)) and L.obj(x) == G.obj(x)
+    for a, b in ((L.jac_structure(), G.jac_structure()), (L.hess_structure(), G.hess_structure())):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert [t["global_index"] for t in tpl] == list(range(G.n_templates))
+
+
+def test_time_sharded_pandemic_keeps_its_stencil_local(built):
+    """Pandemic sharded over TIME (group 1) instead of xi: the 2-D slabs are cut along their FAST axis, the
+    backward-difference rows need a halo of one time support per xi row, u(t) is itself sharded, and the initial
+    conditions s(0, xi) == s0 (a semi-infinite template over xi only) belong to the rank holding t = 0."""
+    gcore, _ = _global("pandemic", (9, 4))
+    gblob = gcore.to_blob()
+    G = OracleModel(gblob)
+    xg, yg = _point(G, "pandemic")
+    ref = dict(c=G.cons(xg), j=G.jac_coord(xg), h=G.hess_coord(xg, yg, 0.7))
+    c = np.full(G.ncon, np.nan); j = np.full(G.nnzj, np.nan); h = np.full(G.nnzh, np.nan)
+    f = 0.0
+    for r in range(3):
+        lblob, info, vmap, vflag, tpl = iemlib.shard_blob(gblob, 1, r, 3)
+        assert info["halo"] == (0 if r == 0 else 1) and info["halo_reach"] == 1
+        assert info["halo_doubles"] == 8 * 4 + 1        # the window of EVERY slab over t carries the halo support: s,e,i,r and their derivatives (4 xi rows each) + u
+        L = OracleModel(lblob)
+        x = xg[vmap]
+        row_map = np.full(L.ncon, -1); jpos = np.full(L.nnzj, -1); hpos = np.full(L.nnzh, -1)
+        for t in tpl:
+            k = _ordinals(t)
+            if t["kind"] == 1:
+                row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
+                if t["o1step"]:
+                    jpos[t["o1"]:t["o1"] + k.size * t["o1step"]] = (t["global_o1"] + t["o1step"] * k[:, None] + np.arange(t["o1step"])[None, :]).reshape(-1)
+            if t["o2step"]:
+                hpos[t["o2"]:t["o2"] + k.size * t["o2step"]] = (t["global_o2"] + t["o2step"] * k[:, None] + np.arange(t["o2step"])[None, :]).reshape(-1)
+        c[row_map] = L.cons(x); j[jpos] = L.jac_coord(x); h[hpos] = L.hess_coord(x, yg[row_map], 0.7)
+        f += L.obj(x)
+    assert np.array_equal(c, ref["c"]) and np.array_equal(j, ref["j"]) and np.array_equal(h, ref["h"])
+    assert abs(f - G.obj(xg)) <= 1e-12 * max(1.0, abs(G.obj(xg)))
