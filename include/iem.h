@@ -105,7 +105,8 @@ int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_optio
  * all-gathers the IEM_COMM_HANDLE_BYTES-byte handles (MPI / torch.distributed / a pipe — like an
  * ncclUniqueId), every rank calls iem_comm_connect with all of them in rank order. */
 typedef struct iem_shard_t {
-  int32_t group, rank, world, reserved;
+  int32_t group, rank, world;
+  int32_t mailbox_kind;        /* 0 no mailbox yet; 1 uncached, 3 fine-grained device memory (coherent across GPUs); 2 plain hipMalloc (one-GPU rehearsal only) */
   int64_t n_global;            /* supports of the sharded group                       */
   int64_t own_lo, own_n, halo; /* first owned support (global, 0-based), count, halo supports in front */
   int64_t halo_reach, halo_doubles;

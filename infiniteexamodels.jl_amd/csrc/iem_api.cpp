@@ -71,6 +71,7 @@ std::string full_source(const iem::Program &p, const iem::Options &o) {
   s += std::string("#define IEM_NT ") + (o.nt_stores ? "1" : "0") + "\n";
   s += "#define IEM_TILE " + std::to_string(p.block) + "\n";
   s += std::string("#define IEM_WIDE_STORES ") + (o.wide_stores ? "1" : "0") + "\n";
+  if (o.flush32 != 2) s += "#define IEM_FLUSH32 " + std::to_string(o.flush32) + "\n";
   if (o.ablate) s += "#define IEM_ABLATE " + std::to_string(o.ablate & 1) + "  // timing experiment, results are wrong\n";
   s += kDeviceHeader;
   s += "\n";
@@ -131,6 +132,7 @@ struct iem_model {
   hipFunction_t fn_halo = nullptr, fn_reduce = nullptr;
   unsigned long long *mailbox = nullptr;   // device memory, exported through HIP IPC
   size_t mailbox_words = 0;
+  int mailbox_kind = 0;   // 0 none yet, 1 uncached (fine-grained) device memory, 2 plain hipMalloc
   bool connected = false;
   std::vector<unsigned long long *> peers; // peers[r]: rank r's mailbox as mapped here (peers[rank] = mailbox)
   std::vector<void *> ipc_opened;          // what hipIpcCloseMemHandle must release
@@ -526,6 +528,8 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   }
   if (std::strcmp(name, "det_shared") == 0) { o.det_shared = (int)value; return IEM_OK; }
   if (std::strcmp(name, "obj_unroll") == 0) { o.obj_unroll = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "flat2d") == 0) { o.flat2d = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "flush32") == 0) { o.flush32 = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -952,7 +956,7 @@ namespace {
 
 void fill_shard_t(const iem::Model &M, const iem::ShardInfo &si, iem_shard_t *o) {
   std::memset(o, 0, sizeof *o);
-  o->group = si.group; o->rank = si.rank; o->world = si.world;
+  o->group = si.group; o->rank = si.rank; o->world = si.world; o->mailbox_kind = 0;
   o->n_global = si.n_global; o->own_lo = si.own_lo; o->own_n = si.own_n; o->halo = si.halo;
   o->halo_reach = si.halo_reach; o->halo_doubles = si.halo_doubles;
   o->nvar_global = si.nvar_global; o->ncon_global = si.ncon_global; o->nnzj_global = si.nnzj_global; o->nnzh_global = si.nnzh_global;
@@ -1023,6 +1027,7 @@ int iem_shard_info(const iem_model *m, iem_shard_t *out) {
   if (!m || !out) return fail(IEM_E_ARG, "null argument");
   if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
   fill_shard_t(m->model, m->shard, out);
+  out->mailbox_kind = m->mailbox_kind;
   return IEM_OK;
 }
 
@@ -1054,33 +1059,30 @@ int iem_comm_export(iem_model *m, void *out_handle) {
       iem::partition_block(si.n_global, si.world, r, a, b);
       if (b - a < si.halo_reach) return fail(IEM_E_ARG, "a rank owns fewer supports than the stencil reaches");
     }
-  if (!m->mailbox) {
-    int64_t ns = 0;
-    for (unsigned char f : si.var_flag) ns += (f & 2) ? 1 : 0;
-    m->n_shared = ns;
-    m->mailbox_words = mailbox_words(si.world, si.halo_doubles, 1 + ns);
-    void *p = nullptr;
-    // uncached (fine-grained) device memory when the runtime offers it for IPC, plain hipMalloc otherwise
-    if (hipExtMallocWithFlags(&p, m->mailbox_words * 8, hipDeviceMallocUncached) != hipSuccess) {
-      (void)hipGetLastError();
-      HIP_TRY(hipMalloc(&p, m->mailbox_words * 8));
-    }
-    m->mailbox = (unsigned long long *)p;
-    HIP_TRY(hipMemset(m->mailbox, 0, m->mailbox_words * 8));
-    HIP_TRY(hipDeviceSynchronize());
-  }
+  int64_t ns = 0;
+  for (unsigned char f : si.var_flag) ns += (f & 2) ? 1 : 0;
+  m->n_shared = ns;
+  m->mailbox_words = mailbox_words(si.world, si.halo_doubles, 1 + ns);
   CommHandle h;
   std::memset(&h, 0, sizeof h);
-  hipError_t e = hipIpcGetMemHandle(&h.ipc, m->mailbox);
-  if (e != hipSuccess) {   // some runtimes refuse IPC on uncached allocations: fall back to a plain one
-    (void)hipGetLastError();
-    hipFree(m->mailbox);
-    m->mailbox = nullptr;
-    void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, m->mailbox_words * 8));
-    m->mailbox = (unsigned long long *)p;
+  if (!m->mailbox) {
+    // Peers write into this memory while a kernel here polls it: it must be FINE-GRAINED (coherent across
+    // agents inside a kernel) — uncached device memory first, fine-grained next; plain hipMalloc memory is
+    // the last resort (coherent only between processes sharing this GPU's L2: the one-GPU rehearsal) and
+    // is reported through iem_shard_info().mailbox_kind so a multi-GPU host can refuse it.
+    const unsigned flags[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, 0};
+    for (int attempt = 0; attempt < 3 && !m->mailbox; ++attempt) {
+      void *p = nullptr;
+      hipError_t e = attempt < 2 ? hipExtMallocWithFlags(&p, m->mailbox_words * 8, flags[attempt]) : hipMalloc(&p, m->mailbox_words * 8);
+      if (e != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (hipIpcGetMemHandle(&h.ipc, p) != hipSuccess) { (void)hipGetLastError(); hipFree(p); continue; }
+      m->mailbox = (unsigned long long *)p;
+      m->mailbox_kind = attempt == 0 ? 1 : attempt == 1 ? 3 : 2;
+    }
+    if (!m->mailbox) return fail(IEM_E_HIP, "could not allocate an IPC-exportable mailbox");
     HIP_TRY(hipMemset(m->mailbox, 0, m->mailbox_words * 8));
     HIP_TRY(hipDeviceSynchronize());
+  } else {
     HIP_TRY(hipIpcGetMemHandle(&h.ipc, m->mailbox));
   }
   h.pid = (int64_t)getpid(); h.device = m->device; h.rank = si.rank; h.world = si.world; h.words = (int64_t)m->mailbox_words;

@@ -128,6 +128,7 @@ struct Output {
   int tpl;
   int guard;
   int pos_idx;       // IdxVal id: position of slot 0 / the row / unused
+  int64_t pos_off = 0;   // ... = pos_off + (values per item) * (item ordinal)
   std::vector<int> vals;      // DAG ids
   std::vector<int> grad_idx;  // KK_GRAD: IdxVal ids (0-based) per value
   std::vector<int> grad_mode; // 0 exclusive store, 1 wave-uniform, 2 atomic
@@ -638,7 +639,7 @@ class KernelBuilder {
         case KK_CONS: {
           tg.forward(0);
           IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
-          o.pos_idx = idxval(iv);
+          o.pos_idx = idxval(iv); o.pos_off = t.o0;
           o.vals = {tg.val[t.root]};
           alg_w_ += t.n_items;
           break;
@@ -655,7 +656,7 @@ class KernelBuilder {
           o.vals = tg.slots1;
           if (kind_ == KK_JAC) {
             IdxVal iv; iv.aff = klin_aff(t, G, t.o1step, t.o1);
-            o.pos_idx = idxval(iv);
+            o.pos_idx = idxval(iv); o.pos_off = t.o1;
             alg_w_ += t.n_items * t.o1step;
           } else {
             for (int s = 0; s < t.o1step; ++s) {
@@ -677,7 +678,7 @@ class KernelBuilder {
             acc = add(acc, mul(tg.slots1[s] < 0 ? C(0.0) : tg.slots1[s], vv));
           }
           IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
-          o.pos_idx = idxval(iv);
+          o.pos_idx = idxval(iv); o.pos_off = t.o0;
           o.vals = {acc};
           alg_w_ += t.n_items;
           break;
@@ -751,7 +752,7 @@ class KernelBuilder {
             o.slot_ti.push_back(t.slot2_i[s2]); o.slot_tj.push_back(t.slot2_j[s2]);
           }
           IdxVal iv; iv.aff = klin_aff(t, G, t.o2step, t.o2);
-          o.pos_idx = idxval(iv);
+          o.pos_idx = idxval(iv); o.pos_off = t.o2;
           if (!opt_.hess_merge) alg_w_ += t.n_items * t.o2step;
           break;
         }
@@ -873,7 +874,7 @@ class KernelBuilder {
       // the class position as a function of q: same item box as its first template
       TGeo G = geo(m.tpl, m.scalar);
       IdxVal iv; iv.aff = klin_aff(t, G, (int64_t)m.vals.size(), o2m);
-      m.pos_idx = idxval(iv);
+      m.pos_idx = idxval(iv); m.pos_off = o2m;
       o2m += hc.n_items * (int64_t)m.vals.size();
       alg_w_ += hc.n_items * (int64_t)m.vals.size();
       // resolve (output index, idx id) → (template id, idx id)
@@ -937,6 +938,12 @@ class KernelBuilder {
   std::string aff_str(const AffQ &a) {
     std::ostringstream os;
     bool any = false;
+    if (g_.flat && g_.nd == 2 && a.k[0] != 0 && a.k[1] == a.k[0] * g_.ext[0] && a.k[2] == 0) {
+      // a slab walked at full stride on a flat 2-D grid: c + k*(q0 + E0*q1) is c + k*q — no 64-bit multiply per index
+      if (a.c != 0) os << ip(a.c) << " + ";
+      if (a.k[0] == 1) os << "q"; else os << coefstr(a.k[0]) << " * q";
+      return os.str();
+    }
     if (a.c != 0) { os << ip(a.c); any = true; }
     for (int d = 0; d < 3; ++d) {
       if (a.k[d] == 0) continue;
@@ -1168,7 +1175,31 @@ class KernelBuilder {
           if (ns > ns_cap) scalar_tpl = true;   // direct strided stores for this template
           bool full_box = true;
           for (int d = 0; d < g_.nd; ++d) if (o.qlo[d] != 0 || o.qhi[d] != g_.ext[d]) full_box = false;
-          if (g_.flat && !full_box) scalar_tpl = true;   // item ordinal is not linear in the flat lane index
+          const bool by_ordinal = g_.flat && !full_box && g_.nd == 2 && opt_.store_mode == 2 && !scalar_tpl;
+          if (g_.flat && !full_box && !by_ordinal) scalar_tpl = true;   // item ordinal is not linear in the flat lane index
+          if (by_ordinal) {
+            // sub-box template on a flat 2-D grid: stage by item ordinal (iem_device.h: iem_stage_ord / iem_flush_ord)
+            if (batch_slots + ns > lds_budget) flush_batch();
+            const std::string rn = "r" + std::to_string(oi), on = "ob" + std::to_string(oi);
+            const int64_t w0 = o.qhi[0] - o.qlo[0], h1 = o.qhi[1] - o.qlo[1];
+            const std::string box = ip(o.qlo[0]) + ", " + ip(w0) + ", " + ip(o.qlo[1]) + ", " + ip(h1);
+            tail << "  const double " << rn << "[" << ns << "] = {";
+            for (int s = 0; s < ns; ++s) tail << (s ? ", " : "") << "v" << o.vals[s];
+            tail << "};\n";
+            tail << "  const long long " << on << " = iem_ord_lt(fr1_, fr0_, " << box << ");\n";
+            tail << "  const long long sl" << oi << " = (q0 - " << ip(o.qlo[0]) << ") + " << ip(w0) << " * (q1 - " << ip(o.qlo[1]) << ") - " << on << ";\n";
+            tail << "  iem_stage_ord<" << ns << ">(" << rn << ", lds_blk + " << (batch_slots * opt_.block) << ", sl" << oi << ", " << g << ");\n";
+            std::ostringstream fl;
+            fl << "  { long long r1_, r0_;\n"
+               << "    iem_flat_split(fr1_, fr0_, 16, " << ip(g_.ext[0]) << ", r1_, r0_); const long long o16 = iem_ord_lt(r1_, r0_, " << box << ");\n"
+               << "    iem_flat_split(fr1_, fr0_, " << qstep_str() << ", " << ip(g_.ext[0]) << ", r1_, r0_); const long long ou = iem_ord_lt(r1_, r0_, " << box << ");\n"
+               << "    iem_flat_split(fr1_, fr0_, IEM_TILE, " << ip(g_.ext[0]) << ", r1_, r0_); const long long oa = iem_ord_lt(r1_, r0_, " << box << ");\n"
+               << "    iem_flush_ord<" << ns << ", " << qstep_str() << ">(OUT, " << ip(o.pos_off) << ", " << on << ", o16, ou, oa, lds_blk + "
+               << (batch_slots * opt_.block) << ", sl" << oi << ", " << g << "); }\n";
+            pending_flush.push_back(fl.str());
+            batch_slots += ns;
+            break;
+          }
           if (opt_.store_mode == 2 && !scalar_tpl) {
             // stage now, flush with the rest of the batch (one barrier pair per batch)
             if (batch_slots + ns > lds_budget) flush_batch();
@@ -1268,7 +1299,15 @@ class KernelBuilder {
       }
       head << "  }\n";
     }
-    if (g_.flat) {
+    if (g_.flat && g_.nd == 2) {
+      // one division per WORKGROUP (block-uniform), then a 32-bit step per lane: (row, column) of the flat index
+      head << "  const long long q = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
+      head << "  const bool inb = q < " << ip(g_.ext[0] * g_.ext[1]) << ";\n";
+      head << "  const long long fqb_ = (long long)blockIdx.x * " << qstep_str() << ";\n";
+      head << "  long long fr1_, fr0_; iem_flat_base(fqb_, " << ip(g_.ext[0]) << ", fr1_, fr0_);\n";
+      head << "  long long q1, q0; iem_flat_split(fr1_, fr0_, (int)threadIdx.x, " << ip(g_.ext[0]) << ", q1, q0);\n";
+      head << "  const long long q2 = 0; (void)fr1_; (void)fr0_;\n";
+    } else if (g_.flat) {
       head << "  const long long q = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
       head << "  const bool inb = q < " << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << ";\n";
       head << "  const long long q0 = q % " << ip(g_.ext[0]) << ", qr = q / " << ip(g_.ext[0]) << ";\n";
@@ -1459,7 +1498,7 @@ class KernelBuilder {
 // ---------------------------------------------------------------------------
 // `solo(ti)`: template ti gets a launch domain of its own (its item box) instead of joining the
 // lanes of its support grid
-std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)> &solo) {
+std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)> &solo, bool flat2d) {
   std::vector<Group> groups;
   std::map<std::pair<int64_t, int>, int> by_key;
   std::vector<int> scalars;
@@ -1502,6 +1541,11 @@ std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)>
       for (int d = 0; d < g.nd; ++d) g.ext[d] -= g.lo[d];  // hi -> extent
   for (auto &g : groups)
     if (g.nd > 1 && g.ext[0] < 64 && g.ext[1] * g.ext[2] > 1) g.flat = true;
+  // 2-D grids: one linear lane index over the whole grid, so that no row ends in a partly filled
+  // workgroup; sub-box templates are stored by item ordinal (iem_flush_ord)
+  if (flat2d)
+    for (auto &g : groups)
+      if (g.nd == 2 && g.ext[1] > 1) g.flat = true;
   if (!scalars.empty()) {
     if (groups.empty()) {
       groups.emplace_back();
@@ -1609,6 +1653,7 @@ static int choose_block(const Model &m, const Options &opt) {
   const int cand[2] = {512, 256};
   for (const Template &t : m.tpl) {
     if (t.nd < 2 || t.grid_id <= 0 || t.dims[0] < 64 || t.n_items == 0) continue;
+    if (t.nd == 2 && opt.flat2d) continue;   // flat 2-D grids have no per-row waste
     items += (double)t.n_items;
     for (int c = 0; c < 2; ++c) {
       const int64_t step = overlap ? cand[c] - 16 : cand[c];
@@ -1625,7 +1670,7 @@ Program generate(const Model &m, const Options &opt_in) {
   if (opt.block == 0) opt.block = choose_block(m, opt);
   Program P;
   P.block = opt.block;
-  std::vector<Group> groups = make_groups(m, [&](size_t) { return opt.no_fuse != 0; });
+  std::vector<Group> groups = make_groups(m, [&](size_t) { return opt.no_fuse != 0; }, opt.flat2d != 0);
   // The scatter kinds (grad, J'v, Hv) always keep the lane-fused groups: when several templates add
   // into the same entry, ONE lane issues those adds in program order (deterministic); side by side
   // they would come from different workgroups in arrival order.
@@ -1644,7 +1689,7 @@ Program generate(const Model &m, const Options &opt_in) {
                                 : (g.ext[0] + opt.block - 1) / opt.block * g.ext[1] * g.ext[2];
       if (nb <= opt.split_small) solo.insert(g.tpls.begin(), g.tpls.end());
     }
-    if (!solo.empty()) { groups = make_groups(m, [&](size_t ti) { return solo.count(ti) != 0; }); split = true; }
+    if (!solo.empty()) { groups = make_groups(m, [&](size_t ti) { return solo.count(ti) != 0; }, opt.flat2d != 0); split = true; }
   }
   std::ostringstream src;
   src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";

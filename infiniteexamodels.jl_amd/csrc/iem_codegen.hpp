@@ -48,6 +48,12 @@ struct Options {
   int fuse_zero = 1;   // 1: scatter kernels zero the untouched output entries themselves when nothing accumulates (no memset launch)
   int fp_contract = 0; // 0: -ffp-contract=off (bit-comparable with the oracle's arithmetic), 1: fast (FMA)
   int obj_wgs = 1024;  // obj: at most this many workgroups walk the tiles (one partial each; fixed, so the summation order is)
+  int flat2d = 0;      // 1: every 2-D support grid is walked by one linear lane index (no partly filled workgroup per row; sub-box
+                       // templates stored by item ordinal).  Opt-in: measured equal on jac/hess and slower on cons! for pandemic
+                       // 5000 x 100 (profiles/r02_ab_flush_flat.txt) — the 256-lane tiles of Options::block = 0 already remove the waste
+  int flush32 = 2;     // block-store loops: 2 = 32-bit offsets relative to the block start, per-lane predicate on every round (default);
+                       // 1 = whole rounds decided by scalar compares + branch (1-5 % SLOWER: the branches cost more than the predicates
+                       // they save); 0 = round-1 form with 64-bit predicates (equal to 2) — profiles/r02_ab_flush_flat.txt
   int obj_unroll = 1;  // 2: the objective's tile walk takes two tiles per trip (single-body kernels)
   int det_shared = 1;  // 1: scatter entries shared by many items are reduced deterministically (iem_shared_*), 0: one f64 atomic per wave
 };

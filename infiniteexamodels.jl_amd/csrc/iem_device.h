@@ -160,6 +160,63 @@ __device__ __forceinline__ void iem_stage(const double (&v)[NS], double *__restr
 // writes exactly the 128-byte lines that START inside its own STRIDE lanes — whole lines only,
 // except at the two ends of the row.  STRIDE = IEM_TILE: disjoint tiles, a partial line at
 // every seam (two workgroups write the two parts; costs ~10 % of the store rate).
+// The range logic runs in 32-bit offsets relative to `lo` (the block's first element).  Measured
+// (profiles/r02_ab_flush_flat.txt, in-process A/B): deciding whole rounds with scalar compares and a
+// branch (IEM_FLUSH32 == 1) is 1-5 % SLOWER than a per-lane predicate on every round — the kernels
+// wait on the store queue, not on instruction issue — so the default (2) predicates every round.
+//   ph   = lo & 15: phase of the block's first element inside its 128-byte line
+//   n_u  = elements of the lanes only this workgroup computes, n_all = of all its lanes (halo included)
+//   prev = elements the PREVIOUS workgroup's lanes reach past `lo` (its halo), -1: no previous workgroup
+template <int NS, int STRIDE>
+__device__ __forceinline__ void iem_flush_rel(double *__restrict__ out_lo, const double *__restrict__ lds_lo, int ph, int n_u,
+                                              int n_all, int prev) {
+  const int t = (int)threadIdx.x;
+  int own_lo = 0, own_hi = n_all;
+  if (STRIDE < IEM_TILE) {
+    if (prev >= 0) {                       // not the first workgroup of the row: start at the next line boundary ...
+      own_lo = (16 - ph) & 15;
+      if (own_lo > prev) own_lo = prev;    // ... but never leave a gap behind what the previous workgroup could write
+    }
+    own_hi = ((ph + n_u + 15) & ~15) - ph;
+    if (own_hi > n_all) own_hi = n_all;
+  }
+  const int e_al = ((ph + own_lo) & ~15) - ph;   // in (-16, 16): 128-byte aligned in the output
+#if IEM_WIDE_STORES
+#pragma unroll
+  for (int j = 0; j < (NS + 3) / 2; ++j) {
+    const int e = e_al + 2 * t + j * (2 * IEM_TILE);
+    const bool a = e >= own_lo && e < own_hi, b = e + 1 >= own_lo && e + 1 < own_hi;
+    if (a && b) iem_stg2(out_lo + e, lds_lo[e], lds_lo[e + 1]);
+    else if (a) iem_stg(out_lo + e, lds_lo[e]);
+    else if (b) iem_stg(out_lo + e + 1, lds_lo[e + 1]);
+  }
+#else
+#if IEM_FLUSH32 == 2
+#pragma unroll
+  for (int j = 0; j <= NS; ++j) {          // 32-bit per-lane predicate on every round, no branch
+    const int e = e_al + t + j * IEM_TILE;
+    if (e >= own_lo && e < own_hi) iem_stg(out_lo + e, lds_lo[e]);
+  }
+#else
+#pragma unroll
+  for (int j = 0; j <= NS; ++j) {
+    const int eb = e_al + j * IEM_TILE;    // block-uniform
+    if (eb >= own_lo && eb + IEM_TILE <= own_hi) {
+      iem_stg(out_lo + eb + t, lds_lo[eb + t]);
+    } else if (eb < own_hi && eb + IEM_TILE > own_lo) {
+      const int e = eb + t;
+      if (e >= own_lo && e < own_hi) iem_stg(out_lo + e, lds_lo[e]);
+    }
+  }
+#endif
+#endif
+}
+
+#ifndef IEM_FLUSH32
+#define IEM_FLUSH32 2
+#endif
+#if !IEM_FLUSH32
+// round-1 form (knob flush32 = 0, A/B runs only): 64-bit range checks as per-lane predicates on every round
 template <int NS, int STRIDE>
 __device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0, int v0, int v1, bool first,
                                           const double *__restrict__ lds_reg) {
@@ -167,33 +224,82 @@ __device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0
   const long long lo = P0 + (long long)v0 * NS, hi_all = P0 + (long long)v1 * NS;
   long long own_lo = lo, own_hi = hi_all;
   if (STRIDE < IEM_TILE) {
-    if (v0 >= STRIDE) return;   // the row starts in the halo: the next workgroup owns all of it
+    if (v0 >= STRIDE) return;
     const int vu = v1 < STRIDE ? v1 : STRIDE;
-    const long long hi_u = P0 + (long long)vu * NS;   // end of the lanes only this workgroup computes
+    const long long hi_u = P0 + (long long)vu * NS;
     if (!first) own_lo = (lo + 15) & ~15LL;
     own_hi = (hi_u + 15) & ~15LL;
     if (own_hi > hi_all) own_hi = hi_all;
   }
   const long long e_al = own_lo & ~15LL;
-#if IEM_WIDE_STORES
-  // 16 bytes per lane (a 16 GB fill runs at 7.0 TB/s with 16-byte stores, 6.6 with 8-byte ones):
-  // lane t owns the element pair (2t, 2t+1) of each 2*TILE-element round; pairs cut by own_lo /
-  // own_hi (only at the two ends of a row) fall back to single stores
-#pragma unroll
-  for (int j = 0; j < (NS + 3) / 2; ++j) {
-    const long long e = e_al + 2 * t + (long long)j * (2 * IEM_TILE);
-    const bool a = e >= own_lo && e < own_hi, b = e + 1 >= own_lo && e + 1 < own_hi;
-    if (a && b) iem_stg2(out + e, lds_reg[e - P0], lds_reg[e + 1 - P0]);
-    else if (a) iem_stg(out + e, lds_reg[e - P0]);
-    else if (b) iem_stg(out + e + 1, lds_reg[e + 1 - P0]);
-  }
-#else
 #pragma unroll
   for (int j = 0; j <= NS; ++j) {
     const long long e = e_al + t + (long long)j * IEM_TILE;
     if (e >= own_lo && e < own_hi) iem_stg(out + e, lds_reg[e - P0]);
   }
+}
+#else
+template <int NS, int STRIDE>
+__device__ __forceinline__ void iem_flush(double *__restrict__ out, long long P0, int v0, int v1, bool first,
+                                          const double *__restrict__ lds_reg) {
+  if (STRIDE < IEM_TILE && v0 >= STRIDE) return;   // the row starts in the halo: the next workgroup owns all of it
+  if (v1 <= v0) return;
+  const long long lo = P0 + (long long)v0 * NS;
+  const int vu = v1 < STRIDE ? v1 : STRIDE;
+  // previous workgroup's reach past lo: its lanes end 16 lanes into this tile
+  const int prev = first ? -1 : ((v1 < 16 ? v1 : 16) - v0) * NS;
+  iem_flush_rel<NS, STRIDE>(out + lo, lds_reg + v0 * NS, (int)(lo & 15), (vu - v0) * NS, (v1 - v0) * NS, prev);
+}
 #endif
+
+// ---- flat 2-D grids: block store by ITEM ORDINAL -----------------------------------------------
+// A 2-D support grid (E0 x E1, first coordinate fastest) walked by ONE linear lane index has no
+// partly filled workgroup at the end of every row.  A template whose item box is a sub-box of the
+// grid (the difference rows t = 2..Nt) then skips lanes, so its items are not lane-linear any more —
+// but they are still consecutive in ORDINAL: ord_lt(q) = number of the template's items at flat
+// indices < q.  Lanes stage at (ord - ord_lt(first lane)) and the workgroup writes the contiguous
+// positions of the ordinals it owns; ownership is the whole-line rule of iem_flush, stated in
+// ordinals: workgroup b owns the lines that start in [lo_b, lo_{b+1}) rounded up, never past what
+// its own lanes (halo included) computed.
+// (row, column) of a workgroup's first flat index: one division per workgroup, through a double
+// reciprocal (exact after one correction step for q < 2^52) instead of the 64-bit integer sequence
+__device__ __forceinline__ void iem_flat_base(long long q, long long E0, long long &r1, long long &r0) {
+  long long d = (long long)((double)q / (double)E0);
+  long long r = q - d * E0;
+  if (r < 0) { --d; r += E0; }
+  if (r >= E0) { ++d; r -= E0; }
+  r1 = d; r0 = r;
+}
+// (r1, r0) = (row, column) of flat index  fr1*E0 + fr0 + d,  0 <= fr0 < E0, 0 <= d <= IEM_TILE
+__device__ __forceinline__ void iem_flat_split(long long fr1, long long fr0, int d, long long E0, long long &r1, long long &r0) {
+  const long long t = fr0 + d;
+  const long long adv = E0 >= 2 * IEM_TILE ? (t >= E0 ? 1LL : 0LL) : (long long)((unsigned)t / (unsigned)E0);   // t < E0 + IEM_TILE
+  r1 = fr1 + adv;
+  r0 = t - adv * E0;
+}
+// items of the box [lo0, lo0 + w0) x [lo1, lo1 + h1) at flat positions before (r1, r0)
+__device__ __forceinline__ long long iem_ord_lt(long long r1, long long r0, long long lo0, long long w0, long long lo1, long long h1) {
+  long long rows = r1 - lo1;
+  rows = rows < 0 ? 0 : (rows > h1 ? h1 : rows);
+  long long in = 0;
+  if (r1 >= lo1 && r1 < lo1 + h1) { in = r0 - lo0; in = in < 0 ? 0 : (in > w0 ? w0 : in); }
+  return rows * w0 + in;
+}
+template <int NS>
+__device__ __forceinline__ void iem_stage_ord(const double (&v)[NS], double *__restrict__ lds_reg, long long slot, bool valid) {
+  if (valid) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) lds_reg[slot * NS + s] = v[s];
+  }
+}
+// o = position of ordinal 0; ob / o16 / ou / oa = ord_lt at this workgroup's lane 0, lane 16 (= where the
+// PREVIOUS workgroup's lanes end), lane STRIDE (where the next workgroup starts) and lane IEM_TILE
+template <int NS, int STRIDE>
+__device__ __forceinline__ void iem_flush_ord(double *__restrict__ out, long long o, long long ob, long long o16, long long ou,
+                                              long long oa, const double *__restrict__ lds_reg, long long /*slot*/, bool /*valid*/) {
+  if (oa <= ob) return;
+  const long long lo = o + NS * ob;
+  iem_flush_rel<NS, STRIDE>(out + lo, lds_reg, (int)(lo & 15), (int)(ou - ob) * NS, (int)(oa - ob) * NS, ob > 0 ? (int)(o16 - ob) * NS : -1);
 }
 
 template <int NS>

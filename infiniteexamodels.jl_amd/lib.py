@@ -37,13 +37,13 @@ class Option(C.Structure):
 
 
 class ShardT(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("group", "rank", "world", "reserved")] + \
+    _fields_ = [(n, C.c_int32) for n in ("group", "rank", "world", "mailbox_kind")] + \
                [(n, C.c_int64) for n in ("n_global", "own_lo", "own_n", "halo", "halo_reach", "halo_doubles", "nvar_global",
                                          "ncon_global", "nnzj_global", "nnzh_global", "nvar", "ncon", "nnzj", "nnzh",
                                          "n_templates", "n_shared")]
 
     def asdict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 class ShardTemplate(C.Structure):
@@ -157,7 +157,7 @@ def set_option(name: str, value: int):
 
 # generator knobs and their defaults (csrc/iem_codegen.hpp: struct Options)
 OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=0, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
-                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1)
+                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2)
 
 
 def option_array(opts: dict):

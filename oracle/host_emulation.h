@@ -69,6 +69,48 @@ inline void iem_flush(double *out, long long P0, int v0, int v1, bool first, con
     if (e >= own_lo && e < own_hi) out[e] = lds_reg[t * NS + s];
   }
 }
+inline void iem_flat_base(long long q, long long E0, long long &r1, long long &r0) { r1 = q / E0; r0 = q - r1 * E0; }
+inline void iem_flat_split(long long fr1, long long fr0, int d, long long E0, long long &r1, long long &r0) {
+  const long long t = fr0 + d, adv = t / E0;
+  r1 = fr1 + adv;
+  r0 = t - adv * E0;
+}
+inline long long iem_ord_lt(long long r1, long long r0, long long lo0, long long w0, long long lo1, long long h1) {
+  long long rows = r1 - lo1;
+  rows = rows < 0 ? 0 : (rows > h1 ? h1 : rows);
+  long long in = 0;
+  if (r1 >= lo1 && r1 < lo1 + h1) { in = r0 - lo0; in = in < 0 ? 0 : (in > w0 ? w0 : in); }
+  return rows * w0 + in;
+}
+// one lane at a time: the lane remembers where it staged and writes exactly its own elements that
+// fall into the range its workgroup owns (the device version's ownership rule)
+static thread_local long long emu_ord_slot = -1;
+template <int NS>
+inline void iem_stage_ord(const double (&v)[NS], double *lds_reg, long long slot, bool valid) {
+  emu_ord_slot = valid ? slot : -1;
+  if (valid) for (int s = 0; s < NS; ++s) lds_reg[slot * NS + s] = v[s];
+}
+template <int NS, int STRIDE>
+inline void iem_flush_ord(double *out, long long o, long long ob, long long o16, long long ou, long long oa, const double *lds_reg,
+                          long long slot, bool valid) {
+  const long long lo = o + NS * ob, hi_all = o + NS * oa;
+  long long own_lo = lo, own_hi = hi_all;
+  if (STRIDE < IEM_TILE) {
+    const long long hi_u = o + NS * ou;
+    if (ob > 0) {
+      own_lo = (lo + 15) & ~15LL;
+      const long long prev_all = o + NS * o16;
+      if (own_lo > prev_all) own_lo = prev_all;
+    }
+    own_hi = (hi_u + 15) & ~15LL;
+    if (own_hi > hi_all) own_hi = hi_all;
+  }
+  if (!valid) return;
+  for (int s = 0; s < NS; ++s) {
+    const long long e = lo + slot * NS + s;
+    if (e >= own_lo && e < own_hi) out[e] = lds_reg[slot * NS + s];
+  }
+}
 inline void __syncthreads() {}
 inline void iem_block_partial(double v, double *partials, long long slot, double *, long long n, double *out) {
   partials[slot] += v;                       // lanes run one at a time: the partial accumulates in place

@@ -140,7 +140,8 @@ def main():
             assert abs(fsum - O.obj(xg)) <= 1e-10 * max(1.0, abs(O.obj(xg)))
         dist.barrier()
     if rank == 0:
-        print("OK", name, world, info["halo_doubles"], info["n_shared"], "graph" if graph is not None else "eager")
+        print("OK", name, world, info["halo_doubles"], info["n_shared"], "graph" if graph is not None else "eager",
+              "mailbox_kind", gm.shard_info()["mailbox_kind"])
     dist.destroy_process_group()
 
 

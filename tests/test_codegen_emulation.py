@@ -101,14 +101,37 @@ def test_long_second_grid_dimension_is_folded(lane_fused):
     """A 2-D support grid whose second extent exceeds gridDim.y (65535) is folded over blockIdx.z;
     the overshoot blocks must neither load nor store."""
     from infiniteexamodels.jl_amd import transcribe, workloads
+    from infiniteexamodels.jl_amd import lib as iemlib
     core = transcribe.exa_core(workloads.pandemic(54, 66000))     # 64 x 66000 supports
     blob = core.to_blob()
     om = OracleModel(blob)
     x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
-    em = EmulatedModel(core, blob)
+    em = EmulatedModel(core, blob)        # default: lanes along t, xi on blockIdx.y/z
     assert any(k["grid"][2] > 1 for k in em.kernels)
     assert _rel(em.cons(x), om.cons(x)) <= 1e-14
     assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
+
+
+@pytest.mark.parametrize("nt,nxi", [(54, 300), (300, 7), (490, 23), (1000, 3), (70, 41)])
+def test_flat_two_dimensional_grids_store_by_ordinal(nt, nxi, lane_fused):
+    """Opt-in `flat2d`: 2-D support grids walked by ONE linear lane index (no partly filled workgroup per
+    row); the difference templates (t = 2..Nt, a sub-box) are staged and written by item ordinal.  Row
+    lengths below, around and above the tile, so that rows start and end anywhere inside a workgroup."""
+    from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
+    core = transcribe.exa_core(workloads.pandemic(nt, nxi))
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
+    y = np.random.default_rng(1).standard_normal(om.ncon)
+    with iemlib.options(flat2d=1):
+        em = EmulatedModel(core, blob)
+    assert all(k["grid"][1] == 1 and k["grid"][2] == 1 for k in em.kernels)
+    assert "iem_flush_ord<" in em.source
+    assert _rel(em.cons(x), om.cons(x)) <= 1e-14
+    assert _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-14
+    assert _rel(em.hess_coord(x, y, 1.0, om.nnzh), om.hess_coord(x, y, 1.0)) <= 1e-14
+    v = np.random.default_rng(2).standard_normal(om.nvar)
+    assert _rel(em.jprod(x, v), om.jprod(x, v)) <= 1e-13
 
 
 def test_short_first_dimension_uses_flat_lanes(lane_fused):

@@ -304,10 +304,11 @@ def test_merged_hessian_layout_gpu(name, torch_cuda):
     gm.close()
 
 
-@pytest.mark.parametrize("nt,nxi", [(54, 66000), (2, 70000)])
-def test_folded_or_flat_grids_gpu(nt, nxi, torch_cuda):
-    """64 x 66000 supports: the second grid dimension is folded over blockIdx.z;
-    12 x 70000: the short first dimension switches the kernel to flat lane indexing."""
+@pytest.mark.parametrize("nt,nxi,flat2d", [(54, 66000, 0), (2, 70000, 0), (54, 66000, 1), (490, 2300, 1), (1190, 701, 1)])
+def test_folded_or_flat_grids_gpu(nt, nxi, flat2d, torch_cuda):
+    """flat2d = 0 — 64 x 66000 supports: the second grid dimension is folded over blockIdx.z; 12 x 70000: the
+    short first dimension switches the kernel to flat lane indexing.  flat2d = 1 (default): every 2-D grid is
+    walked by one linear lane index and sub-box templates are stored by item ordinal (iem_flush_ord)."""
     torch = torch_cuda
     from infiniteexamodels.jl_amd import transcribe, workloads
     from infiniteexamodels.jl_amd.model import ExaModel
@@ -316,7 +317,7 @@ def test_folded_or_flat_grids_gpu(nt, nxi, torch_cuda):
     blob = core.to_blob()
     om = OracleModel(blob)
     om.set_threads(min(16, om.max_threads()))
-    gm = ExaModel(core, device=0, blob=blob)
+    gm = ExaModel(core, device=0, blob=blob, options={"flat2d": flat2d})
     x = np.abs(om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)) + 0.05
     y = np.random.default_rng(1).standard_normal(om.ncon)
     xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")

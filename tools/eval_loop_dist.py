@@ -145,7 +145,7 @@ def main():
         print(json.dumps({
             "workload": f"{args.workload}, {int(tot[1].item())} supports over {world} rank(s) ({own} on rank 0), full loop "
                         "obj+grad!+allreduce+cons!+jac_coord!+hess_coord!",
-            "n_gpus": world, "dist_backend": args.dist_backend, "allreduce": args.allreduce, "halo_doubles": info["halo_doubles"], "same_device": bool(args.same_device), "scaling": "weak",
+            "n_gpus": world, "dist_backend": args.dist_backend, "allreduce": args.allreduce, "halo_doubles": info["halo_doubles"], "mailbox_kind": m.shard_info()["mailbox_kind"], "same_device": bool(args.same_device), "scaling": "weak",
             "nvar_rank0": meta.nvar, "ncon_rank0": meta.ncon, "nnzj_rank0": meta.nnzj, "nnzh_rank0": meta.nnzh,
             "loop_ms": dt / args.iters * 1e3, "loops_per_s": args.iters / dt,
             "supports_per_s": float(tot[1].item()) * args.iters / dt,
