@@ -313,7 +313,8 @@ def main():
                                    f"{S_local} per GPU, jac_coord!+hess_coord! only, seed 0/1 inputs resident in HBM",
                        "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
                        "store_mode": args.store_mode, "hess_layout": args.hess_layout, "parallelism": par,
-                       "launch": "hipGraph replay" if args.graph else "eager"},
+                       "launch": "hipGraph replay" if args.graph else "eager",
+                       "kernels_from": "hiprtc at run time (code-object cache miss)" if any(k["jit"] for k in gm.kernels()) else "in-tree code-object cache"},
             "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
                          "traffic_source": traffic_src,

@@ -654,6 +654,12 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
     if (shard_group > 0) {   // cut this rank's window out of the global model (iem_shard.hpp)
       iem::shard_model(m->model, shard_group, rank, world, m->shard);
       m->sharded = true;
+      // continue from the shard's own blob — byte for byte what iem_shard_blob hands out — so that the
+      // generated source (hence the code-object cache key) is the one an offline build of that blob gets,
+      // and the global arrays nothing references any more (x0/lvar/uvar of the whole model) are released
+      std::vector<int64_t> local = iem::serialize_model(m->model);
+      m->model = iem::Model();
+      iem::parse_blob(local.data(), local.size() * 8, m->model);
     }
     m->prog = iem::generate(m->model, m->opt);
   } catch (const std::exception &e) {

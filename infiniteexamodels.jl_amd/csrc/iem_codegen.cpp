@@ -44,14 +44,20 @@ constexpr double kR2D = 57.29577951308232;
 constexpr double kLN2 = 0.6931471805599453;
 constexpr double kLN10 = 2.302585092994046;
 
+// `space` names what the value indexes (0 grid/box constants, 1 x, 2 theta, 3 an output position,
+// 100 + slot an item-data array, 200 + slot an integer column): values of different spaces are never
+// merged, so that a NUMERIC coincidence between, say, a local slab offset and a global data offset
+// (which depends on the rank and the world size of a shard) cannot change the shape of the source.
 struct AffQ {
   int64_t c = 0, k[3] = {0, 0, 0};
+  int space = 0;
   bool operator<(const AffQ &o) const {
+    if (space != o.space) return space < o.space;
     if (c != o.c) return c < o.c;
     for (int d = 0; d < 3; ++d) if (k[d] != o.k[d]) return k[d] < o.k[d];
     return false;
   }
-  bool operator==(const AffQ &o) const { return c == o.c && k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2]; }
+  bool operator==(const AffQ &o) const { return space == o.space && c == o.c && k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2]; }
 };
 
 struct Group {
@@ -144,10 +150,11 @@ class KernelBuilder {
       : m_(m), g_(g), kind_(kind), opt_(opt), name_(name) {}
 
   // ---- parameters ---------------------------------------------------------
-  std::string ip(int64_t v) {
-    auto it = ip_ids_.find(v);
+  std::string ip(int64_t v, int space = 0) {
+    auto key = std::make_pair(space, v);
+    auto it = ip_ids_.find(key);
     if (it == ip_ids_.end()) {
-      it = ip_ids_.emplace(v, (int)ipv_.size()).first;
+      it = ip_ids_.emplace(key, (int)ipv_.size()).first;
       ipv_.push_back(v);
     }
     return "A.ip[" + std::to_string(it->second) + "]";
@@ -319,10 +326,11 @@ class KernelBuilder {
     return a;
   }
 
-  int tpl_idx(int ti, int idx_id, const TGeo &G, int64_t bias) {
+  int tpl_idx(int ti, int idx_id, const TGeo &G, int64_t bias, int space) {
     const Template &t = m_.tpl[ti];
     const IdxExpr &ix = t.idx[idx_id];
     IdxVal iv;
+    iv.aff.space = space;
     iv.aff.c = ix.c0 + bias;
     for (int j = 0; j < ix.nterms; ++j) {
       const FieldDesc &f = t.ifields[ix.field[j]];
@@ -331,6 +339,7 @@ class KernelBuilder {
         iv.aff.c += ix.coef[j] * fa.c;
         for (int d = 0; d < 3; ++d) iv.aff.k[d] += ix.coef[j] * fa.k[d];
       } else {
+        fa.space = 200 + ia_slot(f.arr);
         int il = iload(ia_slot(f.arr), fa, G.guard);
         iv.ind.emplace_back(ix.coef[j], il);
       }
@@ -341,6 +350,7 @@ class KernelBuilder {
 
   AffQ klin_aff(const Template &t, const TGeo &G, int64_t scale, int64_t off) const {
     AffQ a;
+    a.space = 3;
     a.c = off;
     int64_t stride = 1;
     for (int d = 0; d < t.nd; ++d) {
@@ -367,11 +377,11 @@ class KernelBuilder {
       vidx.assign(t.idx.size(), -1);
     }
     int idx1(int id) {
-      if (vidx[id] < 0) vidx[id] = K.tpl_idx(ti, id, G, 0);
+      if (vidx[id] < 0) vidx[id] = K.tpl_idx(ti, id, G, 0, 1);
       return vidx[id];
     }
-    int pos0(int id) {  // 0-based position of a 1-based index
-      return K.tpl_idx(ti, id, G, -1);
+    int pos0(int id, int space = 1) {  // 0-based position of a 1-based index (space 1: x / g, 2: theta)
+      return K.tpl_idx(ti, id, G, -1, space);
     }
     void forward(int order) {
       for (size_t n = 0; n < t.nodes.size(); ++n) {
@@ -386,11 +396,12 @@ class KernelBuilder {
             } else {
               IdxVal iv;
               iv.aff = K.field_aff(t, f, G);
+              iv.aff.space = 100 + K.fa_slot(f.arr);
               val[n] = K.load(3, K.fa_slot(f.arr), K.idxval(iv), G.guard);
             }
             break;
           }
-          case IEM_OP_PAR: val[n] = K.load(1, 0, pos0(nd.a), G.guard); break;
+          case IEM_OP_PAR: val[n] = K.load(1, 0, pos0(nd.a, 2), G.guard); break;
           case IEM_OP_VAR: val[n] = K.load(0, 0, pos0(nd.a), G.guard); break;
           default:
             if (IEM_OP_IS_UNARY(nd.op)) unary((int)n, order);
@@ -686,7 +697,7 @@ class KernelBuilder {
         case KK_JTPROD: {  // (J' v)[col] += dc/dx_slot * v[row]  == gradient of  v . c(x)
           tg.forward(1);
           tg.slots1.assign(t.o1step, -1);
-          IdxVal rv; rv.aff = klin_aff(t, G, 1, t.o0);
+          IdxVal rv; rv.aff = klin_aff(t, G, 1, t.o0); rv.aff.space = 4;   // a row index (into v), not an output position
           int seed = load(4, 0, idxval(rv), G.guard);
           tg.gr(t.root, 0, seed);
           o.vals = tg.slots1;
@@ -703,7 +714,7 @@ class KernelBuilder {
           int adj;
           if (t.kind == IEM_T_OBJ) adj = mk(VW, 0, -1, -1, -1, 0);
           else {
-            IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
+            IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0); iv.aff.space = 4;   // a row index (into y), not an output position
             adj = load(2, 0, idxval(iv), G.guard);
           }
           tg.hr0(t.root, 0, adj, C(0.0));
@@ -742,7 +753,7 @@ class KernelBuilder {
           int adj;
           if (t.kind == IEM_T_OBJ) adj = mk(VW, 0, -1, -1, -1, 0);
           else {
-            IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0);
+            IdxVal iv; iv.aff = klin_aff(t, G, 1, t.o0); iv.aff.space = 4;   // a row index (into y), not an output position
             adj = load(2, 0, idxval(iv), G.guard);
           }
           tg.hr0(t.root, 0, adj, C(0.0));
@@ -940,11 +951,11 @@ class KernelBuilder {
     bool any = false;
     if (g_.flat && g_.nd == 2 && a.k[0] != 0 && a.k[1] == a.k[0] * g_.ext[0] && a.k[2] == 0) {
       // a slab walked at full stride on a flat 2-D grid: c + k*(q0 + E0*q1) is c + k*q — no 64-bit multiply per index
-      if (a.c != 0) os << ip(a.c) << " + ";
+      if (a.c != 0) os << ip(a.c, a.space) << " + ";
       if (a.k[0] == 1) os << "q"; else os << coefstr(a.k[0]) << " * q";
       return os.str();
     }
-    if (a.c != 0) { os << ip(a.c); any = true; }
+    if (a.c != 0) { os << ip(a.c, a.space); any = true; }
     for (int d = 0; d < 3; ++d) {
       if (a.k[d] == 0) continue;
       if (any) os << " + ";
@@ -1194,7 +1205,7 @@ class KernelBuilder {
                << "    iem_flat_split(fr1_, fr0_, 16, " << ip(g_.ext[0]) << ", r1_, r0_); const long long o16 = iem_ord_lt(r1_, r0_, " << box << ");\n"
                << "    iem_flat_split(fr1_, fr0_, " << qstep_str() << ", " << ip(g_.ext[0]) << ", r1_, r0_); const long long ou = iem_ord_lt(r1_, r0_, " << box << ");\n"
                << "    iem_flat_split(fr1_, fr0_, IEM_TILE, " << ip(g_.ext[0]) << ", r1_, r0_); const long long oa = iem_ord_lt(r1_, r0_, " << box << ");\n"
-               << "    iem_flush_ord<" << ns << ", " << qstep_str() << ">(OUT, " << ip(o.pos_off) << ", " << on << ", o16, ou, oa, lds_blk + "
+               << "    iem_flush_ord<" << ns << ", " << qstep_str() << ">(OUT, " << ip(o.pos_off, 3) << ", " << on << ", o16, ou, oa, lds_blk + "
                << (batch_slots * opt_.block) << ", sl" << oi << ", " << g << "); }\n";
             pending_flush.push_back(fl.str());
             batch_slots += ns;
@@ -1223,7 +1234,7 @@ class KernelBuilder {
             pb.k[0] = 0;
             if (g_.flat) {
               // full-box template in a flat group: item ordinal == flat lane index
-              fl << "  { const long long pb = " << ip(pv.aff.c) << " + " << coefstr(k0) << " * qb0;\n";
+              fl << "  { const long long pb = " << ip(pv.aff.c, pv.aff.space) << " + " << coefstr(k0) << " * qb0;\n";
               fl << "    const int v0 = 0;\n";
               fl << "    const int v1 = iem_clamp256(" << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << " - qb0);\n";
             } else {
@@ -1294,7 +1305,7 @@ class KernelBuilder {
       head << "  {\n    const long long nb_ = (long long)gridDim.x * gridDim.y * gridDim.z;\n"
            << "    const long long b_ = (long long)blockIdx.x + (long long)gridDim.x * ((long long)blockIdx.y + (long long)gridDim.y * blockIdx.z);\n";
       for (auto &z : zero_fill_) {
-        head << "    iem_zero_fill(OUT + " << ip(z.first) << ", " << ip(z.second - z.first) << ", b_, nb_);\n";
+        head << "    iem_zero_fill(OUT + " << ip(z.first, 5) << ", " << ip(z.second - z.first, 5) << ", b_, nb_);\n";
         alg_w_ += z.second - z.first;
       }
       head << "  }\n";
@@ -1460,7 +1471,7 @@ class KernelBuilder {
 
   int ip_index(int64_t v) {
     ip(v);
-    return ip_ids_[v];
+    return ip_ids_[std::make_pair(0, v)];
   }
 
   static constexpr int IEM_BLOCK_WAVES = 4;
@@ -1481,7 +1492,7 @@ class KernelBuilder {
   std::vector<std::string> guards_;
   std::map<std::string, int> guard_ids_;
   std::vector<Output> outs_;
-  std::map<int64_t, int> ip_ids_;
+  std::map<std::pair<int, int64_t>, int> ip_ids_;
   std::vector<int64_t> ipv_;
   std::map<uint64_t, int> dp_ids_;
   std::vector<double> dpv_;

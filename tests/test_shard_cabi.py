@@ -185,3 +185,21 @@ def test_time_sharded_pandemic_keeps_its_stencil_local(built):
         f += L.obj(x)
     assert np.array_equal(c, ref["c"]) and np.array_equal(j, ref["j"]) and np.array_equal(h, ref["h"])
     assert abs(f - G.obj(xg)) <= 1e-12 * max(1.0, abs(G.obj(xg)))
+
+
+def test_shard_kernels_are_rank_world_and_size_independent(built):
+    """A numeric coincidence between, say, a local slab offset and a global data offset depends on the rank
+    and the world size; it must not change the SHAPE of the generated source (index values are merged
+    per index space only).  Every shard of a time-sharded quadrotor is one of two code objects — the first
+    rank's (point constraints; the unsharded model's own kernels) and every later rank's — whatever the
+    world size and the horizon, so the in-tree code-object cache serves an 8-GPU run."""
+    g_small = transcribe.exa_core(workloads.quadrotor(4000)).to_blob()
+    g_big = transcribe.exa_core(workloads.quadrotor(600_000)).to_blob()    # 75 000 supports per shard of 8: the lane-fused regime
+    with iemlib.options(split_small=0):
+        first = {iemlib.emit_source(iemlib.shard_blob(g_small, 1, 0, 2)[0])[1], iemlib.emit_source(g_small)[1]}
+        later = {iemlib.emit_source(iemlib.shard_blob(g_small, 1, 1, 2)[0])[1]}
+    for r, w in ((0, 8), (0, 3)):
+        first.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
+    for r, w in ((1, 8), (3, 8), (7, 8), (1, 2), (2, 3)):
+        later.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
+    assert len(first) == 1 and len(later) == 1 and first != later
