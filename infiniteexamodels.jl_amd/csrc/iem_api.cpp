@@ -92,7 +92,7 @@ std::string lib_dir() {
 std::string cache_dir() {
   const char *e = std::getenv("IEM_KERNEL_CACHE");
   if (e && *e) return e;
-  return lib_dir() + "/../kernels";
+  return lib_dir() + "/kernels";   // next to libiem_hip.so: where lib.precompile / build() put the offline-built objects
 }
 
 std::string key_hex(uint64_t k) {

@@ -394,3 +394,20 @@ def test_two_handles_with_different_options_coexist(torch_cuda):
     assert iemlib.emit_source(blob)[1] == key_before
     for m in (merged, plain, waves):
         m.close()
+
+
+def test_offline_code_objects_are_used(torch_cuda):
+    """A model whose kernels build() compiled offline (hipcc --genco into infiniteexamodels.jl_amd/kernels) must
+    LOAD that object at iem_create, not recompile it with hiprtc (round 1 looked for the cache one directory too
+    high and compiled every model at run time)."""
+    import os
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.model import ExaModel
+    blob = cases.build_core("quadrotor_100").to_blob()
+    _, key = iemlib.emit_source(blob)
+    path = os.path.join(iemlib.KERNEL_DIR, f"iem_{key:016x}.hsaco")
+    if not os.path.exists(path):
+        pytest.skip("no offline-built object for this model in the tree (build() not run)")
+    gm = ExaModel.from_blob(blob)
+    assert not any(k["jit"] for k in gm.kernels()), "the offline-built code object was not used"
+    gm.close()
