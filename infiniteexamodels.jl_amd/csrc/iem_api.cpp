@@ -716,7 +716,16 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
   }
   m->argbuf.resize(m->prog.kernels.size());
   for (size_t k = 0; k < m->prog.kernels.size(); ++k) build_argbuf(m, k);
-  for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) m->zero_ranges[kind] = m->prog.zero_ranges[kind];
+  for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) {
+    // ranges the kernels of the kind do not overwrite completely.  Neighbouring ranges separated by a SHORT
+    // fully-overwritten stretch are zeroed as one (what lies between is written afterwards, on the same
+    // stream): one memset launch instead of two around pandemic's u(t) slab (grad! 11.5 -> 6 us of memsets)
+    auto &zr = m->zero_ranges[kind];
+    for (auto &z : m->prog.zero_ranges[kind]) {
+      if (!zr.empty() && z.first - zr.back().second <= std::max<int64_t>(8192, (z.second - zr.front().first) / 16)) zr.back().second = z.second;
+      else zr.push_back(z);
+    }
+  }
   m->grad_zero = m->zero_ranges[iem::KK_GRAD];
   if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) return bail(fail(IEM_E_HIP, "hipEventCreate"));
   *out = m;

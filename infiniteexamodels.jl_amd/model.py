@@ -271,6 +271,23 @@ class ExaModel:
     def synchronize(self):
         _lib.check(self._L.iem_synchronize(self._h))
 
+    def raw_pair(self, x, y, jac, hess, obj_weight: float = 1.0):
+        """``step()`` closure for hot loops: one ``iem_jac_coord`` + one ``iem_hess_coord`` on fixed buffers with the
+        Python-side argument checks and the stream lookup done ONCE here (what a compiled host — the Julia
+        ``ccall`` shim — pays per call is the two C calls, not ~10 µs of interpreter work each)."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(y, self.meta.ncon, "y")
+        self._chk(jac, self.meta.nnzj, "vals"); self._chk(hess, self.meta.nnzh, "vals")
+        self._sync_stream()
+        L, h = self._L, self._h
+        px, py, pj, ph, w = _ptr(x), _ptr(y), _ptr(jac), _ptr(hess), float(obj_weight)
+        jac_coord, hess_coord, check = L.iem_jac_coord, L.iem_hess_coord, _lib.check
+
+        def step():
+            rc = jac_coord(h, px, pj) or hess_coord(h, px, py, w, ph)
+            if rc:
+                check(rc)
+        return step
+
     # ---- sharding / multi-GPU ------------------------------------------------------
     def shard_info(self) -> dict:
         t = _lib.ShardT()
