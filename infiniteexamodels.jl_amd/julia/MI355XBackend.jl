@@ -124,6 +124,29 @@ function set_parameter!(m::MI355XModel, param, vals)
                 m.handle, param.offset, length(v), v))
 end
 
+# ---- multi-GPU: one process per GPU (e.g. under MPI.jl) ----------------------------------------
+# UNEXECUTED, like the rest of this file.  Every rank builds the SAME global core; the library cuts the
+# rank's support window (include/iem.h: iem_create_sharded) — `slabs` / `template_groups` as for to_blob.
+# `allgather(bytes) -> Vector{UInt8}` is the host's transport (MPI.Allgather, ...): 128 bytes per rank.
+function MI355XShardedModel(core, backend::MI355XBackend, group::Int, rank::Int, world::Int, allgather;
+                            slabs, template_groups = nothing)
+    blob = to_blob(core; slabs = slabs, template_groups = template_groups)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:iem_create_sharded, LIBIEM), Cint,
+                (Ptr{UInt8}, Csize_t, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}),
+                blob, length(blob), backend.device, group, rank, world, C_NULL, 0, h))
+    mine = Vector{UInt8}(undef, 128)                       # IEM_COMM_HANDLE_BYTES
+    check(ccall((:iem_comm_export, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{UInt8}), h[], mine))
+    check(ccall((:iem_comm_connect, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{UInt8}), h[], allgather(mine)))
+    return h[]                                             # wrap like MI355XModel(core, backend) (meta from iem_meta)
+end
+# before cons!/jac_coord!/hess_coord!: the stencil neighbours x_k[a_r - 1] from the left rank (transform.jl:535-557)
+halo_exchange!(m::MI355XModel, x::ROCVector{Float64}) =
+    (check(ccall((:iem_halo_exchange, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.handle, dptr(x))); x)
+# after obj (device scalar f) / grad!: objective + gradient entries of replicated variables, summed over the ranks
+allreduce_obj_grad!(m::MI355XModel, f::ROCVector{Float64}, g::ROCVector{Float64}) =
+    (check(ccall((:iem_allreduce_obj_grad, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), m.handle, dptr(f), dptr(g))); (f, g))
+
 # ---- blob writer ----------------------------------------------------------------------------
 # Serialises a host ExaCore into the wire format of include/iem_blob.h.  [EXT]: the field and
 # type names of ExaModels' internal structs (Objective/Constraint linked lists, SIMDFunction,
