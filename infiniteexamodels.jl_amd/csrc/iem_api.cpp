@@ -1000,8 +1000,10 @@ size_t mailbox_words(int64_t W, int64_t NH, int64_t NR) {
 
 struct CommHandle {   // what iem_comm_export writes (IEM_COMM_HANDLE_BYTES)
   hipIpcMemHandle_t ipc;
-  int64_t pid, device, rank, world, words;
+  int32_t pid, device, rank, world, kind, pad;
+  int64_t words;
   uint64_t local_ptr;
+  char bus[16];       // PCI bus id of the GPU the mailbox lives on ("0000:05:00.0"): device ordinals are per process
 };
 static_assert(sizeof(CommHandle) <= IEM_COMM_HANDLE_BYTES, "comm handle too large");
 
@@ -1100,8 +1102,14 @@ int iem_comm_export(iem_model *m, void *out_handle) {
   } else {
     HIP_TRY(hipIpcGetMemHandle(&h.ipc, m->mailbox));
   }
-  h.pid = (int64_t)getpid(); h.device = m->device; h.rank = si.rank; h.world = si.world; h.words = (int64_t)m->mailbox_words;
+  h.pid = (int32_t)getpid(); h.device = m->device; h.rank = si.rank; h.world = si.world; h.words = (int64_t)m->mailbox_words;
+  h.kind = m->mailbox_kind;
   h.local_ptr = (uint64_t)(uintptr_t)m->mailbox;
+  {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, m->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    std::memcpy(h.bus, bus, sizeof(h.bus) - 1);   // h was zeroed: stays terminated
+  }
   std::memset(out_handle, 0, IEM_COMM_HANDLE_BYTES);
   std::memcpy(out_handle, &h, sizeof h);
   return IEM_OK;
@@ -1114,13 +1122,20 @@ int iem_comm_connect(iem_model *m, const void *all_handles) {
   DevGuard dg_(m->device);
   const iem::ShardInfo &si = m->shard;
   m->peers.assign((size_t)si.world, nullptr);
+  CommHandle mine;
+  std::memcpy(&mine, (const char *)all_handles + (size_t)si.rank * IEM_COMM_HANDLE_BYTES, sizeof mine);
   for (int r = 0; r < si.world; ++r) {
     CommHandle h;
     std::memcpy(&h, (const char *)all_handles + (size_t)r * IEM_COMM_HANDLE_BYTES, sizeof h);
     if (h.rank != r || h.world != si.world || h.words != (int64_t)m->mailbox_words)
       return fail(IEM_E_ARG, "iem_comm_connect: handle " + std::to_string(r) + " does not belong to this communicator");
+    // a kernel polls its mailbox while peers write into it: across GPUs that is only coherent for
+    // fine-grained memory — refuse plain hipMalloc mailboxes there instead of timing out at run time
+    if ((h.kind == 2 || mine.kind == 2) && std::strncmp(h.bus, mine.bus, sizeof h.bus) != 0)
+      return fail(IEM_E_HIP, "iem_comm_connect: this runtime gave no fine-grained IPC memory for the mailboxes; "
+                             "ranks on different GPUs cannot use them — fall back to the host's collective (RCCL) for obj/grad and copy the halo");
     if (r == si.rank) { m->peers[r] = m->mailbox; continue; }
-    if (h.pid == (int64_t)getpid()) {   // same process (one process driving several handles): the pointer itself
+    if (h.pid == (int32_t)getpid()) {   // same process (one process driving several handles): the pointer itself
       if ((int)h.device != m->device) {
         hipError_t e = hipDeviceEnablePeerAccess((int)h.device, 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(IEM_E_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));

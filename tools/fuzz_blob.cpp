@@ -25,6 +25,16 @@ int main(int argc, char **argv) {
     int rc2 = iem_emit_launch_plan(b.data(), b.size(), &plan);
     int rc3 = iem_blob_hess_structure(b.data(), b.size(), 1, &r, &c, &nnz);
     if (src) iem_free(src); if (plan) iem_free(plan); if (r) iem_free(r); if (c) iem_free(c);
+    for (int rw = 0; rw < 3; ++rw) {   // the window cut of iem_create_sharded: slab table, re-based indices, serialiser, re-parse
+      static const int ranks[3] = {0, 1, 2}, worlds[3] = {2, 2, 3};
+      void *lb = nullptr; size_t ln = 0; iem_shard_t info; int64_t *vm = nullptr; uint8_t *vf = nullptr; iem_shard_template_t *tp = nullptr;
+      if (iem_shard_blob(b.data(), b.size(), 1, ranks[rw], worlds[rw], &lb, &ln, &info, &vm, &vf, &tp) == 0) {
+        char *s2 = nullptr;
+        iem_emit_source(lb, ln, &s2, &key);
+        if (s2) iem_free(s2);
+        iem_free(lb); iem_free(vm); iem_free(vf); iem_free(tp);
+      }
+    }
     (rc1 || rc2 || rc3) ? ++rej : ++ok;
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (dt > 1) fprintf(stderr, "  SLOW %.1fs\n", dt);
