@@ -58,7 +58,13 @@ class ExaTranscriptionBackend:
         self.empty()
         self._inf_model = inf_model
         self.core = transcribe.exa_core(inf_model, self.data, backend=self.backend)
-        if isinstance(self.backend, MI355XBackend):
+        if isinstance(self.backend, MI355XBackend) and self.backend.shard is not None:
+            # one rank of a multi-GPU run: the same global core on every rank, the window cut in the library;
+            # theta stays global there, so update_parameter_value / set_parameter! work unchanged
+            self.model = ExaModel.sharded(self.core.to_blob(), *self.backend.shard, device=self.backend.device)
+            self.model.core = self.core
+            self.core._model = self.model
+        elif isinstance(self.backend, MI355XBackend):
             self.model = ExaModel(self.core)            # ExaModels.ExaModel(backend.core)
         elif self.backend is not None:
             raise TypeError(f"unsupported backend {self.backend!r}: use MI355XBackend() (the CPU ExaModel of the "

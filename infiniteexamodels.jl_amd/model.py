@@ -24,11 +24,15 @@ class MI355XBackend:
     """Value for ``backend =`` that selects the HIP evaluator (the reference's
     ``CUDABackend()`` slot, ``README.md:41``)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, shard=None):
+        """``shard = (group, rank, world)``: this process is rank ``rank`` of a ``world``-GPU run sharded over
+        the supports of infinite-parameter group ``group`` (1 = the first parameter): the backend still
+        transcribes the GLOBAL model, ``iem_create_sharded`` cuts the rank's window."""
         self.device = int(device)
+        self.shard = tuple(int(v) for v in shard) if shard is not None else None
 
     def __repr__(self):
-        return f"MI355XBackend(device={self.device})"
+        return f"MI355XBackend(device={self.device}" + (f", shard={self.shard})" if self.shard else ")")
 
 
 def _ptr(t) -> int:

@@ -100,3 +100,33 @@ def test_shard_and_config_cores_match_oracle(spec, built):
     _close(gm.jtprod(xd, vcd, nanv(om.nvar)).cpu().numpy(), om.jtprod(x, vc), "jtprod")
     _close(gm.hprod(xd, yd, vd, nanv(om.nvar), obj_weight=0.6).cpu().numpy(), om.hprod(x, y, v, 0.6), "hprod")
     gm.close()
+
+
+def test_backend_plug_point_with_a_shard(built):
+    """`ExaTranscriptionBackend(solver; backend = MI355XBackend(0, shard = (group, rank, world)))`: the reference's plug
+    point (src/infiniteopt_backend.jl:112-131,155-156) on one rank of a sharded run — global transcription, window cut in
+    the library, and the parameter-update hook (:511-550 -> set_parameter!) reaching the rank's (global) theta."""
+    import torch
+    import cases
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
+    from infiniteexamodels.jl_amd.model import MI355XBackend
+    from pyoracle import OracleModel
+    m, (P1, P2) = cases.rosenbrock()
+    be = ExaTranscriptionBackend(solver=None, backend=MI355XBackend(0, shard=(1, 1, 2)))
+    be.build_transformation_backend(m)
+    gm = be.model
+    info = gm.shard_info()
+    assert (info["rank"], info["world"], info["n_global"]) == (1, 2, 3) and gm.meta.nvar < be.core.nvar
+    vm, _ = gm.shard_var_map()
+    x = np.array([0.4, 0.5, 0.6, 1.9, 2.0, 2.1])[vm]
+    xd = torch.tensor(x, device="cuda")
+    for p1 in (100.0, 90.0):
+        if p1 != 100.0:
+            assert be.update_parameter_value(P1, p1)
+        so = OracleModel(iemlib.shard_blob(be.core.to_blob(), 1, 1, 2)[0])      # the same cut of the UPDATED core
+        np.testing.assert_array_equal(gm.theta, so.theta)
+        assert abs(gm.obj(xd) - so.obj(x)) <= RTOL * max(1.0, abs(so.obj(x)))
+        _close(gm.grad(xd).cpu().numpy(), so.grad(x), "grad")
+        _close(gm.jac_coord(xd).cpu().numpy(), so.jac_coord(x), "jac")
+    be.empty()
