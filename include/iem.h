@@ -122,6 +122,10 @@ typedef struct iem_shard_template_t {
   int64_t klo[3], dims[3], global_dims[3];
   int64_t o0, o1, o2, global_o0, global_o1, global_o2;
   int64_t o1step, o2step;
+  /* -1: the local items are the box klo .. klo + dims of global_dims; >= 0: the template is an explicit item
+   * list (a domain restriction filtered its iterator, transform.jl:448-451) and local item j is global item
+   * items[items_offset + j] of the array iem_shard_template_items / iem_shard_blob hand out */
+  int64_t items_offset;
 } iem_shard_template_t;
 #define IEM_COMM_HANDLE_BYTES 128
 int iem_create_sharded(const void *blob, size_t nbytes, int device, int group, int rank, int world,
@@ -131,10 +135,14 @@ int iem_shard_info(const iem_model *m, iem_shard_t *out);
  * bit 1 replicated on every rank, bit 2 halo copy of the left neighbour's variable (either may be NULL) */
 int iem_shard_var_map(const iem_model *m, int64_t *h_map, uint8_t *h_flag);
 int iem_shard_template_info(const iem_model *m, int64_t i, iem_shard_template_t *out);
+/* global item ordinals of every explicit-list template, concatenated (see items_offset); h_items may be NULL to
+ * query the length */
+int iem_shard_template_items(const iem_model *m, int64_t *h_items, int64_t *out_n);
 /* the cut without a device (tooling / tests): the rank's shard re-serialised as a blob of its own, plus
- * the maps; every out array is malloc'ed (iem_free), any of the last four may be NULL */
+ * the maps; every out array is malloc'ed (iem_free), any of the last five may be NULL */
 int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int world, void **out_blob, size_t *out_nbytes,
-                   iem_shard_t *out_info, int64_t **out_var_map, uint8_t **out_var_flag, iem_shard_template_t **out_tpl);
+                   iem_shard_t *out_info, int64_t **out_var_map, uint8_t **out_var_flag, iem_shard_template_t **out_tpl,
+                   int64_t **out_items);
 int iem_comm_export(iem_model *m, void *out_handle /* IEM_COMM_HANDLE_BYTES */);
 int iem_comm_connect(iem_model *m, const void *all_handles /* world x IEM_COMM_HANDLE_BYTES, rank order */);
 int iem_halo_exchange(iem_model *m, double *d_x);

@@ -988,6 +988,18 @@ void fill_shard_tpl(const iem::Model &M, const iem::ShardInfo &si, size_t i, iem
   for (int d = 0; d < 3; ++d) { o->klo[d] = st.klo[d]; o->dims[d] = t.dims[d]; o->global_dims[d] = st.gdims[d]; }
   o->o0 = t.o0; o->o1 = t.o1; o->o2 = t.o2; o->global_o0 = st.go0; o->global_o1 = st.go1; o->global_o2 = st.go2;
   o->o1step = t.o1step; o->o2step = t.o2step; o->kind = t.kind;
+  o->items_offset = -1;
+  if (st.explicit_items) {
+    int64_t off = 0;
+    for (size_t j = 0; j < i; ++j) if (si.tpl[j].explicit_items) off += (int64_t)si.tpl[j].items.size();
+    o->items_offset = off;
+  }
+}
+
+std::vector<int64_t> shard_items(const iem::ShardInfo &si) {
+  std::vector<int64_t> all;
+  for (const iem::ShardTpl &st : si.tpl) if (st.explicit_items) all.insert(all.end(), st.items.begin(), st.items.end());
+  return all;
 }
 
 // mailbox words: see iem_device.h
@@ -1010,7 +1022,8 @@ static_assert(sizeof(CommHandle) <= IEM_COMM_HANDLE_BYTES, "comm handle too larg
 }  // namespace
 
 int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int world, void **out_blob, size_t *out_nbytes,
-                   iem_shard_t *out_info, int64_t **out_var_map, uint8_t **out_var_flag, iem_shard_template_t **out_tpl) {
+                   iem_shard_t *out_info, int64_t **out_var_map, uint8_t **out_var_flag, iem_shard_template_t **out_tpl,
+                   int64_t **out_items) {
   if (!blob || !out_blob || !out_nbytes) return fail(IEM_E_ARG, "null argument");
   try {
     iem::Model model;
@@ -1033,6 +1046,11 @@ int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int wor
     if (out_tpl) {
       *out_tpl = (iem_shard_template_t *)std::malloc(sizeof(iem_shard_template_t) * std::max<size_t>(si.tpl.size(), 1));
       for (size_t i = 0; i < si.tpl.size(); ++i) fill_shard_tpl(model, si, i, *out_tpl + i);
+    }
+    if (out_items) {
+      const std::vector<int64_t> all = shard_items(si);
+      *out_items = (int64_t *)std::malloc(sizeof(int64_t) * std::max<size_t>(all.size(), 1));
+      std::memcpy(*out_items, all.data(), all.size() * 8);
     }
     return IEM_OK;
   } catch (const std::exception &e) {
@@ -1061,6 +1079,15 @@ int iem_shard_template_info(const iem_model *m, int64_t i, iem_shard_template_t 
   if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
   if (i < 0 || i >= (int64_t)m->shard.tpl.size()) return fail(IEM_E_ARG, "bad template index");
   fill_shard_tpl(m->model, m->shard, (size_t)i, out);
+  return IEM_OK;
+}
+
+int iem_shard_template_items(const iem_model *m, int64_t *h_items, int64_t *out_n) {
+  if (!m || !out_n) return fail(IEM_E_ARG, "null argument");
+  if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
+  const std::vector<int64_t> all = shard_items(m->shard);
+  *out_n = (int64_t)all.size();
+  if (h_items) std::memcpy(h_items, all.data(), all.size() * 8);
   return IEM_OK;
 }
 

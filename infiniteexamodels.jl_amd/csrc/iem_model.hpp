@@ -105,7 +105,8 @@ struct Model {
   int arr_x0 = 0, arr_lvar = 0, arr_uvar = 0, arr_theta = 0;
   std::vector<ArrayDesc> arrs;
   std::vector<Template> tpl;
-  std::deque<std::vector<double>> synth;  // arrays created by recover_lattice (ArrayDesc::data points here)
+  std::deque<std::vector<double>> synth;  // arrays created by recover_lattice / the shard cut (ArrayDesc::data points here)
+  std::deque<std::vector<int64_t>> synth_i;   // ... integer columns (shard cut of explicit item lists)
 };
 
 inline double w2d(int64_t w) {

@@ -24,7 +24,10 @@
 //     fields of the local item box).
 // Supported: templates on support grids (grid hint present) with affine integer fields, stencils
 // that reach to the LEFT only (backward differences) — what the reference's default derivative
-// method emits.  Anything else throws with a message (IEM_E_BLOB at the ABI).
+// method emits; and explicit item lists (a domain restriction filters the iterator,
+// transform.jl:448-451) whose variable indices all sit at the item's own support: the list is
+// filtered to the owned supports and every column re-gathered.  Anything else throws with a message
+// (IEM_E_BLOB at the ABI).
 #pragma once
 #include <algorithm>
 #include <map>
@@ -41,6 +44,8 @@ struct ShardTpl {           // a local template and where it sits in the global 
   int64_t klo[3] = {0, 0, 0};   // local item coordinate 0 = global item coordinate klo
   int64_t gdims[3] = {1, 1, 1}; // the global item box
   int64_t go0 = 0, go1 = 0, go2 = 0;
+  bool explicit_items = false;  // an explicit item list (domain restriction, transform.jl:448-451): local item j = global item items[j]
+  std::vector<int64_t> items;
 };
 
 struct HaloSeg {            // one sharded slab of the LOCAL x (window length wn along the sharded axis)
@@ -189,6 +194,7 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
   // pass 1: which item dimension of each template runs over the group; stencil reach
   const size_t nt = m.tpl.size();
   std::vector<int> sdim(nt, -1);
+  std::vector<char> explicit_tpl(nt, 0);
   std::vector<std::vector<Walk>> walks(nt);
   int64_t reach = 0;
   for (size_t ti = 0; ti < nt; ++ti) {
@@ -198,6 +204,14 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
     for (int d = 0; d < t.nd; ++d) if (dim_group(t, d) == group) sdim[ti] = d;
     walks[ti].resize(t.idx.size());
     if (t.n_items == 0) continue;
+    bool gathered = false;
+    for (size_t i = 0; i < t.idx.size(); ++i)
+      if (is_var[i] && !idx_affine(t, t.idx[i]).ok) gathered = true;
+    if (gathered) {   // explicit item list: handled item by item in pass 2
+      if (t.nd != 1 || sdim[ti] >= 0) throw std::runtime_error("template " + std::to_string(ti) + ": explicit index columns on a support-grid template cannot be sharded");
+      explicit_tpl[ti] = 1;
+      continue;
+    }
     for (size_t i = 0; i < t.idx.size(); ++i) {
       if (!is_var[i]) continue;
       walks[ti][i] = walk_of(m, t, ti, t.idx[i]);
@@ -282,6 +296,101 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
     std::vector<char> is_var(t.idx.size(), 0);
     for (const Node &nd : t.nodes) if (nd.op == IEM_OP_VAR) is_var[nd.a] = 1;
     int64_t klo[3] = {0, 0, 0};
+    if (explicit_tpl[ti]) {
+      // item by item: where does each variable index sit, which items does this rank own
+      const int64_t n = t.n_items;
+      auto ifield_at = [&](const FieldDesc &f, int64_t k) { const int64_t p = f.base + f.step[0] * k; return f.mode == IEM_F_AFFINE ? p : m.arrs[f.arr].i(p); };
+      std::vector<std::vector<int64_t>> lidx(t.idx.size());   // per variable index expression: local 1-based index per item (0: outside the window)
+      std::vector<int64_t> coord((size_t)n, -1);              // the item's support on the sharded axis (-1: touches no sharded slab)
+      for (size_t i = 0; i < t.idx.size(); ++i) {
+        if (!is_var[i]) continue;
+        lidx[i].assign((size_t)n, 0);
+        for (int64_t k = 0; k < n; ++k) {
+          int64_t v = t.idx[i].c0;
+          for (int j = 0; j < t.idx[i].nterms; ++j) v += t.idx[i].coef[j] * ifield_at(t.ifields[t.idx[i].field[j]], k);
+          if (v < 1 || v > info.nvar_global) throw std::runtime_error(where + ": variable index out of range");
+          const int si = find_slab(m.slabs, v - 1);
+          const Slab &g = m.slabs[si], &l = ls[si];
+          int64_t rem = v - 1 - g.off, c3[3];
+          c3[0] = rem % g.dims[0]; rem /= g.dims[0]; c3[1] = rem % g.dims[1]; c3[2] = rem / g.dims[1];
+          const int ax = sax[si];
+          if (ax >= 0) {
+            if (coord[(size_t)k] >= 0 && coord[(size_t)k] != c3[ax]) throw std::runtime_error(where + ": an explicit item list with a stencil along the sharded group is not supported");
+            coord[(size_t)k] = c3[ax];
+            c3[ax] -= wlo;
+            if (c3[ax] < 0 || c3[ax] >= wn) continue;   // outside this rank's window: the item is not kept (checked below)
+          }
+          lidx[i][(size_t)k] = l.off + 1 + c3[0] + l.dims[0] * (c3[1] + l.dims[1] * c3[2]);
+        }
+      }
+      int64_t cmin = -1, cmax = -1;
+      for (int64_t k = 0; k < n; ++k) if (coord[(size_t)k] >= 0) { cmin = cmin < 0 ? coord[(size_t)k] : std::min(cmin, coord[(size_t)k]); cmax = std::max(cmax, coord[(size_t)k]); }
+      std::vector<int64_t> keep;
+      if (cmin >= 0 && cmin != cmax) {            // runs over the sharded group: the owned supports
+        for (int64_t k = 0; k < n; ++k) {
+          if (coord[(size_t)k] < 0) throw std::runtime_error(where + ": an explicit item list mixes items on and off the sharded group");
+          if (coord[(size_t)k] >= a0 && coord[(size_t)k] < b0) keep.push_back(k);
+        }
+      } else {                                     // one support (or none): like a point-variable template
+        int owner = 0;
+        if (cmin >= 0) for (; owner < world; ++owner) { int64_t a, b; partition_block(ng, world, owner, a, b); if (cmin >= a && cmin < b) break; }
+        if (owner != rank) continue;
+        for (int64_t k = 0; k < n; ++k) keep.push_back(k);
+      }
+      const int64_t nk = (int64_t)keep.size();
+      auto new_i64 = [&](std::vector<int64_t> v) {
+        m.synth_i.push_back(std::move(v));
+        ArrayDesc a; a.kind = IEM_A_I64_DATA; a.n = (int64_t)m.synth_i.back().size(); a.data = m.synth_i.back().data();
+        m.arrs.push_back(a);
+        return (int)m.arrs.size() - 1;
+      };
+      auto new_f64 = [&](std::vector<double> v) {
+        m.synth.push_back(std::move(v));
+        ArrayDesc a; a.kind = IEM_A_F64_DATA; a.n = (int64_t)m.synth.back().size(); a.data = m.synth.back().data();
+        m.arrs.push_back(a);
+        return (int)m.arrs.size() - 1;
+      };
+      auto as_column = [](FieldDesc &f, int arr) { f.mode = IEM_F_GATHER; f.base = 0; f.step[0] = 1; f.step[1] = f.step[2] = 0; f.arr = arr; };
+      for (FieldDesc &f : t.ifields) {
+        std::vector<int64_t> col((size_t)nk);
+        for (int64_t j = 0; j < nk; ++j) col[(size_t)j] = ifield_at(f, keep[(size_t)j]);
+        as_column(f, new_i64(std::move(col)));
+      }
+      for (FieldDesc &f : t.ffields) {
+        std::vector<double> col((size_t)nk);
+        for (int64_t j = 0; j < nk; ++j) col[(size_t)j] = m.arrs[f.arr].f(f.base + f.step[0] * keep[(size_t)j]);
+        as_column(f, new_f64(std::move(col)));
+      }
+      for (size_t i = 0; i < t.idx.size(); ++i) {
+        if (!is_var[i]) continue;
+        std::vector<int64_t> col((size_t)nk);
+        for (int64_t j = 0; j < nk; ++j) {
+          col[(size_t)j] = lidx[i][(size_t)keep[(size_t)j]];
+          if (col[(size_t)j] == 0) throw std::runtime_error(where + ": a variable index leaves the rank's window");
+        }
+        FieldDesc f;
+        as_column(f, new_i64(std::move(col)));
+        IdxExpr &ix = t.idx[i];
+        ix.c0 = 0; ix.nterms = 1; ix.field[0] = (int)t.ifields.size(); ix.coef[0] = 1;
+        for (int j = 1; j < IEM_MAX_IDX_TERMS; ++j) { ix.field[j] = 0; ix.coef[j] = 0; }
+        t.ifields.push_back(f);
+      }
+      auto cut_bound = [&](int mode, int &arr) {
+        if (mode != 1) return;
+        std::vector<double> col((size_t)nk);
+        for (int64_t j = 0; j < nk; ++j) col[(size_t)j] = m.arrs[arr].f(keep[(size_t)j]);
+        arr = new_f64(std::move(col));
+      };
+      cut_bound(t.lmode, t.larr); cut_bound(t.umode, t.uarr);
+      t.n_items = nk; t.dims[0] = nk; t.dims[1] = t.dims[2] = 1;
+      t.grid_id = -1; t.origin[0] = t.origin[1] = t.origin[2] = 0;
+      st.explicit_items = true; st.items = keep;
+      t.o2 = o2; o2 += t.n_items * t.o2step;
+      if (t.kind == IEM_T_CON) { t.o0 = o0; o0 += t.n_items; t.o1 = o1; o1 += t.n_items * t.o1step; }
+      kept.push_back(std::move(t));
+      info.tpl.push_back(st);
+      continue;
+    }
     if (sdim[ti] >= 0) {
       const int d = sdim[ti];
       const int64_t lo = std::min(std::max<int64_t>(a0 - t.origin[d], 0), t.dims[d]);

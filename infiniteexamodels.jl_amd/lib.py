@@ -49,11 +49,21 @@ class ShardT(C.Structure):
 class ShardTemplate(C.Structure):
     _fields_ = [("global_index", C.c_int64), ("kind", C.c_int64), ("n_items", C.c_int64), ("klo", C.c_int64 * 3),
                 ("dims", C.c_int64 * 3), ("global_dims", C.c_int64 * 3)] + \
-               [(n, C.c_int64) for n in ("o0", "o1", "o2", "global_o0", "global_o1", "global_o2", "o1step", "o2step")]
+               [(n, C.c_int64) for n in ("o0", "o1", "o2", "global_o0", "global_o1", "global_o2", "o1step", "o2step", "items_offset")]
 
-    def asdict(self):
+    def asdict(self, items=None):
+        """``items``: the concatenated explicit item lists; adds ``ordinals`` = global item ordinal of every local item."""
+        import numpy as np
         d = {n: getattr(self, n) for n, _ in self._fields_}
-        return {k: (tuple(int(x) for x in v) if hasattr(v, "__len__") else int(v)) for k, v in d.items()}
+        d = {k: (tuple(int(x) for x in v) if hasattr(v, "__len__") else int(v)) for k, v in d.items()}
+        if d["items_offset"] >= 0:
+            d["ordinals"] = np.asarray(items[d["items_offset"]:d["items_offset"] + d["n_items"]], dtype=np.int64)
+        else:
+            k0, k1, k2 = (np.arange(n) for n in d["dims"])
+            g0, g1, _ = d["global_dims"]
+            d["ordinals"] = ((d["klo"][0] + k0)[None, None, :] + g0 * ((d["klo"][1] + k1)[None, :, None]
+                             + g1 * (d["klo"][2] + k2)[:, None, None])).reshape(-1)
+        return d
 
 
 COMM_HANDLE_BYTES = 128
@@ -66,7 +76,7 @@ class KernelInfo(C.Structure):
 
 # every symbol include/iem.h declares (tests check the export list against the header)
 SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_info", "iem_shard_var_map", "iem_shard_template_info",
-           "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_allreduce_obj_grad", "iem_comm_status",
+           "iem_shard_template_items", "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_allreduce_obj_grad", "iem_comm_status",
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
@@ -111,7 +121,8 @@ def lib():
     L.iem_shard_var_map.argtypes = [vp, vp, vp]
     L.iem_shard_template_info.argtypes = [vp, i64, C.POINTER(ShardTemplate)]
     L.iem_shard_blob.argtypes = [C.c_char_p, C.c_size_t, i32, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(ShardT),
-                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.iem_shard_template_items.argtypes = [vp, vp, C.POINTER(C.c_int64)]
     L.iem_comm_export.argtypes = [vp, vp]
     L.iem_comm_connect.argtypes = [vp, vp]
     L.iem_halo_exchange.argtypes = [vp, vp]
@@ -256,18 +267,20 @@ def shard_blob(blob: bytes, group: int, rank: int, world: int):
     import numpy as np
     L = lib()
     ob, on, info = C.c_void_p(), C.c_size_t(), ShardT()
-    vm, vf, tp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    vm, vf, tp, it = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
     check(L.iem_shard_blob(blob, len(blob), group, rank, world, C.byref(ob), C.byref(on), C.byref(info),
-                           C.byref(vm), C.byref(vf), C.byref(tp)))
+                           C.byref(vm), C.byref(vf), C.byref(tp), C.byref(it)))
     try:
         local = C.string_at(ob, on.value)
         n = int(info.nvar)
         var_map = np.ctypeslib.as_array(C.cast(vm, C.POINTER(C.c_int64)), shape=(max(n, 1),))[:n].copy()
         var_flag = np.ctypeslib.as_array(C.cast(vf, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
         tarr = C.cast(tp, C.POINTER(ShardTemplate))
-        tpl = [tarr[i].asdict() for i in range(int(info.n_templates))]
+        n_items = sum(int(tarr[i].n_items) for i in range(int(info.n_templates)) if tarr[i].items_offset >= 0)
+        items = np.ctypeslib.as_array(C.cast(it, C.POINTER(C.c_int64)), shape=(max(n_items, 1),))[:n_items].copy()
+        tpl = [tarr[i].asdict(items) for i in range(int(info.n_templates))]
     finally:
-        for p in (ob, vm, vf, tp):
+        for p in (ob, vm, vf, tp, it):
             L.iem_free(p)
     return local, info.asdict(), var_map, var_flag, tpl
 

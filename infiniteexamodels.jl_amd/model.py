@@ -306,11 +306,17 @@ class ExaModel:
         return vm[:self.meta.nvar], vf[:self.meta.nvar]
 
     def shard_templates(self):
+        """Per local template: where it sits in the global model; ``["ordinals"]`` = global item ordinal of every
+        local item (global row = ``global_o0 + ordinal``, COO position = ``global_o1 + o1step·ordinal + slot``)."""
+        n = C.c_int64()
+        _lib.check(self._L.iem_shard_template_items(self._h, None, C.byref(n)))
+        items = np.zeros(max(int(n.value), 1), dtype=np.int64)
+        _lib.check(self._L.iem_shard_template_items(self._h, items.ctypes.data, C.byref(n)))
         out = []
         for i in range(self.meta.n_templates):
             t = _lib.ShardTemplate()
             _lib.check(self._L.iem_shard_template_info(self._h, i, C.byref(t)))
-            out.append(t.asdict())
+            out.append(t.asdict(items))
         return out
 
     def comm_export(self) -> bytes:

@@ -56,7 +56,7 @@ def main():
     jpos = np.full(gm.meta.nnzj, -1)
     hpos = np.full(gm.meta.nnzh, -1)
     for t in tpl:
-        k = ordinals(t)
+        k = t["ordinals"]
         if t["kind"] == 1:
             row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
             if t["o1step"]:

@@ -88,7 +88,7 @@ def test_cxx_cut_equals_python_shards_and_reassembles(name, size, world, group, 
         jpos = np.full(L.nnzj, -1)
         hpos = np.full(L.nnzh, -1)
         for t in tpl:
-            k = _ordinals(t)
+            k = t["ordinals"]
             assert k.size == t["n_items"]
             if t["kind"] == 1:
                 row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
@@ -121,9 +121,6 @@ def test_cxx_cut_equals_python_shards_and_reassembles(name, size, world, group, 
 def test_unsupported_inputs_fail_loudly(built):
     import cases
     L = iemlib.lib()
-    g = cases.build_core("irregular").to_blob()          # explicit index columns on the sharded group
-    with pytest.raises(iemlib.IemError):
-        iemlib.shard_blob(g, 1, 0, 2)
     q = cases.build_core("quadrotor_oc3_40").to_blob()   # collocation: stencil over element/node boxes, not backward differences
     with pytest.raises(iemlib.IemError):
         iemlib.shard_blob(q, 1, 1, 2)
@@ -174,7 +171,7 @@ def test_time_sharded_pandemic_keeps_its_stencil_local(built):
         x = xg[vmap]
         row_map = np.full(L.ncon, -1); jpos = np.full(L.nnzj, -1); hpos = np.full(L.nnzh, -1)
         for t in tpl:
-            k = _ordinals(t)
+            k = t["ordinals"]
             if t["kind"] == 1:
                 row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
                 if t["o1step"]:
@@ -203,3 +200,64 @@ def test_shard_kernels_are_rank_world_and_size_independent(built):
     for r, w in ((1, 8), (3, 8), (7, 8), (1, 2), (2, 3)):
         later.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
     assert len(first) == 1 and len(later) == 1 and first != later
+
+
+def _restricted(supports=None, n=130):
+    """tests/cases.irregular: a domain restriction that is not a contiguous range (transform.jl:448-451) + a
+    finite variable + a derivative — over all supports, or over a window of them (the Python shard)."""
+    from infiniteexamodels.jl_amd.infinite import DomainRestriction, InfiniteModel
+    m = InfiniteModel()
+    t = m.infinite_parameter("t", 0, 1, supports=supports) if supports is not None else m.infinite_parameter("t", 0, 1, num_supports=n)
+    y = m.variable("y", t, start=1.0)
+    w = m.variable("w", start=0.5)
+    m.constraint(y ** 2 * w >= 2, restriction=DomainRestriction(lambda s: np.sin(40 * s) >= 0.2, t))
+    m.constraint(m.deriv(y, t) == -y * w)
+    m.objective("min", m.integral(y ** 2, t) + w ** 2)
+    return m
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_explicit_item_lists_are_filtered_to_the_owned_supports(world, built):
+    """A domain-restricted constraint reaches the library as an explicit item list (index COLUMNS, no box).
+    The cut keeps the items whose support the rank owns and re-gathers every column; equal to the Python
+    transcriber's shard bit for bit, and reassembling the global model through `ordinals`."""
+    from infiniteexamodels.jl_amd.infinite import _round_sig
+    gdata = transcribe.ExaMappingData()
+    gcore = transcribe.exa_core(_restricted(), gdata)
+    gblob = gcore.to_blob()
+    G = OracleModel(gblob)
+    xg = np.abs(G.x0 + 0.1 * np.random.default_rng(0).standard_normal(G.nvar)) + 0.05
+    yg = np.random.default_rng(1).standard_normal(G.ncon)
+    ref = dict(c=G.cons(xg), j=G.jac_coord(xg), h=G.hess_coord(xg, yg, 0.7))
+    c = np.full(G.ncon, np.nan); j = np.full(G.nnzj, np.nan); h = np.full(G.nnzh, np.nan)
+    t_g = _round_sig(np.linspace(0.0, 1.0, 130))
+    n_explicit = 0
+    for r in range(world):
+        lblob, info, vmap, vflag, tpl = iemlib.shard_blob(gblob, 1, r, world)
+        L = OracleModel(lblob)
+        # the Python transcriber's shard of the same statement
+        local, f = shard.window(t_g, r, world, halo=1)
+        pm = _restricted(supports=local)
+        pm.shard = shard.ShardSpec(group_index=1, rank=r, world=world, **f)
+        P = OracleModel(transcribe.exa_core(pm, transcribe.ExaMappingData()).to_blob())
+        assert (P.nvar, P.ncon, P.nnzj, P.nnzh) == (L.nvar, L.ncon, L.nnzj, L.nnzh)
+        x = xg[vmap]
+        row_map = np.full(L.ncon, -1); jpos = np.full(L.nnzj, -1); hpos = np.full(L.nnzh, -1)
+        for t in tpl:
+            k = t["ordinals"]
+            n_explicit += t["items_offset"] >= 0
+            if t["kind"] == 1:
+                row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
+                if t["o1step"]:
+                    jpos[t["o1"]:t["o1"] + k.size * t["o1step"]] = (t["global_o1"] + t["o1step"] * k[:, None] + np.arange(t["o1step"])[None, :]).reshape(-1)
+            if t["o2step"]:
+                hpos[t["o2"]:t["o2"] + k.size * t["o2step"]] = (t["global_o2"] + t["o2step"] * k[:, None] + np.arange(t["o2step"])[None, :]).reshape(-1)
+        y = yg[row_map]
+        for a, b in ((L.cons(x), P.cons(x)), (L.jac_coord(x), P.jac_coord(x)), (L.hess_coord(x, y, 0.7), P.hess_coord(x, y, 0.7)),
+                     (L.grad(x), P.grad(x)), (L.lcon, P.lcon), (L.ucon, P.ucon)):
+            assert np.array_equal(a, b)
+        for a, b in ((L.jac_structure(), P.jac_structure()), (L.hess_structure(), P.hess_structure())):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        c[row_map] = L.cons(x); j[jpos] = L.jac_coord(x); h[hpos] = L.hess_coord(x, y, 0.7)
+    assert n_explicit == world
+    assert np.array_equal(c, ref["c"]) and np.array_equal(j, ref["j"]) and np.array_equal(h, ref["h"])

@@ -28,11 +28,12 @@ int main(int argc, char **argv) {
     for (int rw = 0; rw < 3; ++rw) {   // the window cut of iem_create_sharded: slab table, re-based indices, serialiser, re-parse
       static const int ranks[3] = {0, 1, 2}, worlds[3] = {2, 2, 3};
       void *lb = nullptr; size_t ln = 0; iem_shard_t info; int64_t *vm = nullptr; uint8_t *vf = nullptr; iem_shard_template_t *tp = nullptr;
-      if (iem_shard_blob(b.data(), b.size(), 1, ranks[rw], worlds[rw], &lb, &ln, &info, &vm, &vf, &tp) == 0) {
+      int64_t *its = nullptr;
+      if (iem_shard_blob(b.data(), b.size(), 1, ranks[rw], worlds[rw], &lb, &ln, &info, &vm, &vf, &tp, &its) == 0) {
         char *s2 = nullptr;
         iem_emit_source(lb, ln, &s2, &key);
         if (s2) iem_free(s2);
-        iem_free(lb); iem_free(vm); iem_free(vf); iem_free(tp);
+        iem_free(lb); iem_free(vm); iem_free(vf); iem_free(tp); iem_free(its);
       }
     }
     (rc1 || rc2 || rc3) ? ++rej : ++ok;
