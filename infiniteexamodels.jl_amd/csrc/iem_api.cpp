@@ -1037,11 +1037,11 @@ int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int wor
     if (out_info) fill_shard_t(model, si, out_info);
     if (out_var_map) {
       *out_var_map = (int64_t *)std::malloc(sizeof(int64_t) * std::max<size_t>(si.var_map.size(), 1));
-      std::memcpy(*out_var_map, si.var_map.data(), si.var_map.size() * 8);
+      if (!si.var_map.empty()) std::memcpy(*out_var_map, si.var_map.data(), si.var_map.size() * 8);
     }
     if (out_var_flag) {
       *out_var_flag = (uint8_t *)std::malloc(std::max<size_t>(si.var_flag.size(), 1));
-      std::memcpy(*out_var_flag, si.var_flag.data(), si.var_flag.size());
+      if (!si.var_flag.empty()) std::memcpy(*out_var_flag, si.var_flag.data(), si.var_flag.size());
     }
     if (out_tpl) {
       *out_tpl = (iem_shard_template_t *)std::malloc(sizeof(iem_shard_template_t) * std::max<size_t>(si.tpl.size(), 1));
@@ -1050,7 +1050,7 @@ int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int wor
     if (out_items) {
       const std::vector<int64_t> all = shard_items(si);
       *out_items = (int64_t *)std::malloc(sizeof(int64_t) * std::max<size_t>(all.size(), 1));
-      std::memcpy(*out_items, all.data(), all.size() * 8);
+      if (!all.empty()) std::memcpy(*out_items, all.data(), all.size() * 8);
     }
     return IEM_OK;
   } catch (const std::exception &e) {
@@ -1087,7 +1087,7 @@ int iem_shard_template_items(const iem_model *m, int64_t *h_items, int64_t *out_
   if (!m->sharded) return fail(IEM_E_ARG, "not a sharded handle (iem_create_sharded)");
   const std::vector<int64_t> all = shard_items(m->shard);
   *out_n = (int64_t)all.size();
-  if (h_items) std::memcpy(h_items, all.data(), all.size() * 8);
+  if (h_items && !all.empty()) std::memcpy(h_items, all.data(), all.size() * 8);
   return IEM_OK;
 }
 

@@ -80,14 +80,22 @@ struct Affine {   // value(k) = c + sum_d k[d] * kd  over the template's item bo
 };
 
 inline Affine idx_affine(const Template &t, const IdxExpr &ix) {
+  // blobs come from foreign producers: 128-bit arithmetic, and anything that does not fit an index is refused
   Affine a;
-  a.c = ix.c0;
+  __int128 c = ix.c0, k[3] = {0, 0, 0};
   for (int j = 0; j < ix.nterms; ++j) {
     const FieldDesc &f = t.ifields[ix.field[j]];
     if (f.mode != IEM_F_AFFINE) { a.ok = false; continue; }
-    a.c += (__int128)ix.coef[j] * f.base;
-    for (int d = 0; d < 3; ++d) a.k[d] += ix.coef[j] * f.step[d];
+    c += (__int128)ix.coef[j] * f.base;
+    for (int d = 0; d < 3; ++d) k[d] += (__int128)ix.coef[j] * f.step[d];
   }
+  const __int128 lim = (__int128)1 << 50;
+  if (c > lim || c < -lim) throw std::runtime_error("index expression out of range");
+  for (int d = 0; d < 3; ++d) {
+    if (k[d] > lim || k[d] < -lim) throw std::runtime_error("index stride out of range");
+    a.k[d] = (int64_t)k[d];
+  }
+  a.c = c;
   return a;
 }
 
@@ -306,9 +314,10 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
         if (!is_var[i]) continue;
         lidx[i].assign((size_t)n, 0);
         for (int64_t k = 0; k < n; ++k) {
-          int64_t v = t.idx[i].c0;
-          for (int j = 0; j < t.idx[i].nterms; ++j) v += t.idx[i].coef[j] * ifield_at(t.ifields[t.idx[i].field[j]], k);
-          if (v < 1 || v > info.nvar_global) throw std::runtime_error(where + ": variable index out of range");
+          __int128 v128 = t.idx[i].c0;
+          for (int j = 0; j < t.idx[i].nterms; ++j) v128 += (__int128)t.idx[i].coef[j] * ifield_at(t.ifields[t.idx[i].field[j]], k);
+          if (v128 < 1 || v128 > (__int128)info.nvar_global) throw std::runtime_error(where + ": variable index out of range");
+          const int64_t v = (int64_t)v128;
           const int si = find_slab(m.slabs, v - 1);
           const Slab &g = m.slabs[si], &l = ls[si];
           int64_t rem = v - 1 - g.off, c3[3];
