@@ -130,3 +130,32 @@ def test_backend_plug_point_with_a_shard(built):
         _close(gm.grad(xd).cpu().numpy(), so.grad(x), "grad")
         _close(gm.jac_coord(xd).cpu().numpy(), so.jac_coord(x), "jac")
     be.empty()
+
+
+@pytest.mark.parametrize("rank,world", [(0, 3), (1, 3), (2, 3)])
+def test_sharded_handle_with_an_explicit_item_list(rank, world, built):
+    """iem_create_sharded on a model with a domain-restricted constraint (explicit item list, index columns):
+    the rank's filtered list evaluates on the GPU like the oracle on the device-free cut of the same shard."""
+    import torch
+    from infiniteexamodels.jl_amd import lib as iemlib, transcribe
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    from test_shard_cabi import _restricted
+    gblob = transcribe.exa_core(_restricted(n=3000)).to_blob()
+    gm = ExaModel.sharded(gblob, 1, rank, world, device=0)
+    lblob, info, vmap, vflag, tpl = iemlib.shard_blob(gblob, 1, rank, world)
+    om = OracleModel(lblob)
+    assert any(t["items_offset"] >= 0 for t in gm.shard_templates())
+    assert [t["ordinals"].tolist() for t in gm.shard_templates()] == [t["ordinals"].tolist() for t in tpl]
+    x = np.abs(om.x0 + 0.1 * np.random.default_rng(3).standard_normal(om.nvar)) + 0.05
+    y = np.random.default_rng(4).standard_normal(om.ncon)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    r, c = gm.jac_structure_device(1)
+    ro, co = om.jac_structure(1)
+    assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
+    _close(gm.cons(xd).cpu().numpy(), om.cons(x), "cons")
+    _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac")
+    _close(gm.hess_coord(xd, yd, obj_weight=0.6).cpu().numpy(), om.hess_coord(x, y, 0.6), "hess")
+    _close(gm.grad(xd).cpu().numpy(), om.grad(x), "grad")
+    assert abs(gm.obj(xd) - om.obj(x)) <= RTOL * max(1.0, abs(om.obj(x)))
+    gm.close()
