@@ -242,6 +242,42 @@ def replicated_indices(core: ExaCore) -> np.ndarray:
     return np.concatenate(out).astype(np.int64) if out else np.zeros(0, dtype=np.int64)
 
 
+class ShardLayout:
+    """Local → global maps of a shard as the C-ABI reports them (``iem_shard_var_map``,
+    ``iem_shard_template_info`` / ``_items``): ``var_map``, the ``owned / replicated / halo`` masks,
+    ``row_map`` (constraint rows) and the global COO positions ``jac_pos`` / ``hess_pos`` of every local
+    Jacobian / Hessian entry.  Built from a sharded :class:`ExaModel` or from the tuple ``lib.shard_blob`` returns."""
+
+    def __init__(self, var_map, var_flag, templates, ncon: int, nnzj: int, nnzh: int):
+        self.var_map = np.asarray(var_map)
+        f = np.asarray(var_flag)
+        self.owned, self.replicated, self.halo = (f & 1) != 0, (f & 2) != 0, (f & 4) != 0
+        self.row_map = np.full(ncon, -1, dtype=np.int64)
+        self.jac_pos = np.full(nnzj, -1, dtype=np.int64)
+        self.hess_pos = np.full(nnzh, -1, dtype=np.int64)
+        for t in templates:
+            k = t["ordinals"]
+            if t["kind"] == T_CON:
+                self.row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
+                if t["o1step"]:
+                    self.jac_pos[t["o1"]:t["o1"] + k.size * t["o1step"]] = \
+                        (t["global_o1"] + t["o1step"] * k[:, None] + np.arange(t["o1step"])[None, :]).reshape(-1)
+            if t["o2step"]:
+                self.hess_pos[t["o2"]:t["o2"] + k.size * t["o2step"]] = \
+                    (t["global_o2"] + t["o2step"] * k[:, None] + np.arange(t["o2step"])[None, :]).reshape(-1)
+        assert (self.row_map >= 0).all() and (self.jac_pos >= 0).all() and (self.hess_pos >= 0).all()
+
+    @classmethod
+    def of_model(cls, gm) -> "ShardLayout":
+        vm, vf = gm.shard_var_map()
+        return cls(vm, vf, gm.shard_templates(), gm.meta.ncon, gm.meta.nnzj, gm.meta.nnzh)
+
+    @classmethod
+    def of_cut(cls, cut) -> "ShardLayout":
+        _, info, vm, vf, tpl = cut
+        return cls(vm, vf, tpl, info["ncon"], info["nnzj"], info["nnzh"])
+
+
 def connect_mailboxes(gm, dist=None) -> None:
     """Wire the ranks' mailboxes (``iem_comm_export`` → all-gather of the 128-byte handles over the
     host process group, like an ncclUniqueId → ``iem_comm_connect``); afterwards

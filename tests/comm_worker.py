@@ -28,13 +28,6 @@ def build_global(name, size):
     return transcribe.exa_core(workloads.pandemic(size[0], size[1]))
 
 
-def ordinals(t):
-    k0, k1, k2 = (np.arange(n) for n in t["dims"])
-    g0, g1, _ = t["global_dims"]
-    o = (t["klo"][0] + k0)[None, None, :] + g0 * ((t["klo"][1] + k1)[None, :, None] + g1 * (t["klo"][2] + k2)[:, None, None])
-    return o.reshape(-1)
-
-
 def main():
     name, group = sys.argv[1], int(sys.argv[2])
     size = tuple(int(v) for v in sys.argv[3].split("x"))
@@ -49,20 +42,9 @@ def main():
     info = gm.shard_info()
     assert (info["rank"], info["world"]) == (rank, world)
     shard.connect_mailboxes(gm, dist)
-    vm, vf = gm.shard_var_map()
-    halo, repl, owned = (vf & 4) != 0, (vf & 2) != 0, (vf & 1) != 0
-    tpl = gm.shard_templates()
-    row_map = np.full(gm.meta.ncon, -1)
-    jpos = np.full(gm.meta.nnzj, -1)
-    hpos = np.full(gm.meta.nnzh, -1)
-    for t in tpl:
-        k = t["ordinals"]
-        if t["kind"] == 1:
-            row_map[t["o0"] + np.arange(k.size)] = t["global_o0"] + k
-            if t["o1step"]:
-                jpos[t["o1"]:t["o1"] + k.size * t["o1step"]] = (t["global_o1"] + t["o1step"] * k[:, None] + np.arange(t["o1step"])[None, :]).reshape(-1)
-        if t["o2step"]:
-            hpos[t["o2"]:t["o2"] + k.size * t["o2step"]] = (t["global_o2"] + t["o2step"] * k[:, None] + np.arange(t["o2step"])[None, :]).reshape(-1)
+    lay = shard.ShardLayout.of_model(gm)
+    vm, halo, repl, owned = lay.var_map, lay.halo, lay.replicated, lay.owned
+    row_map, jpos, hpos = lay.row_map, lay.jac_pos, lay.hess_pos
     if rank == 0:
         from pyoracle import OracleModel
         G = ExaModel(gcore, device=0, blob=gblob, options=opts)      # the unsharded model on the same GPU

@@ -150,6 +150,9 @@ def test_world_one_is_the_identity(name, size, group, built):
     for a, b in ((L.jac_structure(), G.jac_structure()), (L.hess_structure(), G.hess_structure())):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert [t["global_index"] for t in tpl] == list(range(G.n_templates))
+    lay = shard.ShardLayout.of_cut((lblob, info, vmap, vflag, tpl))
+    assert np.array_equal(lay.row_map, np.arange(G.ncon)) and np.array_equal(lay.jac_pos, np.arange(G.nnzj))
+    assert np.array_equal(lay.hess_pos, np.arange(G.nnzh)) and lay.owned.all() and not lay.halo.any()
 
 
 def test_time_sharded_pandemic_keeps_its_stencil_local(built):
