@@ -816,6 +816,27 @@ class KernelBuilder {
         else o.grad_mode[parts[c].second] = -1;   // folded into the host slot
       }
     }
+    // several single-item templates adding into one entry (the terms of a first-stage cost): one sum, one slot
+    {
+      std::map<int, std::vector<std::pair<int, int>>> sc;
+      for (size_t oi = 0; oi < outs_.size(); ++oi) {
+        if (!outs_[oi].scalar) continue;
+        for (size_t s = 0; s < outs_[oi].grad_idx.size(); ++s)
+          if (idx_[outs_[oi].grad_idx[s]].ind.empty() && outs_[oi].grad_mode[s] >= 0) sc[outs_[oi].grad_idx[s]].emplace_back((int)oi, (int)s);
+      }
+      for (auto &kv : sc) {
+        auto &parts = kv.second;
+        if (parts.size() < 2) continue;
+        int acc = -1;
+        for (auto &p : parts) {
+          int v = outs_[p.first].vals[p.second];
+          if (outs_[p.first].guard != outs_[parts[0].first].guard) v = mk(VGUARD, outs_[p.first].guard, v, -1, -1, 0);
+          acc = acc < 0 ? v : add(acc, v);
+        }
+        outs_[parts[0].first].vals[parts[0].second] = acc;
+        for (size_t c = 1; c < parts.size(); ++c) outs_[parts[c].first].grad_mode[parts[c].second] = -1;
+      }
+    }
     // single-item templates (point constraints x_k(0) == 0) run on the lane of grid point 0: fold their
     // contribution into the slot of that lane that hits the same entry
     for (size_t oi = 0; oi < outs_.size(); ++oi) {
@@ -1821,36 +1842,8 @@ Program generate(const Model &m, const Options &opt_in) {
     builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;
     if (!(mode == 0 && a.hi - a.lo + 1 == a.count)) accumulates[a.kind] = true;
   }
-  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
-    if (dest_slots[kind].empty()) continue;
-    KernelBuilder::SharedInfo si;
-    si.on = true;
-    std::map<int, int> vid;   // gslot -> value id
-    std::vector<int> kernel_of;
-    for (size_t i = 0; i < gslots.size(); ++i)
-      if (gslots[i].kind == kind && shared_dest[i]) { vid[(int)i] = (int)kernel_of.size(); kernel_of.push_back(gslots[i].kernel); }
-    si.nv_total = (int64_t)kernel_of.size();
-    std::map<int, int64_t> off_of;   // kernel -> first workgroup of the call
-    for (size_t k = 0; k < descs.size(); ++k)
-      if (descs[k].kind == kind) { off_of[(int)k] = si.n_wg; si.n_wg += descs[k].n_blocks; }
-    for (int k : kernel_of) si.owner.emplace_back(off_of[k], descs[k].n_blocks);
-    for (auto &kv : dest_slots[kind]) {
-      std::vector<int> ids;
-      for (int i : kv.second) ids.push_back(vid[i]);
-      si.dests.emplace_back(kv.first, ids);
-      P.covered[kind].emplace_back(kv.first, kv.first);   // written (not accumulated) by the last workgroup
-    }
-    for (auto &ko : off_of) {
-      KernelBuilder::SharedInfo mine = si;
-      mine.red_off = ko.second;
-      for (size_t i = 0; i < gslots.size(); ++i)
-        if (gslots[i].kind == kind && shared_dest[i] && gslots[i].kernel == ko.first)
-          mine.mine.emplace_back(gslots[i].out, gslots[i].slot, vid[(int)i]);
-      builders[ko.first]->set_shared(mine);
-    }
-    P.red_values[kind] = si.nv_total;
-    P.red_wgs[kind] = si.n_wg;
-  }
+  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD})
+    for (auto &kv : dest_slots[kind]) P.covered[kind].emplace_back(kv.first, kv.first);   // written (not accumulated) by the last workgroup
   // Entries of the scatter outputs (g, Jᵀv, Hv) that no template overwrites completely must be
   // zero before the kernels run.  When NOTHING of a kind accumulates (every slot stores
   // exclusively and tiles its range), the complement is disjoint from every store and the largest
@@ -1871,11 +1864,47 @@ Program generate(const Model &m, const Options &opt_in) {
     int64_t hole_len = 0;
     for (auto &h : holes) hole_len += h.second - h.first;
     // per-workgroup share bounded (64 rounds of the block) so a small kernel never serialises a big memset
-    if (opt.fuse_zero && !accumulates[kind] && best >= 0 && !holes.empty() && holes.size() <= 16 &&
-        hole_len <= descs[best].n_blocks * 64 * (int64_t)opt.block)
+    const bool fusable = opt.fuse_zero && !accumulates[kind] && best >= 0 && !holes.empty() && holes.size() <= 16;
+    if (fusable && hole_len <= descs[best].n_blocks * 64 * (int64_t)opt.block)
       builders[best]->set_zero_fill(holes);
-    else
+    else if (fusable && descs[best].grid[1] == 1 && descs[best].grid[2] == 1 && (hole_len + 16 * (int64_t)opt.block - 1) / (16 * (int64_t)opt.block) <= 4096) {
+      // a kernel far smaller than what it must zero (an objective over a handful of variables: the OPF's
+      // first-stage cost, pandemic's ∫u dt): launch EXTRA workgroups — past the grid, every lane's guard is
+      // false, they only take their share of the zero fill — instead of a memset launch of its own
+      const int64_t need = (hole_len + 16 * (int64_t)opt.block - 1) / (16 * (int64_t)opt.block);
+      if (need > descs[best].grid[0]) { descs[best].grid[0] = need; descs[best].n_blocks = need; }
+      builders[best]->set_zero_fill(holes);
+    } else
       P.zero_ranges[kind] = holes;
+  }
+  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
+    if (dest_slots[kind].empty()) continue;
+    KernelBuilder::SharedInfo si;
+    si.on = true;
+    std::map<int, int> vid;   // gslot -> value id
+    std::vector<int> kernel_of;
+    for (size_t i = 0; i < gslots.size(); ++i)
+      if (gslots[i].kind == kind && shared_dest[i]) { vid[(int)i] = (int)kernel_of.size(); kernel_of.push_back(gslots[i].kernel); }
+    si.nv_total = (int64_t)kernel_of.size();
+    std::map<int, int64_t> off_of;   // kernel -> first workgroup of the call
+    for (size_t k = 0; k < descs.size(); ++k)
+      if (descs[k].kind == kind) { off_of[(int)k] = si.n_wg; si.n_wg += descs[k].n_blocks; }
+    for (int k : kernel_of) si.owner.emplace_back(off_of[k], descs[k].n_blocks);
+    for (auto &kv : dest_slots[kind]) {
+      std::vector<int> ids;
+      for (int i : kv.second) ids.push_back(vid[i]);
+      si.dests.emplace_back(kv.first, ids);
+    }
+    for (auto &ko : off_of) {
+      KernelBuilder::SharedInfo mine = si;
+      mine.red_off = ko.second;
+      for (size_t i = 0; i < gslots.size(); ++i)
+        if (gslots[i].kind == kind && shared_dest[i] && gslots[i].kernel == ko.first)
+          mine.mine.emplace_back(gslots[i].out, gslots[i].slot, vid[(int)i]);
+      builders[ko.first]->set_shared(mine);
+    }
+    P.red_values[kind] = si.nv_total;
+    P.red_wgs[kind] = si.n_wg;
   }
   // One launch per NLPModels call: when the templates of a call live on several support grids
   // (pandemic: t x xi and t; collocation: the node grids), the per-grid bodies become
