@@ -21,10 +21,14 @@
 //     a template that does not is kept by the rank that owns the supports of its point variables
 //     (x(0) == 0 -> the rank holding t = 0), else by rank 0.
 //   * variable index expressions are re-based into the local numbering (they become affine
-//     fields of the local item box).
+//     fields of the local item box);
+//   * templates that walk the sharded axis without iterating over its support grid (orthogonal
+//     collocation: node x element boxes with indices like 2e + j, constant-over-collocation pairs) are
+//     cut along the dimension with the largest stride, whole elements at a time; an item belongs to
+//     the rank owning the LAST support it references, the halo covers the first.
 // Supported: templates on support grids (grid hint present) with affine integer fields, stencils
-// that reach to the LEFT only (backward differences) — what the reference's default derivative
-// method emits; and explicit item lists (a domain restriction filters the iterator,
+// that reach to the LEFT only (backward differences, orthogonal collocation) — what the reference's
+// derivative methods emit; and explicit item lists (a domain restriction filters the iterator,
 // transform.jl:448-451) whose variable indices all sit at the item's own support: the list is
 // filtered to the owned supports and every column re-gathered.  Anything else throws with a message
 // (IEM_E_BLOB at the ABI).
@@ -202,6 +206,8 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
   // pass 1: which item dimension of each template runs over the group; stencil reach
   const size_t nt = m.tpl.size();
   std::vector<int> sdim(nt, -1);
+  std::vector<int> gdim(nt, -1);            // un-hinted templates that walk the sharded axis: the item dimension to cut,
+  std::vector<int64_t> gm(nt, 0), ganchor(nt, 0);   // its stride in supports, and the last referenced support at item 0
   std::vector<char> explicit_tpl(nt, 0);
   std::vector<std::vector<Walk>> walks(nt);
   int64_t reach = 0;
@@ -220,24 +226,57 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
       explicit_tpl[ti] = 1;
       continue;
     }
+    const bool hinted = sdim[ti] >= 0;   // iterates over the sharded group's own support grid
+    int64_t a_max = INT64_MIN, c_min = INT64_MAX;
     for (size_t i = 0; i < t.idx.size(); ++i) {
       if (!is_var[i]) continue;
       walks[ti][i] = walk_of(m, t, ti, t.idx[i]);
       const Walk &w = walks[ti][i];
       const int ax = sax[w.slab];
       if (ax < 0) continue;
+      if (hinted) {
+        for (int d = 0; d < t.nd; ++d) {
+          if (w.m[d][ax] == 0) continue;
+          if (sdim[ti] != d) throw std::runtime_error("template " + std::to_string(ti) + ": two item dimensions run over the sharded group");
+          if (w.m[d][ax] != 1) throw std::runtime_error("template " + std::to_string(ti) + ": strided access along the sharded group's own grid is not supported");
+        }
+        if (w.m[sdim[ti]][ax] == 1) {
+          const int64_t shift = w.i0[ax] - t.origin[sdim[ti]];   // slab coordinate minus the item's own support
+          if (shift > 0) throw std::runtime_error("template " + std::to_string(ti) + ": stencils that reach to the right of their support are not supported (backward differences only)");
+          reach = std::max(reach, -shift);
+        }
+        continue;
+      }
+      // No support-grid hint, but the template walks the sharded axis (collocation rows over node x element
+      // boxes, transform.jl:535-557: indices like 2e + j): the item dimension with the LARGEST stride
+      // (the element) is the one to cut, whole elements at a time; an item belongs to the rank that
+      // owns the LAST support it references (for a backward difference that is the row's own support),
+      // and the stencil's reach is how far the first referenced support lies before it.
+      int dstar = -1;
       for (int d = 0; d < t.nd; ++d) {
-        if (w.m[d][ax] == 0) continue;
-        if (sdim[ti] >= 0 && sdim[ti] != d) throw std::runtime_error("template " + std::to_string(ti) + ": two item dimensions run over the sharded group");
-        if (t.grid_id <= 0 || t.lattice_recovered) throw std::runtime_error("template " + std::to_string(ti) + ": sharding needs a support-grid hint on templates over the sharded group");
-        sdim[ti] = d;
-        if (w.m[d][ax] != 1) throw std::runtime_error("template " + std::to_string(ti) + ": strided access along the sharded group is not supported");
+        if (w.m[d][ax] < 0) throw std::runtime_error("template " + std::to_string(ti) + ": an index runs backwards along the sharded group");
+        if (w.m[d][ax] > 0 && (dstar < 0 || w.m[d][ax] > w.m[dstar][ax])) dstar = d;
       }
-      if (sdim[ti] >= 0 && w.m[sdim[ti]][ax] == 1) {
-        const int64_t shift = w.i0[ax] - t.origin[sdim[ti]];   // slab coordinate minus the item's own support
-        if (shift > 0) throw std::runtime_error("template " + std::to_string(ti) + ": stencils that reach to the right of their support are not supported (backward differences only)");
-        reach = std::max(reach, -shift);
+      if (dstar < 0) continue;   // a fixed support (point variable): decided in pass 2
+      if (gdim[ti] >= 0 && (gdim[ti] != dstar || gm[ti] != w.m[dstar][ax]))
+        throw std::runtime_error("template " + std::to_string(ti) + ": index expressions walk the sharded group with different strides");
+      gdim[ti] = dstar; gm[ti] = w.m[dstar][ax];
+      int64_t hi = w.i0[ax];
+      for (int d = 0; d < t.nd; ++d) if (d != dstar) hi += w.m[d][ax] * (t.dims[d] - 1);
+      a_max = std::max(a_max, hi);
+      c_min = std::min(c_min, w.i0[ax]);
+    }
+    if (gdim[ti] >= 0) {
+      // every referenced support that does NOT move with the cut dimension must move with it too (all walks
+      // into sharded slabs share the stride): a walk that stays put would leave the window
+      for (size_t i = 0; i < t.idx.size(); ++i) {
+        if (!is_var[i]) continue;
+        const Walk &w = walks[ti][i];
+        if (sax[w.slab] >= 0 && w.m[gdim[ti]][sax[w.slab]] != gm[ti])
+          throw std::runtime_error("template " + std::to_string(ti) + ": mixes moving and fixed supports of the sharded group");
       }
+      ganchor[ti] = a_max;
+      reach = std::max(reach, a_max - c_min);
     }
   }
   info.halo_reach = reach;
@@ -400,10 +439,17 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
       info.tpl.push_back(st);
       continue;
     }
-    if (sdim[ti] >= 0) {
-      const int d = sdim[ti];
-      const int64_t lo = std::min(std::max<int64_t>(a0 - t.origin[d], 0), t.dims[d]);
-      const int64_t hi = std::min(std::max<int64_t>(b0 - t.origin[d], 0), t.dims[d]);
+    if (sdim[ti] >= 0 || gdim[ti] >= 0) {
+      const int d = sdim[ti] >= 0 ? sdim[ti] : gdim[ti];
+      int64_t lo, hi;
+      if (sdim[ti] >= 0) {
+        lo = std::min(std::max<int64_t>(a0 - t.origin[d], 0), t.dims[d]);
+        hi = std::min(std::max<int64_t>(b0 - t.origin[d], 0), t.dims[d]);
+      } else {   // items whose last referenced support  ganchor + gm*k  this rank owns
+        auto ceil_div = [](int64_t p, int64_t q) { return p >= 0 ? (p + q - 1) / q : -((-p) / q); };
+        lo = std::min(std::max<int64_t>(ceil_div(a0 - ganchor[ti], gm[ti]), 0), t.dims[d]);
+        hi = std::min(std::max<int64_t>(ceil_div(b0 - ganchor[ti], gm[ti]), 0), t.dims[d]);
+      }
       klo[d] = lo;
       // per-item bound arrays follow the cut
       auto cut_bound = [&](int mode, int &arr) {
@@ -430,7 +476,7 @@ inline void shard_model(Model &m, int group, int rank, int world, ShardInfo &inf
       for (FieldDesc &f : t.ifields) f.base += f.step[d] * lo;
       for (FieldDesc &f : t.ffields) f.base += f.step[d] * lo;
       t.dims[d] = std::max<int64_t>(hi - lo, 0);
-      t.origin[d] = t.origin[d] + lo - wlo;   // grid coordinate inside the local window
+      if (sdim[ti] >= 0) t.origin[d] = t.origin[d] + lo - wlo;   // grid coordinate inside the local window
       t.n_items = t.dims[0] * t.dims[1] * t.dims[2];
     } else {
       // not over the sharded group: the rank that owns the supports of its point variables, else rank 0

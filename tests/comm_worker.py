@@ -21,6 +21,8 @@ from infiniteexamodels.jl_amd.model import ExaModel
 def build_global(name, size):
     if name == "quadrotor":
         return transcribe.exa_core(workloads.quadrotor(size[0]))
+    if name == "quadrotor_oc3":      # ESCAPE34 variant: OrthogonalCollocation(3), halo of TWO supports
+        return transcribe.exa_core(workloads.quadrotor(size[0], collocation=3))
     if name == "farmer":
         return transcribe.exa_core(workloads.farmer(size[0]))
     if name == "opf":
@@ -71,7 +73,7 @@ def main():
     for it in range(5):
         rng = np.random.default_rng(100 + it)
         xg = np.concatenate([np.zeros(0), 0.3 + 0.1 * rng.standard_normal(nvg)])
-        if name not in ("quadrotor", "opf"):
+        if name not in ("quadrotor", "quadrotor_oc3", "opf"):
             xg = np.abs(xg) + 0.05
         yg = np.random.default_rng(200 + it).standard_normal(ncg)
         xl = xg[vm].copy()

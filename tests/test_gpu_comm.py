@@ -25,7 +25,7 @@ def _free_port():
 
 @pytest.mark.parametrize("name,group,size,world,mode", [
     ("quadrotor", 1, "4000", 2, "eager"), ("quadrotor", 1, "4001", 4, "graph"), ("farmer", 1, "3000", 3, "eager"),
-    ("opf", 1, "500", 2, "graph"), ("pandemic", 2, "40x12", 4, "eager")])
+    ("opf", 1, "500", 2, "graph"), ("pandemic", 2, "40x12", 4, "eager"), ("quadrotor_oc3", 1, "2000", 3, "eager")])
 def test_distributed_x_halo_and_allreduce(name, group, size, world, mode, built):
     port = _free_port()
     procs = []
