@@ -92,8 +92,10 @@ int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_optio
  * contiguous block of the supports of parameter group `group` (the 1-based group id the blob's grid
  * hints and slab table use: 1 = the first infinite parameter).  iem_create_sharded takes the GLOBAL
  * blob — exactly what iem_create takes — and cuts the rank's window in C++ (csrc/iem_shard.hpp): local
- * x = window slices of the sharded slabs (with the stencil's halo in front) + replicated slabs;
- * cons!/jac_coord!/hess_coord! then need no communication at all.  Two exchanges remain:
+ * x = window slices of the sharded slabs (with the stencil's halo in front: 1 support for backward
+ * differences, the element's first support for orthogonal collocation) + replicated slabs; templates over
+ * the group are cut to the owned supports (whole elements for collocation boxes, filtered lists for domain
+ * restrictions); cons!/jac_coord!/hess_coord! then need no communication at all.  Two exchanges remain:
  *   iem_halo_exchange        before cons!/jac!/hess!: the stencil neighbours  x_k[a_r - 1]
  *                            (transform.jl:535-557) from the left rank into the halo entries of x
  *   iem_allreduce_obj_grad   after obj / grad!: the scalar objective and the gradient entries of
