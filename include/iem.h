@@ -234,13 +234,23 @@ void iem_free(void *p);
  *   "obj_wgs"      at most this many workgroups walk the objective's tiles (default 1024; fixed, so the
  *                  summation order is — obj is bitwise reproducible)
  *   "det_shared"   1 (default): gradient / J'v / Hv entries shared by many items are reduced in a fixed
- *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs) */
+ *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs)
+ *   "autotune"     1 (default): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups
+ *                  keep a second code object with a 48-slot LDS store batch and choose per output buffer,
+ *                  from the first twenty calls into it (HIP events, every call a valid evaluation), which of
+ *                  the two writes that buffer faster (the buffer's physical placement decides,
+ *                  by up to 10 %).  Both variants write identical bytes.  0: default code object only. */
 int iem_set_option(const char *name, int64_t value);
 
 /* per-kernel timing of the last jac/hess call pair, measured with HIP events on the
  * handle's stream (used by bench.py for the roofline line) */
 int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess,
                      int iters, double *h_ms_jac, double *h_ms_hess);
+
+/* Store-batch tuner (options "autotune", "autotune_min_blocks"): which variant jac_coord! (kind 0) /
+ * hess_coord! (kind 1) uses for output buffer d_vals — -1 still measuring (or tuner off / buffer not seen),
+ * 0 the default code object, 1 the large-batch one.  Introspection only; results never depend on it. */
+int iem_tuner_choice(iem_model *m, int kind, const double *d_vals, int *out_choice);
 
 const char *iem_last_error(void);
 const char *iem_version(void);

@@ -126,6 +126,30 @@ struct iem_model {
   hipFunction_t fn_struct = nullptr, fn_csr = nullptr;
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *d_red[iem::KK_COUNT] = {};   // per scatter kind: parked shared-entry values + tickets (iem_shared_*)
+  // Second code object of jac_coord!/hess_coord! with a larger LDS staging batch (lds_slots = 48: one 96-KB
+  // workgroup per CU, a third of the concurrently open store streams) and the tuner that picks, per kind and
+  // per OUTPUT BUFFER, whichever of the two is faster there — how a COO buffer's physical pages fall onto the HBM
+  // channels decides that, and both variants write identical bytes, so the first twenty calls into a
+  // buffer alternate between them under HIP events and every call is a valid evaluation.
+#define IEM_TUNE_CALLS 20   // measured calls per output buffer: ten per variant, alternating
+  struct Alt {
+    bool on = false;
+    iem::Program prog;
+    hipModule_t mod = nullptr;
+    std::vector<hipFunction_t> fns;
+    std::vector<std::vector<uint64_t>> argbuf;
+    std::vector<void *> d_tables;
+  } alt;
+  struct Tune {
+    const void *out = nullptr;   // the buffer the decision belongs to
+    int calls = 0, choice = -1;  // choice: -1 undecided, 0 default, 1 alt
+    hipEvent_t ev[IEM_TUNE_CALLS][2] = {};
+    bool have_events = false;
+  };
+  struct TuneSet {               // decisions for the last four output buffers of a kind (a solver alternates between few)
+    Tune slot[4];
+    int next = 0;
+  } tune[2];   // [0] jac_coord!, [1] hess_coord!
   // multi-GPU (iem_create_sharded): what was cut, and the mailbox the peers push into
   bool sharded = false;
   iem::ShardInfo shard;
@@ -225,8 +249,9 @@ int jit_compile(iem_model *m, const std::string &src, const std::string &dir, co
   return IEM_OK;
 }
 
-int compile_or_load(iem_model *m) {
-  const std::string src = full_source(m->prog, m->opt);
+// code object of `prog` (cache -> hiprtc on a miss) and its kernel functions
+int load_program(iem_model *m, const iem::Program &prog, const iem::Options &opt, hipModule_t *mod, std::vector<hipFunction_t> *fns) {
+  const std::string src = full_source(prog, opt);
   const uint64_t key = iem::fnv1a64(src);
   const std::string dir = cache_dir();
   const std::string path = dir + "/iem_" + key_hex(key) + ".hsaco";
@@ -234,17 +259,23 @@ int compile_or_load(iem_model *m) {
   bool loaded = false;
   if (read_file(path, code)) {
     // a cached object that does not load (truncated file, built for another architecture) is rebuilt
-    loaded = hipModuleLoadData(&m->mod, code.data()) == hipSuccess;
-    if (!loaded) { m->mod = nullptr; (void)hipGetLastError(); }
+    loaded = hipModuleLoadData(mod, code.data()) == hipSuccess;
+    if (!loaded) { *mod = nullptr; (void)hipGetLastError(); }
   }
   if (!loaded) {
     int rc = jit_compile(m, src, dir, path, code);
     if (rc) return rc;
-    HIP_TRY(hipModuleLoadData(&m->mod, code.data()));
+    HIP_TRY(hipModuleLoadData(mod, code.data()));
   }
-  m->fns.resize(m->prog.kernels.size());
-  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
-    HIP_TRY(hipModuleGetFunction(&m->fns[k], m->mod, m->prog.kernels[k].name.c_str()));
+  fns->resize(prog.kernels.size());
+  for (size_t k = 0; k < prog.kernels.size(); ++k)
+    HIP_TRY(hipModuleGetFunction(&(*fns)[k], *mod, prog.kernels[k].name.c_str()));
+  return IEM_OK;
+}
+
+int compile_or_load(iem_model *m) {
+  int rc = load_program(m, m->prog, m->opt, &m->mod, &m->fns);
+  if (rc) return rc;
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
   HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
@@ -252,15 +283,13 @@ int compile_or_load(iem_model *m) {
   return IEM_OK;
 }
 
-// Builds the static part of kernel k's argument block once (iem_create); launch() only rewrites
+// Builds the static part of a kernel's argument block once (iem_create); launching only rewrites
 // the head {x, theta, y, v, out, w, aux}.
-void build_argbuf(iem_model *m, size_t k) {
-  const iem::KernelDesc &kd = m->prog.kernels[k];
-  std::vector<uint64_t> &buf = m->argbuf[k];
+void build_argbuf(iem_model *m, const iem::KernelDesc &kd, const void *d_table, std::vector<uint64_t> &buf) {
   buf.assign(7, 0);
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
   if (kd.tables_in_memory) {
-    const uint64_t *tb = (const uint64_t *)m->d_tables[k];
+    const uint64_t *tb = (const uint64_t *)d_table;
     size_t nip = std::max<size_t>(1, kd.ip.size()), ndp = std::max<size_t>(1, kd.dp.size()), nfa = std::max<size_t>(1, kd.fa.size());
     push_ptr(tb); push_ptr(tb + nip); push_ptr(tb + nip + ndp); push_ptr(tb + nip + ndp + nfa);
   } else {
@@ -275,19 +304,50 @@ void build_argbuf(iem_model *m, size_t k) {
   }
 }
 
-int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
-  const iem::KernelDesc &kd = m->prog.kernels[k];
+// uploads what the program's kernels read and builds their argument blocks
+int prepare_program(iem_model *m, const iem::Program &prog, std::vector<void *> &d_tables, std::vector<std::vector<uint64_t>> &argbuf) {
+  int rc;
+  for (const iem::KernelDesc &kd : prog.kernels) {
+    for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return rc;
+    for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return rc;
+  }
+  d_tables.assign(prog.kernels.size(), nullptr);
+  for (size_t k = 0; k < prog.kernels.size(); ++k) {
+    const iem::KernelDesc &kd = prog.kernels[k];
+    if (!kd.tables_in_memory) continue;
+    std::vector<uint64_t> tb;
+    for (int64_t v : kd.ip) tb.push_back((uint64_t)v);
+    if (kd.ip.empty()) tb.push_back(0);
+    for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); tb.push_back(b); }
+    if (kd.dp.empty()) tb.push_back(0);
+    for (int id : kd.fa) tb.push_back((uint64_t)(uintptr_t)m->d_arrays[id]);
+    if (kd.fa.empty()) tb.push_back(0);
+    for (int id : kd.ia) tb.push_back((uint64_t)(uintptr_t)m->d_arrays[id]);
+    if (kd.ia.empty()) tb.push_back(0);
+    HIP_TRY(hipMalloc(&d_tables[k], tb.size() * 8));
+    HIP_TRY(hipMemcpy(d_tables[k], tb.data(), tb.size() * 8, hipMemcpyHostToDevice));
+  }
+  argbuf.resize(prog.kernels.size());
+  for (size_t k = 0; k < prog.kernels.size(); ++k) build_argbuf(m, prog.kernels[k], d_tables[k], argbuf[k]);
+  return IEM_OK;
+}
+
+int launch_one(iem_model *m, const iem::KernelDesc &kd, hipFunction_t fn, std::vector<uint64_t> &buf, const double *x, const double *y,
+               double *out, double w, const double *v, double *aux) {
   if (kd.n_blocks <= 0) return IEM_OK;   // a support grid none of whose templates has an item
-  std::vector<uint64_t> &buf = m->argbuf[k];
   buf[0] = (uint64_t)(uintptr_t)x; buf[1] = (uint64_t)(uintptr_t)m->d_theta; buf[2] = (uint64_t)(uintptr_t)y;
   buf[3] = (uint64_t)(uintptr_t)v; buf[4] = (uint64_t)(uintptr_t)out;
   std::memcpy(&buf[5], &w, 8);
   buf[6] = (uint64_t)(uintptr_t)aux;
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_TRY(hipModuleLaunchKernel(m->fns[k], (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
+  HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
                                 m->stream, nullptr, cfg));
   return IEM_OK;
+}
+
+int launch(iem_model *m, size_t k, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
+  return launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], x, y, out, w, v, aux);
 }
 
 int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
@@ -297,6 +357,68 @@ int launch_kind(iem_model *m, int kind, const double *x, const double *y, double
       if (rc) return rc;
     }
   return IEM_OK;
+}
+
+int launch_kind_alt(iem_model *m, int kind, const double *x, const double *y, double *out, double w) {
+  for (size_t k = 0; k < m->alt.prog.kernels.size(); ++k)
+    if (m->alt.prog.kernels[k].kind == kind) {
+      int rc = launch_one(m, m->alt.prog.kernels[k], m->alt.fns[k], m->alt.argbuf[k], x, y, out, w, nullptr, nullptr);
+      if (rc) return rc;
+    }
+  return IEM_OK;
+}
+
+// jac_coord! / hess_coord! through the tuner (struct Alt): the first IEM_TUNE_CALLS calls into an output buffer
+// alternate default / alt under events, then the faster variant (medians; alt only if > 2 % faster) is kept.
+int launch_tuned(iem_model *m, int which, int kind, const double *x, const double *y, double *out, double w) {
+  if (!m->alt.on) return launch_kind(m, kind, x, y, out, w);
+  iem_model::TuneSet &S = m->tune[which];
+  iem_model::Tune *hit = nullptr;
+  for (auto &t : S.slot)
+    if (t.out == out) hit = &t;
+  if (!hit) {                    // a buffer not seen lately: its own measurement, in the oldest slot
+    hit = &S.slot[S.next];
+    S.next = (S.next + 1) % 4;
+    hit->out = out; hit->calls = 0; hit->choice = -1;
+  }
+  iem_model::Tune &T = *hit;
+  if (T.choice >= 0) return T.choice ? launch_kind_alt(m, kind, x, y, out, w) : launch_kind(m, kind, x, y, out, w);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(m->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap != hipStreamCaptureStatusNone) return launch_kind(m, kind, x, y, out, w);   // no timing inside a graph capture
+  if (T.calls < IEM_TUNE_CALLS) {
+    if (!T.have_events) {
+      for (auto &e : T.ev) for (auto &q : e) HIP_TRY(hipEventCreate(&q));
+      T.have_events = true;
+    }
+    const int v = T.calls & 1;
+    HIP_TRY(hipEventRecord(T.ev[T.calls][0], m->stream));
+    int rc = v ? launch_kind_alt(m, kind, x, y, out, w) : launch_kind(m, kind, x, y, out, w);
+    HIP_TRY(hipEventRecord(T.ev[T.calls][1], m->stream));
+    ++T.calls;
+    return rc;
+  }
+  if (hipEventQuery(T.ev[IEM_TUNE_CALLS - 1][1]) == hipSuccess) {   // all have run: decide (never waits)
+    // single launches time to +-5 % and the first ones of a process run cold: median of each variant's last
+    // eight samples; the large batch must win by 2 %
+    std::vector<float> s[2];
+    for (int c = 4; c < IEM_TUNE_CALLS; ++c) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, T.ev[c][0], T.ev[c][1]) == hipSuccess) s[c & 1].push_back(ms);
+    }
+    float med[2] = {0.f, 1e30f};
+    for (int v = 0; v < 2; ++v)
+      if (!s[v].empty()) { std::sort(s[v].begin(), s[v].end()); med[v] = s[v][s[v].size() / 2]; }
+    T.choice = med[1] < 0.98f * med[0] ? 1 : 0;
+    if (getenv("IEM_TUNER_LOG")) {
+      fprintf(stderr, "iem tuner: kind %d buffer %p:", kind, (const void *)out);
+      for (int c = 0; c < IEM_TUNE_CALLS; ++c) { float ms = -1.f; (void)hipEventElapsedTime(&ms, T.ev[c][0], T.ev[c][1]); fprintf(stderr, " %s%.4f", c & 1 ? "a" : "d", ms); }
+      fprintf(stderr, " medians %.4f / %.4f -> %s\n", med[0], med[1], T.choice ? "alt" : "default");
+    }
+    return T.choice ? launch_kind_alt(m, kind, x, y, out, w) : launch_kind(m, kind, x, y, out, w);
+  }
+  (void)hipGetLastError();
+  return launch_kind(m, kind, x, y, out, w);
 }
 
 // host-side item index evaluation for the structure calls
@@ -530,6 +652,8 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "obj_unroll") == 0) { o.obj_unroll = (int)value; return IEM_OK; }
   if (std::strcmp(name, "flat2d") == 0) { o.flat2d = (int)value; return IEM_OK; }
   if (std::strcmp(name, "flush32") == 0) { o.flush32 = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "autotune") == 0) { o.autotune = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "autotune_min_blocks") == 0) { o.autotune_min_blocks = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -694,28 +818,26 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
   if (hipMalloc((void **)&m->d_obj, 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc obj"));
   if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&m->d_hobj, m->h_obj, 0) != hipSuccess) return bail(fail(IEM_E_HIP, "hipHostMalloc"));
-  for (const iem::KernelDesc &kd : m->prog.kernels) {
-    for (int id : kd.fa) if ((rc = upload_array(m, id, false)) != IEM_OK) return bail(rc);
-    for (int id : kd.ia) if ((rc = upload_array(m, id, true)) != IEM_OK) return bail(rc);
+  if ((rc = prepare_program(m, m->prog, m->d_tables, m->argbuf)) != IEM_OK) return bail(rc);
+  // second code object for the tuner: only for block-store models with a large jac/hess grid (below ~2e5 supports
+  // the larger batch loses), never for the experiment knobs
+  if (m->opt.autotune && m->opt.store_mode == 2 && m->opt.lds_slots < 48 && !m->opt.no_fuse && !m->opt.ablate) {
+    int64_t big = 0;
+    for (const iem::KernelDesc &kd : m->prog.kernels)
+      if (kd.kind == iem::KK_JAC || kd.kind == iem::KK_HESS) big = std::max(big, kd.n_blocks);
+    if (big >= m->opt.autotune_min_blocks) {
+      iem::Options ob = m->opt;
+      ob.lds_slots = 48;
+      try {
+        m->alt.prog = iem::generate(m->model, ob);
+      } catch (const std::exception &e) {
+        return bail(fail(IEM_E_BLOB, e.what()));
+      }
+      if ((rc = load_program(m, m->alt.prog, ob, &m->alt.mod, &m->alt.fns)) != IEM_OK) return bail(rc);
+      if ((rc = prepare_program(m, m->alt.prog, m->alt.d_tables, m->alt.argbuf)) != IEM_OK) return bail(rc);
+      m->alt.on = true;
+    }
   }
-  m->d_tables.assign(m->prog.kernels.size(), nullptr);
-  for (size_t k = 0; k < m->prog.kernels.size(); ++k) {
-    const iem::KernelDesc &kd = m->prog.kernels[k];
-    if (!kd.tables_in_memory) continue;
-    std::vector<uint64_t> tb;
-    for (int64_t v : kd.ip) tb.push_back((uint64_t)v);
-    if (kd.ip.empty()) tb.push_back(0);
-    for (double v : kd.dp) { uint64_t b; std::memcpy(&b, &v, 8); tb.push_back(b); }
-    if (kd.dp.empty()) tb.push_back(0);
-    for (int id : kd.fa) tb.push_back((uint64_t)(uintptr_t)m->d_arrays[id]);
-    if (kd.fa.empty()) tb.push_back(0);
-    for (int id : kd.ia) tb.push_back((uint64_t)(uintptr_t)m->d_arrays[id]);
-    if (kd.ia.empty()) tb.push_back(0);
-    if (hipMalloc(&m->d_tables[k], tb.size() * 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc tables"));
-    if (hipMemcpy(m->d_tables[k], tb.data(), tb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(IEM_E_HIP, "upload tables"));
-  }
-  m->argbuf.resize(m->prog.kernels.size());
-  for (size_t k = 0; k < m->prog.kernels.size(); ++k) build_argbuf(m, k);
   for (int kind : {(int)iem::KK_GRAD, (int)iem::KK_JTPROD, (int)iem::KK_HPROD}) {
     // ranges the kernels of the kind do not overwrite completely.  Neighbouring ranges separated by a SHORT
     // fully-overwritten stretch are zeroed as one (what lies between is written afterwards, on the same
@@ -748,6 +870,9 @@ int iem_destroy(iem_model *m) {
   if (m->h_obj) hipHostFree(m->h_obj);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
   for (void *t : m->d_tables) if (t) hipFree(t);
+  for (void *t : m->alt.d_tables) if (t) hipFree(t);
+  if (m->alt.mod) hipModuleUnload(m->alt.mod);
+  for (auto &S : m->tune) for (auto &T : S.slot) if (T.have_events) for (auto &e : T.ev) for (auto &q : e) hipEventDestroy(q);
   if (m->ev0) hipEventDestroy(m->ev0);
   if (m->ev1) hipEventDestroy(m->ev1);
   if (m->mod) hipModuleUnload(m->mod);
@@ -918,13 +1043,13 @@ int iem_cons(iem_model *m, const double *d_x, double *d_c) {
 int iem_jac_coord(iem_model *m, const double *d_x, double *d_vals) {
   if (!m || !d_x || (!d_vals && m->model.nnzj)) return fail(IEM_E_ARG, "null argument");
   DevGuard dg_(m->device);
-  return launch_kind(m, iem::KK_JAC, d_x, nullptr, d_vals, 0.0);
+  return launch_tuned(m, 0, iem::KK_JAC, d_x, nullptr, d_vals, 0.0);
 }
 
 int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_vals) {
   if (!m || !d_x || (!d_y && m->model.ncon) || (!d_vals && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
   DevGuard dg_(m->device);
-  return launch_kind(m, iem::KK_HESS, d_x, d_y, d_vals, obj_weight);
+  return launch_tuned(m, 1, iem::KK_HESS, d_x, d_y, d_vals, obj_weight);
 }
 
 int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
@@ -1242,6 +1367,15 @@ int iem_comm_status(iem_model *m, int64_t *out_status) {
   unsigned long long st = 0;
   HIP_TRY(hipMemcpy(&st, m->mailbox, 8, hipMemcpyDeviceToHost));
   *out_status = (int64_t)st;
+  return IEM_OK;
+}
+
+int iem_tuner_choice(iem_model *m, int kind, const double *d_vals, int *out_choice) {
+  if (!m || !out_choice || kind < 0 || kind > 1) return fail(IEM_E_ARG, "bad argument");
+  *out_choice = -1;
+  if (m->alt.on)
+    for (auto &t : m->tune[kind].slot)
+      if (t.out == d_vals) *out_choice = t.choice;
   return IEM_OK;
 }
 

@@ -81,7 +81,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
-           "iem_set_option", "iem_time_kernels", "iem_last_error", "iem_version"]
+           "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_last_error", "iem_version"]
 
 
 def build_library(force: bool = False) -> str:
@@ -153,6 +153,7 @@ def lib():
     L.iem_free.argtypes = [vp]
     L.iem_set_option.argtypes = [C.c_char_p, i64]
     L.iem_time_kernels.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
+    L.iem_tuner_choice.argtypes = [vp, i32, vp, C.POINTER(i32)]
     _lib = L
     return L
 
@@ -168,7 +169,7 @@ def set_option(name: str, value: int):
 
 # generator knobs and their defaults (csrc/iem_codegen.hpp: struct Options)
 OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=0, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
-                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2)
+                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2, autotune=1, autotune_min_blocks=400)
 
 
 def option_array(opts: dict):

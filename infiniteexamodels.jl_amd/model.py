@@ -349,6 +349,13 @@ class ExaModel:
         _lib.check(self._L.iem_comm_status(self._h, C.byref(st)))
         return int(st.value)
 
+    def tuner_choice(self, kind: str, out) -> int:
+        """Which code object ``jac_coord!`` / ``hess_coord!`` (kind "jac" / "hess") uses for output
+        buffer ``out``: -1 still measuring or tuner off, 0 default, 1 large store batch."""
+        ch = C.c_int32(-1)
+        _lib.check(self._L.iem_tuner_choice(self._h, {"jac": 0, "hess": 1}[kind], _ptr(out), C.byref(ch)))
+        return int(ch.value)
+
     def time_kernels(self, x, y, jac, hess, iters: int = 20):
         """Average device time (ms) of one jac_coord! and one hess_coord! call, HIP events
         on the launch stream."""

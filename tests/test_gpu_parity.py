@@ -411,3 +411,44 @@ def test_offline_code_objects_are_used(torch_cuda):
     gm = ExaModel.from_blob(blob)
     assert not any(k["jit"] for k in gm.kernels()), "the offline-built code object was not used"
     gm.close()
+
+
+def test_store_batch_tuner_is_invisible_in_the_results(torch_cuda):
+    """Large jac/hess grids keep a second code object (lds_slots = 48) and pick per output buffer from the first twenty
+    calls: every call, whichever variant ran, writes the same bytes as a handle with the tuner off, into either of
+    two buffers, and the later calls (decided) too."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    S = 260_000                                   # 525 workgroups: above autotune_min_blocks
+    core = transcribe.exa_core(workloads.quadrotor(S))
+    blob = core.to_blob()
+    tuned = ExaModel(core, device=0, blob=blob)
+    plain = ExaModel(core, device=0, blob=blob, options={"autotune": 0})
+    om = OracleModel(blob)
+    om.set_threads(min(om.max_threads(), 16))
+    x = tuned.meta.x0 + 0.1 * np.random.default_rng(0).standard_normal(tuned.meta.nvar)
+    x[7 * S:8 * S] = np.clip(x[7 * S:8 * S], -1.2, 1.2)
+    y = np.random.default_rng(1).standard_normal(tuned.meta.ncon)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    jref = plain.jac_coord(xd).cpu().numpy()
+    href = plain.hess_coord(xd, yd, obj_weight=0.7).cpu().numpy()
+    _close(jref, om.jac_coord(x), "jac")
+    _close(href, om.hess_coord(x, y, 0.7), "hess")
+    bufs = [(torch.empty(tuned.meta.nnzj, dtype=torch.float64, device="cuda"), torch.empty(tuned.meta.nnzh, dtype=torch.float64, device="cuda")) for _ in range(2)]
+    for it in range(24):
+        for jb, hb in bufs:                       # each buffer has its own tuner slot
+            jb.fill_(float("nan")); hb.fill_(float("nan"))
+            assert np.array_equal(tuned.jac_coord(xd, jb).cpu().numpy(), jref), f"jac call {it}"
+            assert np.array_equal(tuned.hess_coord(xd, yd, hb, obj_weight=0.7).cpu().numpy(), href), f"hess call {it}"
+    for jb, hb in bufs:                           # 24 synchronised calls each: both buffers are decided, separately
+        assert tuned.tuner_choice("jac", jb) in (0, 1) and tuned.tuner_choice("hess", hb) in (0, 1)
+    assert plain.tuner_choice("jac", bufs[0][0]) == -1
+    jb, hb = bufs[0]
+    for it in range(12):                          # decided: the chosen variant alone
+        jb.fill_(float("nan"))
+        assert np.array_equal(tuned.jac_coord(xd, jb).cpu().numpy(), jref), f"jac call {it} (same buffer)"
+        hb.fill_(float("nan"))
+        assert np.array_equal(tuned.hess_coord(xd, yd, hb, obj_weight=0.7).cpu().numpy(), href)
+    tuned.close(); plain.close()

@@ -39,6 +39,9 @@ for rnd in range(3):
     for v, m in zip(variants, models):
         row = []
         for jb, hb in bufs:
+            for _ in range(24):         # lets a handle's store-batch tuner decide for THIS buffer pair (it needs completed events)
+                m.jac_coord(xd, jb); m.hess_coord(xd, yd, hb)
+                torch.cuda.synchronize()
             ms_j, ms_h = m.time_kernels(xd, yd, jb, hb, iters=50)
             row.append(f"{ms_j:.4f}/{ms_h:.4f}")
         print(f"round {rnd} {v:28s} jac/hess ms into 3 buffer pairs: " + "  ".join(row), flush=True)
