@@ -45,3 +45,21 @@ def test_distributed_x_halo_and_allreduce(name, group, size, world, mode, built)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     assert "OK" in outs[0], outs[0][-3000:]
+
+
+def test_bench_line_carries_a_checked_comm_section(built):
+    """bench.py at N = 2 (two ranks rehearsed on this one GPU, gloo for the host rendezvous): the JSON line reports the
+    halo exchange and objective all-reduce of the C-ABI's own mailboxes — exact, timed — next to the headline value."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device",
+                        "--supports", "40000", "--steps", "5", "--warmup", "2", "--no-weak"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    c = j["comm"]
+    assert "error" not in c, c
+    assert c["halo_exact"] is True and c["allreduce_exact"] is True
+    assert c["halo_exchange_us"] > 0 and c["allreduce_obj_us"] > 0 and c["pair_with_halo"]["value"] > 0
