@@ -194,6 +194,47 @@ def comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, iter
     return out
 
 
+def comm_isolated(args, dist, rank, world, local_rank, barrier):
+    """Run comm_section in CHILD processes (one per rank, on this rank's GPU, gloo for their host rendezvous) while
+    the parents idle: peer-mapped memory is the one part of this script that has only been rehearsed with all ranks
+    on a single GPU, and whatever it does on a real xGMI node — an error code, a time-out, a fault — must end in a
+    "comm": {"error": …} entry, never in a lost headline line."""
+    import socket
+    import subprocess
+    port = [0]
+    if rank == 0:
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port[0] = sk.getsockname()[1]; sk.close()
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--comm-child", "--gpus", str(world), "--dist-backend", "gloo", "--supports", str(args.supports),
+           "--scaling", args.scaling, "--steps", str(min(args.steps, 200)), "--warmup", "3", "--store-mode", str(args.store_mode),
+           "--hess-layout", args.hess_layout] + (["--same-device"] if args.same_device else []) + [a for kv in args.opt for a in ("--opt", kv)]
+    out, rc = "", -1
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, errtxt = p.communicate(timeout=240)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, errtxt = p.communicate()
+            rc = -9
+    except Exception as e:     # noqa: BLE001
+        errtxt = str(e)
+    barrier()
+    if rank != 0:
+        return None
+    for ln in out.splitlines():
+        if ln.startswith("COMM "):
+            c = json.loads(ln[5:])
+            c["isolation"] = "child processes, one per rank"
+            return c
+    return {"error": f"comm child exited {rc}: {errtxt.strip().splitlines()[-1] if errtxt.strip() else 'no output'}"[:400]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +255,7 @@ def main():
     ap.add_argument("--emulate-shard", default="", help="R/N: time shard R of an N-way sharded run on this GPU")
     ap.add_argument("--graph", action="store_true", help="replay the jac+hess pair from a captured HIP graph instead of eager launches")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the (untimed) check of the halo exchange / objective all-reduce")
+    ap.add_argument("--comm-child", action="store_true", help=argparse.SUPPRESS)   # internal: run ONLY the comm section (see comm_isolated)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -345,6 +387,14 @@ def main():
 
     dt, supports_total, (gm, S_local, xd, yd, jac, hess, step) = measure(args.scaling, args.steps, args.warmup)
 
+    if args.comm_child:
+        comm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, min(args.steps, 200))
+        if rank == 0:
+            print("COMM " + json.dumps(comm), flush=True)
+        barrier()
+        dist.destroy_process_group()
+        return
+
     # distribution of single pairs (median, p10/p90), HIP events on the
     # launch stream, outside the timed region
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(min(args.steps, 200) + 1)]
@@ -406,8 +456,11 @@ def main():
     # N > 1, outside the headline timed region and never able to void it: the data path a solver adds around the
     # pair — the halo exchange of x (every iteration moves x) and the one collective (objective all-reduce) —
     # wired through the C-ABI's own mailboxes, checked for correctness and timed on this machine's links
-    if world > 1 and use_dist and not args.no_comm and not args.emulate_shard:
-        comm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, min(args.steps, 200))
+    if world > 1 and use_dist and not args.no_comm and not args.emulate_shard and not args.comm_child:
+        if args.same_device and 2 * world > 6:     # one-GPU rehearsal: parents + children would exceed the box's per-GPU process limit
+            comm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, min(args.steps, 200))
+        else:
+            comm = comm_isolated(args, dist, rank, world, local_rank, barrier)
         if rank == 0:
             if "pair_with_halo" in comm:
                 comm["pair_with_halo"]["value"] = supports_total / 1e6 / (comm["pair_with_halo"]["ms_per_step"] * 1e-3)
