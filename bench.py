@@ -350,6 +350,10 @@ def main():
         # one step = iem_jac_coord + iem_hess_coord through the C-ABI; argument checks and the stream lookup of
         # the Python wrapper are done once (ExaModel.raw_pair) — at 8 GPUs a step is 25 us of device time
         step = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0)
+        # solver set-up, before the warm-up: which of the handle's two code objects writes THESE buffers faster
+        # (iem_tune; large grids only, -1 = the handle has one code object).  Without it the first twenty pairs
+        # of the run would be the measurement.
+        gm._tuned = gm.tune(xd, yd, jac, hess, obj_weight=1.0)
 
         if args.graph:
             def eager():      # the wrappers follow torch's CURRENT stream, which the capture needs
@@ -443,6 +447,7 @@ def main():
                        "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
                        "store_mode": args.store_mode, "hess_layout": args.hess_layout, "parallelism": par,
                        "launch": "hipGraph replay" if args.graph else "eager",
+                       "store_batch_tuner": {**gm._tuned, "meaning": "-1 one code object, 0 default kept, 1 large LDS batch chosen for this output buffer (iem_tune at set-up)"},
                        "kernels_from": "hiprtc at run time (code-object cache miss)" if any(k["jit"] for k in gm.kernels()) else "in-tree code-object cache"},
             "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,

@@ -1379,6 +1379,20 @@ int iem_tuner_choice(iem_model *m, int kind, const double *d_vals, int *out_choi
   return IEM_OK;
 }
 
+int iem_tune(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_jac, double *d_hess) {
+  if (!m || !d_x || (d_hess && !d_y)) return fail(IEM_E_ARG, "bad argument");
+  if (!m->alt.on) return IEM_OK;
+  DevGuard dg_(m->device);
+  for (int round = 0; round < 2; ++round) {   // the measured calls, then (events complete) the call that decides
+    for (int i = 0; i < (round ? 1 : IEM_TUNE_CALLS); ++i) {
+      if (d_jac) { int rc = iem_jac_coord(m, d_x, d_jac); if (rc) return rc; }
+      if (d_hess) { int rc = iem_hess_coord(m, d_x, d_y, obj_weight, d_hess); if (rc) return rc; }
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+  }
+  return IEM_OK;
+}
+
 int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess, int iters,
                      double *h_ms_jac, double *h_ms_hess) {
   if (!m || iters <= 0) return fail(IEM_E_ARG, "bad argument");

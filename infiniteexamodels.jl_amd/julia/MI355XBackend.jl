@@ -92,6 +92,14 @@ function NLPModels.hess_coord!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVect
                 m.handle, dptr(x), dptr(y), obj_weight, dptr(v)))
     return v
 end
+# optional set-up step, once the solver has allocated its COO value buffers: which of the handle's two code objects
+# writes THESE buffers faster (include/iem.h: iem_tune); a no-op for handles with one code object
+function tune!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Float64}, jac::ROCVector{Float64},
+               hess::ROCVector{Float64}; obj_weight = 1.0)
+    check(ccall((:iem_tune, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Float64}),
+                m.handle, dptr(x), dptr(y), obj_weight, dptr(jac), dptr(hess)))
+    return m
+end
 function NLPModels.jac_structure!(m::MI355XModel, rows::AbstractVector{Int}, cols::AbstractVector{Int})
     r, c = Vector{Int64}(undef, m.meta.nnzj), Vector{Int64}(undef, m.meta.nnzj)
     check(ccall((:iem_jac_structure, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Cint), m.handle, r, c, 1))

@@ -81,7 +81,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
-           "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_last_error", "iem_version"]
+           "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
 
 def build_library(force: bool = False) -> str:
@@ -154,6 +154,7 @@ def lib():
     L.iem_set_option.argtypes = [C.c_char_p, i64]
     L.iem_time_kernels.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(dbl), C.POINTER(dbl)]
     L.iem_tuner_choice.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.iem_tune.argtypes = [vp, vp, vp, dbl, vp, vp]
     _lib = L
     return L
 

@@ -349,6 +349,20 @@ class ExaModel:
         _lib.check(self._L.iem_comm_status(self._h, C.byref(st)))
         return int(st.value)
 
+    def tune(self, x, y, jac=None, hess=None, obj_weight: float = 1.0) -> dict:
+        """Decide the store-batch variant for these output buffers now (``iem_tune``: twenty-one complete
+        evaluations into each, then a stream synchronise) instead of during the first calls of a solve."""
+        self._chk(x, self.meta.nvar, "x")
+        if hess is not None:
+            self._chk(y, self.meta.ncon, "y"); self._chk(hess, self.meta.nnzh, "hess")
+        if jac is not None:
+            self._chk(jac, self.meta.nnzj, "jac")
+        self._sync_stream()
+        _lib.check(self._L.iem_tune(self._h, _ptr(x), _ptr(y) if hess is not None else None, float(obj_weight),
+                                    _ptr(jac) if jac is not None else None, _ptr(hess) if hess is not None else None))
+        return {"jac": self.tuner_choice("jac", jac) if jac is not None else -1,
+                "hess": self.tuner_choice("hess", hess) if hess is not None else -1}
+
     def tuner_choice(self, kind: str, out) -> int:
         """Which code object ``jac_coord!`` / ``hess_coord!`` (kind "jac" / "hess") uses for output
         buffer ``out``: -1 still measuring or tuner off, 0 default, 1 large store batch."""

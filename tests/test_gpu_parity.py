@@ -451,4 +451,11 @@ def test_store_batch_tuner_is_invisible_in_the_results(torch_cuda):
         assert np.array_equal(tuned.jac_coord(xd, jb).cpu().numpy(), jref), f"jac call {it} (same buffer)"
         hb.fill_(float("nan"))
         assert np.array_equal(tuned.hess_coord(xd, yd, hb, obj_weight=0.7).cpu().numpy(), href)
+    # explicit set-up form: iem_tune decides for fresh buffers at once, and what it leaves in them is an evaluation
+    jb2 = torch.full((tuned.meta.nnzj,), float("nan"), dtype=torch.float64, device="cuda")
+    hb2 = torch.full((tuned.meta.nnzh,), float("nan"), dtype=torch.float64, device="cuda")
+    ch = tuned.tune(xd, yd, jb2, hb2, obj_weight=0.7)
+    assert ch["jac"] in (0, 1) and ch["hess"] in (0, 1)
+    assert np.array_equal(jb2.cpu().numpy(), jref) and np.array_equal(hb2.cpu().numpy(), href)
+    assert plain.tune(xd, yd, jb2, hb2) == {"jac": -1, "hess": -1}
     tuned.close(); plain.close()

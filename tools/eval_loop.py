@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--supports", type=int, default=100_000)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
+    ap.add_argument("--products", action="store_true", help="also time jprod!/jtprod!/hprod! (event-timed, outside the loop figures)")
     args = ap.parse_args()
     from infiniteexamodels.jl_amd import lib as iemlib
     for kv in args.opt:
@@ -82,12 +83,20 @@ def measure(args):
         "obj": lambda: gm.obj(x), "grad": lambda: gm.grad(x, g), "cons": lambda: gm.cons(x, c),
         "jac_coord": lambda: gm.jac_coord(x, jv), "hess_coord": lambda: gm.hess_coord(x, y, hv, obj_weight=1.0),
     }
-    for f in calls.values():
+    timed = dict(calls)
+    if getattr(args, "products", False):
+        v = torch.tensor(np.random.default_rng(2).standard_normal(gm.meta.nvar), device="cuda")
+        Jv = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
+        Jtv = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+        Hv = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+        timed.update({"jprod": lambda: gm.jprod(x, v, Jv), "jtprod": lambda: gm.jtprod(x, y, Jtv),
+                      "hprod": lambda: gm.hprod(x, y, v, Hv, obj_weight=1.0)})
+    for f in timed.values():
         for _ in range(5):
             f()
     torch.cuda.synchronize()
     ms = {}
-    for name, f in calls.items():
+    for name, f in timed.items():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
@@ -124,6 +133,8 @@ def measure(args):
     torch.cuda.synchronize()
     graph_ms = (time.perf_counter() - t0) / args.iters * 1e3
     kinds = {"obj": "obj", "grad": "grad", "cons": "cons", "jac_coord": "jac", "hess_coord": "hess"}
+    if getattr(args, "products", False):
+        kinds.update({"jprod": "jprod", "jtprod": "jtprod", "hprod": "hprod"})
     bytes_ = {k: sum(kk["alg_bytes_read"] + kk["alg_bytes_written"] for kk in gm.kernels() if kk["kind"] == v)
               for k, v in kinds.items()}
     out = {
