@@ -235,6 +235,8 @@ void iem_free(void *p);
  *                  summation order is — obj is bitwise reproducible)
  *   "det_shared"   1 (default): gradient / J'v / Hv entries shared by many items are reduced in a fixed
  *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs)
+ *   "pull_scatter" 1 (default): grad!/jtprod!/hprod! compute a stencil neighbour's addend (x[i-1] of a difference
+ *                  row) on the neighbour's lane — exclusive stores, no zero fill; 0: atomics (A/B runs)
  *   "autotune"     1 (default): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups
  *                  keep a second code object with a 48-slot LDS store batch and choose per output buffer,
  *                  from the first twenty calls into it (HIP events, every call a valid evaluation), which of

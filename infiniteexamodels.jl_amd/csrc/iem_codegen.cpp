@@ -18,6 +18,7 @@
 #include "iem_codegen.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -294,7 +295,9 @@ class KernelBuilder {
     return it->second;
   }
 
-  TGeo geo(int ti, bool scalar) {
+  // shift0: lane q of dim 0 evaluates the item that normally sits on lane q - shift0 (a "pulled" clone of the
+  // template, build(): scatter slots that land on a neighbour lane's entry are computed BY that neighbour)
+  TGeo geo(int ti, bool scalar, int64_t shift0 = 0) {
     const Template &t = m_.tpl[ti];
     TGeo G;
     G.scalar = scalar;
@@ -304,7 +307,7 @@ class KernelBuilder {
     } else {
       os << "inb";
       for (int d = 0; d < g_.nd; ++d) {
-        G.sh[d] = g_.lo[d] - t.origin[d];
+        G.sh[d] = g_.lo[d] - t.origin[d] - (d == 0 ? shift0 : 0);
         int64_t qlo = -G.sh[d], qhi = t.dims[d] - G.sh[d];  // valid q range [qlo, qhi)
         G.qlo[d] = qlo; G.qhi[d] = qhi;
         if (qlo > 0) os << " && q" << d << " >= " << coefstr(qlo);
@@ -636,15 +639,13 @@ class KernelBuilder {
     for (int ti : g_.tpls) order.emplace_back(ti, false);
     for (int ti : g_.scalars) order.emplace_back(ti, true);
     std::sort(order.begin(), order.end());
-    for (auto &pr : order) {
-      int ti = pr.first;
+    auto make_output = [&](int ti, bool scalar, int64_t shift0) -> Output {
       const Template &t = m_.tpl[ti];
-      if (!relevant(t)) continue;
-      TGeo G = geo(ti, pr.second);
+      TGeo G = geo(ti, scalar, shift0);
       TplGen tg(*this, ti, G);
       Output o;
       o.kind = kind_; o.tpl = ti; o.guard = G.guard; o.pos_idx = -1;
-      o.scalar = pr.second;
+      o.scalar = scalar;
       for (int d = 0; d < 3; ++d) { o.qlo[d] = G.qlo[d]; o.qhi[d] = G.qhi[d]; }
       switch (kind_) {
         case KK_CONS: {
@@ -769,10 +770,85 @@ class KernelBuilder {
         }
       }
       for (int &v : o.vals) if (v < 0) v = C(0.0);
-      outs_.push_back(std::move(o));
+      return o;
+    };
+    for (auto &pr : order) {
+      if (!relevant(m_.tpl[pr.first])) continue;
+      outs_.push_back(make_output(pr.first, pr.second, 0));
     }
-    if (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD) merge_scatter();
+    if (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD) {
+      if (opt_.pull_scatter) pull_neighbours(make_output);
+      merge_scatter();
+    }
     return !outs_.empty();
+  }
+
+  // Scatter kinds, stencil neighbours.  A backward difference row at lane i adds into x[i] AND into x[i-1] — the
+  // entry of the lane next door, which that lane also writes: both must be atomics, and the output must be zeroed
+  // first.  Instead the NEIGHBOUR computes that addend itself: slots of this kernel whose destinations are the same
+  // affine map of the lane up to a small shift along dim 0 form a family; the shift most items use is canonical,
+  // and a slot at another shift is taken out of its template and computed by a clone of the template that is
+  // shifted by as many lanes (geo(shift0): every index, load and guard moves with it), so that its destination
+  // coincides with the canonical one — merge_scatter then sums the family in registers and the entry leaves
+  // through ONE exclusive store.  The clone re-evaluates the template for the neighbouring item: a derivative
+  // approximation (src/transform.jl:511-562 of the reference) is linear, its partials are item data.
+  template <class MakeOutput>
+  void pull_neighbours(MakeOutput &make_output) {
+    if (g_.flat) return;
+    struct Ref { int out, slot; int64_t c, items; };
+    std::map<std::array<int64_t, 4>, std::vector<Ref>> fam;   // (space, k0, k1, k2) -> slots
+    auto box_items = [](const Output &o) { int64_t n = 1; for (int d = 0; d < 3; ++d) n *= std::max<int64_t>(o.qhi[d] - o.qlo[d], 0); return n; };
+    for (size_t oi = 0; oi < outs_.size(); ++oi) {
+      const Output &o = outs_[oi];
+      if (o.scalar) continue;
+      for (size_t s = 0; s < o.grad_idx.size(); ++s) {
+        const IdxVal &iv = idx_[o.grad_idx[s]];
+        if (!iv.ind.empty() || iv.aff.k[0] == 0) continue;
+        fam[{(int64_t)iv.aff.space, iv.aff.k[0], iv.aff.k[1], iv.aff.k[2]}].push_back(Ref{(int)oi, (int)s, iv.aff.c, box_items(o)});
+      }
+    }
+    const int64_t max_shift = 4;
+    std::map<std::pair<int, int64_t>, std::vector<int>> moved;   // (output, shift) -> its slots to move
+    for (auto &kv : fam) {
+      const int64_t k0 = kv.first[1];
+      auto &refs = kv.second;
+      // destination at lane 0 of dim 0 (the other dims enter with the slot's own box: same k1, k2 for the whole family)
+      std::vector<char> taken(refs.size(), 0);
+      for (size_t a = 0; a < refs.size(); ++a) {
+        if (taken[a]) continue;
+        // cluster: slots within max_shift lanes of slot a's map (chains of neighbours stay in one cluster)
+        std::vector<size_t> cl{a};
+        taken[a] = 1;
+        for (size_t grow = 0; grow < cl.size(); ++grow)
+          for (size_t b = 0; b < refs.size(); ++b) {
+            if (taken[b]) continue;
+            const int64_t dc = refs[b].c - refs[cl[grow]].c;
+            if (dc % k0 == 0 && std::llabs(dc / k0) <= max_shift) { taken[b] = 1; cl.push_back(b); }
+          }
+        std::map<int64_t, int64_t> weight;   // c -> items using it
+        for (size_t i : cl) weight[refs[i].c] += refs[i].items;
+        if (weight.size() < 2) continue;
+        int64_t canon = weight.begin()->first;
+        for (auto &w : weight) if (w.second > weight[canon] || (w.second == weight[canon] && w.first > canon)) canon = w.first;
+        for (size_t i : cl) {
+          if (refs[i].c == canon) continue;
+          const int64_t dq = (refs[i].c - canon) / k0;   // the slot's entry belongs to lane q + dq
+          const Output &o = outs_[refs[i].out];
+          if (o.qlo[0] + dq < 0 || o.qhi[0] + dq > g_.ext[0]) continue;   // the clone would leave the launch domain
+          moved[{refs[i].out, dq}].push_back(refs[i].slot);
+        }
+      }
+    }
+    for (auto &mv : moved) {
+      const int oi = mv.first.first;
+      Output clone = make_output(outs_[oi].tpl, false, mv.first.second);
+      if (clone.vals.size() != outs_[oi].vals.size()) throw std::runtime_error("internal: pulled clone differs in shape");
+      std::vector<char> keep(clone.vals.size(), 0);
+      for (int s : mv.second) { keep[s] = 1; outs_[oi].grad_mode[s] = -1; }
+      for (size_t s = 0; s < clone.vals.size(); ++s)
+        if (!keep[s]) clone.grad_mode[s] = -1;
+      outs_.push_back(std::move(clone));
+    }
   }
 
   // Scatter kinds: slots of DIFFERENT templates of this kernel that hit the same destination from
@@ -786,7 +862,7 @@ class KernelBuilder {
     for (size_t oi = 0; oi < outs_.size(); ++oi) {
       if (outs_[oi].scalar) continue;
       for (size_t s = 0; s < outs_[oi].grad_idx.size(); ++s)
-        if (idx_[outs_[oi].grad_idx[s]].ind.empty()) by_dest[outs_[oi].grad_idx[s]].emplace_back((int)oi, (int)s);
+        if (idx_[outs_[oi].grad_idx[s]].ind.empty() && outs_[oi].grad_mode[s] >= 0) by_dest[outs_[oi].grad_idx[s]].emplace_back((int)oi, (int)s);
     }
     for (auto &kv : by_dest) {
       auto &parts = kv.second;
@@ -801,7 +877,43 @@ class KernelBuilder {
         for (auto &p : parts) if (!inside(outs_[p.first], outs_[parts[c].first])) all = false;
         if (all) host = (int)c;
       }
-      if (host < 0) continue;
+      if (host < 0) {
+        // no part contains the others (a difference row and its pulled clone: lanes [1, S) and [0, S-1)): when the
+        // boxes agree in dims 1, 2 and their dim-0 intervals form ONE interval, a new output on the union carries the sum
+        const Output &P0 = outs_[parts[0].first];
+        bool ok = !g_.flat;
+        std::vector<std::pair<int64_t, int64_t>> iv0;
+        for (auto &p : parts) {
+          const Output &o = outs_[p.first];
+          for (int d = 1; d < 3; ++d) if (o.qlo[d] != P0.qlo[d] || o.qhi[d] != P0.qhi[d]) ok = false;
+          iv0.emplace_back(o.qlo[0], o.qhi[0]);
+        }
+        std::sort(iv0.begin(), iv0.end());
+        int64_t lo0 = iv0[0].first, hi0 = iv0[0].second;
+        for (auto &r : iv0) { if (r.first > hi0) ok = false; hi0 = std::max(hi0, r.second); }
+        if (!ok) continue;
+        Output u;
+        u.kind = kind_; u.tpl = P0.tpl; u.pos_idx = -1; u.scalar = false;
+        for (int d = 0; d < 3; ++d) { u.qlo[d] = P0.qlo[d]; u.qhi[d] = P0.qhi[d]; }
+        u.qlo[0] = lo0; u.qhi[0] = hi0;
+        std::ostringstream os;
+        os << "inb";
+        for (int d = 0; d < g_.nd; ++d) {
+          if (u.qlo[d] > 0) os << " && q" << d << " >= " << coefstr(u.qlo[d]);
+          if (u.qhi[d] < g_.ext[d]) os << " && q" << d << " < " << ip(u.qhi[d]);
+        }
+        u.guard = guard_id(os.str());
+        int acc = -1;
+        for (auto &p : parts) {
+          const Output &o = outs_[p.first];
+          int v = mk(VGUARD, o.guard, o.vals[p.second], -1, -1, 0);
+          acc = acc < 0 ? v : add(acc, v);
+        }
+        u.vals = {acc}; u.grad_idx = {kv.first}; u.grad_mode = {2};
+        for (auto &p : parts) outs_[p.first].grad_mode[p.second] = -1;
+        outs_.push_back(std::move(u));
+        continue;
+      }
       const Output &H = outs_[parts[host].first];
       int acc = -1;
       for (auto &p : parts) {
@@ -1398,6 +1510,19 @@ class KernelBuilder {
         elems += cur_hi - cur_lo + 1;
       }
       kd.alg_bytes_read = 8 * (elems + (int64_t)iloads_.size() * g_.ext[0] * g_.ext[1] * g_.ext[2]);
+      if (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD) {
+        // scatter kinds: one write per item of every slot that is still its own (merge_scatter sums a lane's
+        // addends into one slot; entries reduced by the last workgroup are a handful) plus the fused zero fill
+        int64_t w = 0;
+        for (auto &o : outs_) {
+          int64_t n = 1;
+          if (!o.scalar) for (int d = 0; d < 3; ++d) n *= std::max<int64_t>(o.qhi[d] - o.qlo[d], 1);
+          for (size_t sl = 0; sl < o.vals.size(); ++sl)
+            if (sl < o.grad_mode.size() && o.grad_mode[sl] >= 0 && o.grad_mode[sl] != 3) w += n;
+        }
+        for (auto &z : zero_fill_) w += z.second - z.first;
+        alg_w_ = w;
+      }
       kd.alg_bytes_written = 8 * alg_w_;
     }
 
@@ -1757,8 +1882,9 @@ Program generate(const Model &m, const Options &opt_in) {
       if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {
         auto &outs = kb->outputs();
         for (size_t oi = 0; oi < outs.size(); ++oi) {
-          const Template &t = m.tpl[outs[oi].tpl];
-          bool scalar = std::find(g.scalars.begin(), g.scalars.end(), outs[oi].tpl) != g.scalars.end();
+          const bool scalar = outs[oi].scalar;
+          int64_t box_n[3], box_items = 1;   // the output's own item box in the launch domain (a pulled clone's is shifted, a union's is wider than its template's)
+          for (int d = 0; d < 3; ++d) { box_n[d] = scalar ? 1 : std::max<int64_t>(outs[oi].qhi[d] - outs[oi].qlo[d], 1); box_items *= box_n[d]; }
           for (size_t s = 0; s < outs[oi].grad_idx.size(); ++s) {
             if (outs[oi].grad_mode[s] < 0) continue;   // folded into another slot (merge_scatter)
             const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
@@ -1769,8 +1895,8 @@ Program generate(const Model &m, const Options &opt_in) {
               bool inj = true;
               int64_t reach = 0;  // largest offset reachable through the lower dims
               for (int d = 0; d < 3; ++d) {
-                int64_t n = scalar ? 1 : (d < t.nd ? t.dims[d] : 1);
-                int64_t q_lo = scalar ? 0 : (d < t.nd ? t.origin[d] - g.lo[d] : 0);
+                int64_t n = box_n[d];
+                int64_t q_lo = scalar ? 0 : outs[oi].qlo[d];
                 int64_t a = iv.aff.k[d] * q_lo, b = iv.aff.k[d] * (q_lo + n - 1);
                 lo += std::min(a, b); hi += std::max(a, b);
                 if (n > 1) {
@@ -1779,9 +1905,9 @@ Program generate(const Model &m, const Options &opt_in) {
                 }
               }
               gs.lo = lo; gs.hi = hi; gs.injective = inj;
-              gs.count = scalar ? 1 : t.n_items;
+              gs.count = box_items;
               // wave-uniform destination: every lane of a wave shares q1/q2 — not true for flat groups
-              gs.uniform0 = !g.flat && !scalar && iv.aff.k[0] == 0 && t.dims[0] > 1;
+              gs.uniform0 = !g.flat && !scalar && iv.aff.k[0] == 0 && box_n[0] > 1;
             } else {
               gs.lo = INT64_MIN; gs.hi = INT64_MAX;
             }

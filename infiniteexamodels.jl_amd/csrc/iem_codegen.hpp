@@ -54,6 +54,9 @@ struct Options {
   int flush32 = 2;     // block-store loops: 2 = 32-bit offsets relative to the block start, per-lane predicate on every round (default);
                        // 1 = whole rounds decided by scalar compares + branch (1-5 % SLOWER: the branches cost more than the predicates
                        // they save); 0 = round-1 form with 64-bit predicates (equal to 2) — profiles/r02_ab_flush_flat.txt
+  int pull_scatter = 1;   // 1: scatter kinds (grad!/jtprod!/hprod!): an addend that lands on a neighbour lane's entry (x[i-1] of a
+                          // difference row) is computed by that lane through a shifted clone of the template — exclusive stores, no
+                          // zero fill — instead of an atomic (0: A/B)
   int autotune = 1;    // 1: jac_coord!/hess_coord! of large grids keep a second code object (lds_slots = 48) and pick, per output
                        // buffer, the faster of the two from their first twenty calls (runtime only; the generator ignores it)
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)

@@ -176,3 +176,31 @@ def test_gradient_zero_fill_is_fused_when_nothing_accumulates(lane_fused):
     omf = OracleModel(emf.blob)
     xf, _ = cases.eval_point_for("pandemic_20x3", omf)
     np.testing.assert_allclose(emf.grad(xf), omf.grad(xf), rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["quadrotor_100", "hovercraft", "pandemic_300x7", "test_problem_1"])
+def test_stencil_neighbours_are_pulled_not_scattered(name, lane_fused):
+    """jtprod!: a backward-difference row adds into x[i] and into x[i-1], the neighbour lane's entry
+    (/root/reference/src/transform.jl:535-557).  With `pull_scatter` (default) the neighbour computes that addend
+    itself through a shifted clone of the template and the entry leaves through one exclusive store: fewer (the
+    quadrotor: no) float atomics, same values as the scattering form and as the oracle."""
+    import re
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    vc = np.random.default_rng(5).standard_normal(om.ncon)
+    v = np.random.default_rng(6).standard_normal(om.nvar)
+    atomics = {}
+    for ps in (1, 0):
+        with iemlib.options(pull_scatter=ps):
+            em = EmulatedModel(core, blob)
+        seg = "".join(re.findall(r"iem_jtprod_g\d+.*?(?=\nextern|\Z)", em.source, flags=re.S))
+        atomics[ps] = seg.count("iem_grad_atomic(")
+        assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+        assert _rel(em.grad(x), om.grad(x)) <= 1e-14
+        assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
+    assert atomics[1] < atomics[0]
+    if name == "quadrotor_100":
+        assert atomics[1] == 0
