@@ -237,6 +237,8 @@ void iem_free(void *p);
  *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs)
  *   "pull_scatter" 1 (default): grad!/jtprod!/hprod! compute a stencil neighbour's addend (x[i-1] of a difference
  *                  row) on the neighbour's lane — exclusive stores, no zero fill; 0: atomics (A/B runs)
+ *   "lazy_loads"   2 (default): product / scatter kernels with >= "lazy_min_loads" (48) loads emit a load where its value
+ *                  is first used instead of at the head of the kernel (register pressure); 1: only rows of v / y; 0: never
  *   "autotune"     1 (default): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups
  *                  keep a second code object with a 48-slot LDS store batch and choose per output buffer,
  *                  from the first twenty calls into it (HIP events, every call a valid evaluation), which of

@@ -654,6 +654,8 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "flush32") == 0) { o.flush32 = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune") == 0) { o.autotune = (int)value; return IEM_OK; }
   if (std::strcmp(name, "pull_scatter") == 0) { o.pull_scatter = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "lazy_loads") == 0) { o.lazy_loads = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "lazy_min_loads") == 0) { o.lazy_min_loads = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune_min_blocks") == 0) { o.autotune_min_blocks = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }

@@ -1112,6 +1112,12 @@ class KernelBuilder {
     return gs.size() > 1 ? "(" + os.str() + ")" : os.str();
   }
 
+  std::string load_stmt(int i) {
+    const Load &l = loads_[i];
+    std::string arr = l.arr == 0 ? "X" : l.arr == 1 ? "TH" : l.arr == 2 ? "Y" : l.arr == 4 ? "V" : "FA[" + std::to_string(l.slot) + "]";
+    return "const double l" + std::to_string(i) + " = " + guard_or(l.guards) + " ? " + arr + "[i" + std::to_string(l.idxval) + "] : 0.0;\n";
+  }
+
   void emit_val(int id, std::ostringstream &os, std::vector<char> &done, const std::vector<char> &live) {
     if (done[id]) return;
     const VNode &n = v_[id];
@@ -1156,7 +1162,13 @@ class KernelBuilder {
       case VC: os << "  const double " << nm << " = " << hexf(n.imm) << ";\n"; break;
       case VDP: os << "  const double " << nm << " = A.dp[" << n.sub << "];\n"; break;
       case VW: os << "  const double " << nm << " = A.w;\n"; break;
-      case VLD: os << "  const double " << nm << " = l" << n.sub << ";\n"; break;
+      case VLD:
+        if (n.sub < (int)lazy_load_.size() && lazy_load_[n.sub] == 1) {   // first use: the load itself goes here, not into the head
+          lazy_load_[n.sub] = 2;
+          os << "  " << load_stmt(n.sub);
+        }
+        os << "  const double " << nm << " = l" << n.sub << ";\n";
+        break;
       case VGUARD: os << "  const double " << nm << " = g" << n.sub << " ? v" << n.a << " : 0.0;\n"; break;
       case VSEL: {
         const auto &pr = sels_[n.sub];
@@ -1213,6 +1225,13 @@ class KernelBuilder {
   std::string emit(KernelDesc &kd, bool as_body = false) {
     std::ostringstream body;
     std::vector<char> live(v_.size(), 0), done(v_.size(), 0);
+    // Scatter kinds with many loads (the OPF's jtprod!: 36 inputs + 62 rows of v): all loads at the head of the
+    // kernel keep ~200 VGPRs alive from the first instruction.  lazy_loads 1: the rows of v / y are loaded where
+    // the template that uses them starts; 2: every load.
+    lazy_load_.assign(loads_.size(), 0);
+    if (opt_.lazy_loads > 0 && (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD || kind_ == KK_JPROD) && (int)loads_.size() >= opt_.lazy_min_loads)
+      for (size_t i = 0; i < loads_.size(); ++i)
+        if (opt_.lazy_loads >= 2 || loads_[i].arr == 4 || loads_[i].arr == 2) lazy_load_[i] = 1;
     for (auto &o : outs_)
       for (size_t s = 0; s < o.vals.size(); ++s)
         if (o.grad_mode.size() != o.vals.size() || o.grad_mode[s] >= 0) mark_live(o.vals[s], live);   // not the slots merge_scatter folded away
@@ -1483,8 +1502,7 @@ class KernelBuilder {
       bool used = false;
       for (size_t v = 0; v < v_.size(); ++v) if (v_[v].op == VLD && v_[v].sub == (int)i && live[v]) { used = true; break; }
       if (!used) continue;
-      std::string arr = l.arr == 0 ? "X" : l.arr == 1 ? "TH" : l.arr == 2 ? "Y" : l.arr == 4 ? "V" : "FA[" + std::to_string(l.slot) + "]";
-      head << "  const double l" << i << " = " << guard_or(l.guards) << " ? " << arr << "[i" << l.idxval << "] : 0.0;\n";
+      if (!(i < lazy_load_.size() && lazy_load_[i])) head << "  " << load_stmt((int)i);
       alg_r_loads_++;
       // algorithmic read footprint: index range of this load over the launch domain
       const IdxVal &iv = idx_[l.idxval];
@@ -1645,6 +1663,7 @@ class KernelBuilder {
   std::map<int, int> fa_ids_, ia_ids_;
   std::vector<int> fav_, iav_;
   int64_t alg_w_ = 0, alg_r_loads_ = 0;
+  std::vector<char> lazy_load_;   // per load: 0 in the head, 1 at first use (not yet emitted), 2 emitted
   std::vector<std::pair<int64_t, int64_t>> zero_fill_;  // [lo, hi) ranges of OUT this kernel zeroes itself
   SharedInfo shared_;
   std::map<int, std::vector<std::pair<int64_t, int64_t>>> ranges_;

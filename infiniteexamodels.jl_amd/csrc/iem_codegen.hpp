@@ -57,6 +57,8 @@ struct Options {
   int pull_scatter = 1;   // 1: scatter kinds (grad!/jtprod!/hprod!): an addend that lands on a neighbour lane's entry (x[i-1] of a
                           // difference row) is computed by that lane through a shifted clone of the template — exclusive stores, no
                           // zero fill — instead of an atomic (0: A/B)
+  int lazy_loads = 2;     // product and scatter kinds with >= lazy_min_loads loads: 1 load the rows of v / y where first used, 2 every load (0: all loads at the head)
+  int lazy_min_loads = 48;
   int autotune = 1;    // 1: jac_coord!/hess_coord! of large grids keep a second code object (lds_slots = 48) and pick, per output
                        // buffer, the faster of the two from their first twenty calls (runtime only; the generator ignores it)
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)

@@ -204,3 +204,22 @@ def test_stencil_neighbours_are_pulled_not_scattered(name, lane_fused):
     assert atomics[1] < atomics[0]
     if name == "quadrotor_100":
         assert atomics[1] == 0
+
+
+@pytest.mark.parametrize("name", ["opf_7", "quadrotor_100", "pandemic_20x3", "irregular"])
+@pytest.mark.parametrize("lazy", [0, 1, 2])
+def test_lazy_loads_do_not_change_the_products(name, lazy, lane_fused):
+    """Product / scatter kernels with many loads (the OPF: 84-98) emit a load where the value is first used
+    instead of at the head of the kernel (`lazy_loads`; register pressure, not arithmetic): same results."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    v, vc = np.random.default_rng(5).standard_normal(om.nvar), np.random.default_rng(6).standard_normal(om.ncon)
+    with iemlib.options(lazy_loads=lazy, lazy_min_loads=1):
+        em = EmulatedModel(core, blob)
+    assert _rel(em.grad(x), om.grad(x)) <= 1e-14
+    assert _rel(em.jprod(x, v), om.jprod(x, v)) <= 1e-13
+    assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
