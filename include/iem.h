@@ -237,6 +237,8 @@ void iem_free(void *p);
  *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs)
  *   "pull_scatter" 1 (default): grad!/jtprod!/hprod! compute a stencil neighbour's addend (x[i-1] of a difference
  *                  row) on the neighbour's lane — exclusive stores, no zero fill; 0: atomics (A/B runs)
+ *   "det_axis"     1 (default): grad!/jtprod!/hprod! sums over a non-lane axis (an entry that depends on t only, summed over
+ *                  scenarios) are parked per item and reduced in row order by a follow-up kernel; 0: f64 atomics
  *   "lazy_loads"   2 (default): product / scatter kernels with >= "lazy_min_loads" (48) loads emit a load where its value
  *                  is first used instead of at the head of the kernel (register pressure); 1: only rows of v / y; 0: never
  *   "autotune"     1 (default): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups

@@ -123,7 +123,8 @@ struct iem_model {
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
-  hipFunction_t fn_struct = nullptr, fn_csr = nullptr;
+  hipFunction_t fn_struct = nullptr, fn_csr = nullptr, fn_axis = nullptr;
+  long long *d_axis[iem::KK_COUNT] = {};   // per scatter kind: table of its axis sums (iem_axis_sum_kernel)
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *d_red[iem::KK_COUNT] = {};   // per scatter kind: parked shared-entry values + tickets (iem_shared_*)
   // Second code object of jac_coord!/hess_coord! with a larger LDS staging batch (lds_slots = 48: one 96-KB
@@ -278,6 +279,7 @@ int compile_or_load(iem_model *m) {
   if (rc) return rc;
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_axis, m->mod, "iem_axis_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_allreduce_kernel"));
   return IEM_OK;
@@ -356,6 +358,12 @@ int launch_kind(iem_model *m, int kind, const double *x, const double *y, double
       int rc = launch(m, k, x, y, out, w, v, aux);
       if (rc) return rc;
     }
+  if (!m->prog.axis[kind].empty()) {   // sums over a non-lane axis: the rows the kernels parked -> one write per entry (iem_axis_sum_kernel)
+    int64_t n0 = 1;
+    for (auto &a : m->prog.axis[kind]) n0 = std::max(n0, a.n0);
+    void *args[] = {(void *)&out, (void *)&aux, (void *)&m->d_axis[kind]};
+    HIP_TRY(hipModuleLaunchKernel(m->fn_axis, (unsigned)((n0 + 63) / 64), (unsigned)m->prog.axis[kind].size(), 1, 256, 1, 1, 0, m->stream, args, nullptr));   // 64 lanes x 4 row groups per workgroup
+  }
   return IEM_OK;
 }
 
@@ -654,8 +662,10 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "flush32") == 0) { o.flush32 = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune") == 0) { o.autotune = (int)value; return IEM_OK; }
   if (std::strcmp(name, "pull_scatter") == 0) { o.pull_scatter = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "det_axis") == 0) { o.det_axis = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_loads") == 0) { o.lazy_loads = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_min_loads") == 0) { o.lazy_min_loads = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "lazy_all_kinds") == 0) { o.lazy_all_kinds = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune_min_blocks") == 0) { o.autotune_min_blocks = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
@@ -689,6 +699,10 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     os << "partials " << p.n_partials << "\n";
     for (int kind = 0; kind < iem::KK_COUNT; ++kind)   // shared-entry reduction buffer of a scatter kind: values x workgroups (+ tickets)
       if (p.red_values[kind] > 0) os << "reduce " << kind << " " << p.red_values[kind] << " " << p.red_wgs[kind] << "\n";
+    for (int kind = 0; kind < iem::KK_COUNT; ++kind) {   // whole aux buffer of a scatter kind, and its axis sums {c, k0, n0, rows, off}
+      if (p.aux_doubles[kind] > 0) os << "aux " << kind << " " << p.aux_doubles[kind] << "\n";
+      for (auto &a : p.axis[kind]) os << "axis " << kind << " " << a.c << " " << a.k0 << " " << a.n0 << " " << a.rows << " " << a.off << "\n";
+    }
     for (int kind = 0; kind < iem::KK_COUNT; ++kind)   // ranges the runtime memsets before launching a scatter kind
       for (auto &z : p.zero_ranges[kind]) os << "zero " << kind << " " << z.first << " " << z.second << "\n";
     for (const iem::KernelDesc &kd : p.kernels) {
@@ -812,11 +826,18 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
       return bail(fail(IEM_E_HIP, "hipMalloc partials"));
   }
   for (int kind = 0; kind < iem::KK_COUNT; ++kind) {
-    if (m->prog.red_values[kind] <= 0) continue;
-    const size_t nwg = (size_t)m->prog.red_wgs[kind];
-    const size_t words = (size_t)m->prog.red_values[kind] * nwg + 1 + (nwg + 31) / 32;
+    // aux buffer of a scatter kind: shared-entry values x workgroups + ticket words (zeroed once), then the rows of its axis sums
+    const size_t words = (size_t)m->prog.aux_doubles[kind];
+    if (words == 0) continue;
     if (hipMalloc((void **)&m->d_red[kind], words * 8) != hipSuccess || hipMemset(m->d_red[kind], 0, words * 8) != hipSuccess)
-      return bail(fail(IEM_E_HIP, "hipMalloc shared-entry reduction buffer"));
+      return bail(fail(IEM_E_HIP, "hipMalloc reduction buffer"));
+    if (!m->prog.axis[kind].empty()) {
+      std::vector<long long> tab;
+      for (auto &a : m->prog.axis[kind]) { tab.push_back(a.c); tab.push_back(a.k0); tab.push_back(a.n0); tab.push_back(a.rows); tab.push_back(a.off); }
+      if (hipMalloc((void **)&m->d_axis[kind], tab.size() * 8) != hipSuccess ||
+          hipMemcpy(m->d_axis[kind], tab.data(), tab.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(IEM_E_HIP, "hipMalloc axis-sum table"));
+    }
   }
   if (hipMalloc((void **)&m->d_obj, 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc obj"));
   if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocMapped) != hipSuccess ||
@@ -864,6 +885,7 @@ int iem_destroy(iem_model *m) {
   if (m->d_partials) hipFree(m->d_partials);
   if (m->d_obj) hipFree(m->d_obj);
   for (double *r : m->d_red) if (r) hipFree(r);
+  for (long long *r : m->d_axis) if (r) hipFree(r);
   for (void *p : m->ipc_opened) hipIpcCloseMemHandle(p);
   if (m->mailbox) hipFree(m->mailbox);
   if (m->d_peers) hipFree(m->d_peers);

@@ -138,7 +138,8 @@ struct Output {
   int64_t pos_off = 0;   // ... = pos_off + (values per item) * (item ordinal)
   std::vector<int> vals;      // DAG ids
   std::vector<int> grad_idx;  // KK_GRAD: IdxVal ids (0-based) per value
-  std::vector<int> grad_mode; // 0 exclusive store, 1 wave-uniform, 2 atomic
+  std::vector<int> grad_mode; // 0 exclusive store, 1 wave-uniform, 2 atomic, 3 shared entry (parked), 4 axis sum (parked rows), -1 folded
+  std::map<int, int64_t> axis_off;   // slot -> offset (doubles) of its rows in the kind's aux buffer (mode 4)
   std::vector<int> slot_ia, slot_ib;  // KK_HESS: 1-based IdxVal ids of each slot's pair
   std::vector<int> slot_ti, slot_tj;  // ... and the template-local index-expression ids
   bool scalar = false;
@@ -1229,7 +1230,7 @@ class KernelBuilder {
     // kernel keep ~200 VGPRs alive from the first instruction.  lazy_loads 1: the rows of v / y are loaded where
     // the template that uses them starts; 2: every load.
     lazy_load_.assign(loads_.size(), 0);
-    if (opt_.lazy_loads > 0 && (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD || kind_ == KK_JPROD) && (int)loads_.size() >= opt_.lazy_min_loads)
+    if (opt_.lazy_loads > 0 && (opt_.lazy_all_kinds || kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD || kind_ == KK_JPROD) && (int)loads_.size() >= opt_.lazy_min_loads)
       for (size_t i = 0; i < loads_.size(); ++i)
         if (opt_.lazy_loads >= 2 || loads_[i].arr == 4 || loads_[i].arr == 2) lazy_load_[i] = 1;
     for (auto &o : outs_)
@@ -1418,6 +1419,12 @@ class KernelBuilder {
             int mode = o.grad_mode[s];
             if (mode == 3 || mode < 0) continue;   // parked below (deterministic shared-entry reduction) / folded into another slot
             if (mode == 0) tail << "  if (" << g << ") OUT[i" << o.grad_idx[s] << "] = v" << o.vals[s] << ";\n";
+            else if (mode == 4) {
+              // row = position in dims 1, 2 of this output's box, lane = position in dim 0
+              const int64_t n0 = o.qhi[0] - o.qlo[0], n1 = o.qhi[1] - o.qlo[1];
+              tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + ((q1 - " << coefstr(o.qlo[1]) << ") + " << ip(n1, 6) << " * (q2 - "
+                   << coefstr(o.qlo[2]) << ")) * " << ip(n0, 6) << " + (q0 - " << coefstr(o.qlo[0]) << ")] = v" << o.vals[s] << ";\n";
+            }
             else if (mode == 1) tail << "  iem_grad_wave_uniform(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
             else tail << "  iem_grad_atomic(OUT, i" << o.grad_idx[s] << ", v" << o.vals[s] << ", " << g << ");\n";
           }
@@ -1872,7 +1879,8 @@ Program generate(const Model &m, const Options &opt_in) {
   static const char *kname[] = {"cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod"};
 
   // gradient slot classification needs a global view of every objective slot's index range
-  struct GSlot { int kind; int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; int64_t count = 0; };
+  struct GSlot { int kind; int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; int64_t count = 0;
+                 int64_t box_lo[3] = {0, 0, 0}, box_n[3] = {1, 1, 1}; bool axis_ok = false; };
   std::vector<GSlot> gslots;
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
@@ -1925,6 +1933,10 @@ Program generate(const Model &m, const Options &opt_in) {
               }
               gs.lo = lo; gs.hi = hi; gs.injective = inj;
               gs.count = box_items;
+              for (int d = 0; d < 3; ++d) { gs.box_lo[d] = scalar ? 0 : outs[oi].qlo[d]; gs.box_n[d] = box_n[d]; }
+              // a sum over the non-lane axes: the entry depends on the lane only, and every row of dims 1, 2 adds into it
+              gs.axis_ok = !g.flat && !scalar && iv.aff.k[0] != 0 && iv.aff.k[1] == 0 && iv.aff.k[2] == 0 && box_n[1] * box_n[2] > 1 &&
+                           box_n[1] * box_n[2] <= (1LL << 20);
               // wave-uniform destination: every lane of a wave shares q1/q2 — not true for flat groups
               gs.uniform0 = !g.flat && !scalar && iv.aff.k[0] == 0 && box_n[0] > 1;
             } else {
@@ -1967,14 +1979,24 @@ Program generate(const Model &m, const Options &opt_in) {
     GSlot &a = gslots[i];
     if (shared_dest[i]) { builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = 3; continue; }
     int mode = 2;
-    if (a.pure && a.injective) {
-      bool clash = false;
+    bool clash = false;
+    if (a.pure)
       for (size_t j = 0; j < gslots.size() && !clash; ++j) {
         if (i == j) continue;
         const GSlot &b = gslots[j];
         if (b.kind != a.kind) continue;   // different output vectors
         if (!(b.hi < a.lo || b.lo > a.hi)) clash = true;
       }
+    if (a.pure && !a.injective && a.axis_ok && !clash && opt.det_axis) {
+      // nobody else reaches these entries: park the rows, iem_axis_sum_kernel writes each entry once (offsets assigned below)
+      mode = 4;
+      const int64_t k0 = a.aff.k[0];
+      P.axis[a.kind].push_back(Program::AxisSum{a.aff.c + k0 * a.box_lo[0], k0, a.box_n[0], a.box_n[1] * a.box_n[2], -(int64_t)i - 1});
+      if ((k0 == 1 || k0 == -1) && a.hi - a.lo + 1 == a.box_n[0]) P.covered[a.kind].emplace_back(a.lo, a.hi);
+      builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = 4;
+      continue;
+    }
+    if (a.pure && a.injective) {
       if (!clash) mode = 0;
       // a slot whose items tile its index range without gaps fully overwrites that range:
       // iem_grad need not zero it first
@@ -2050,6 +2072,17 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     P.red_values[kind] = si.nv_total;
     P.red_wgs[kind] = si.n_wg;
+  }
+  // aux buffer of a scatter kind: the shared-entry part (values x workgroups, ticket words), then the parked rows of its axis sums
+  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
+    int64_t base = P.red_values[kind] > 0 ? P.red_values[kind] * P.red_wgs[kind] + 1 + (P.red_wgs[kind] + 31) / 32 : 0;
+    for (auto &ax : P.axis[kind]) {
+      const GSlot &a = gslots[(size_t)(-ax.off - 1)];
+      ax.off = base;
+      builders[a.kernel]->outputs()[a.out].axis_off[a.slot] = base;
+      base += ax.n0 * ax.rows;
+    }
+    P.aux_doubles[kind] = base;
   }
   // One launch per NLPModels call: when the templates of a call live on several support grids
   // (pandemic: t x xi and t; collocation: the node grids), the per-grid bodies become

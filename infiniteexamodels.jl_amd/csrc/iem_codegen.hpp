@@ -57,8 +57,10 @@ struct Options {
   int pull_scatter = 1;   // 1: scatter kinds (grad!/jtprod!/hprod!): an addend that lands on a neighbour lane's entry (x[i-1] of a
                           // difference row) is computed by that lane through a shifted clone of the template — exclusive stores, no
                           // zero fill — instead of an atomic (0: A/B)
+  int det_axis = 1;       // 1: sums over a non-lane axis are reduced in a fixed order by a follow-up kernel (Program::axis); 0: atomics
   int lazy_loads = 2;     // product and scatter kinds with >= lazy_min_loads loads: 1 load the rows of v / y where first used, 2 every load (0: all loads at the head)
   int lazy_min_loads = 48;
+  int lazy_all_kinds = 0;   // experiment: also cons!/jac_coord!/hess_coord!/obj
   int autotune = 1;    // 1: jac_coord!/hess_coord! of large grids keep a second code object (lds_slots = 48) and pick, per output
                        // buffer, the faster of the two from their first twenty calls (runtime only; the generator ignores it)
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)
@@ -90,6 +92,13 @@ struct Program {
   // values are parked per workgroup of the call (`red_wgs` of them) in a buffer of red_values*red_wgs
   // doubles + ticket words (zeroed once), passed as the kind's `aux` argument
   int64_t red_values[KK_COUNT] = {}, red_wgs[KK_COUNT] = {};
+  // Sums over a NON-LANE axis of a scatter kind (pandemic: column u(t) of jtprod! gets one addend per scenario):
+  // the kernel parks each lane's addend at aux[off + row*n0 + lane] (row = position in dims 1, 2 of the template's
+  // box) and iem_axis_sum_kernel, launched behind the kind's kernels, writes out[c + k0*lane] = sum over the rows in
+  // row order — deterministic, no atomics.  `off` counts doubles from the start of the kind's aux buffer.
+  struct AxisSum { int64_t c, k0, n0, rows, off; };
+  std::vector<AxisSum> axis[KK_COUNT];
+  int64_t aux_doubles[KK_COUNT] = {};   // whole aux buffer of the kind: shared-entry part (values*wgs + ticket words), then the axis rows
 };
 
 Program generate(const Model &m, const Options &opt);

@@ -531,6 +531,33 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum(const
   csr[i] = acc;
 }
 
+// ---- sums over a non-lane axis of a scatter kind (Program::AxisSum) ----------------------------------
+// The kind's kernels parked one addend per item at aux[off + row*n0 + lane]; entry e (blockIdx.y) writes
+// out[c + k0*lane] = the sum of the lane's column.  A workgroup takes 64 lanes x 4 row groups: thread (l, g) adds
+// the rows g, g+4, g+8, ... of lane l into four interleaved accumulators (sixteen coalesced loads in flight per
+// lane instead of one dependent chain), the groups meet in LDS — a FIXED association of the addends, so the sum is
+// bitwise reproducible; no atomics.  tab: 5 words per entry {c, k0, n0, rows, off}.
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_axis_sum_kernel(double *__restrict__ out, const double *__restrict__ aux,
+                                                                           const long long *__restrict__ tab) {
+  __shared__ double part_[IEM_BLOCK];
+  const long long *__restrict__ t = tab + 5 * (long long)blockIdx.y;
+  const int l = (int)threadIdx.x & 63, g = (int)threadIdx.x >> 6;
+  const long long lane = (long long)blockIdx.x * 64 + l;
+  const long long n0 = t[2], rows = t[3];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (lane < n0) {
+    const double *__restrict__ col = aux + t[4] + lane;
+    long long r = g;
+    for (; r + 12 < rows; r += 16) {
+      a0 += col[r * n0]; a1 += col[(r + 4) * n0]; a2 += col[(r + 8) * n0]; a3 += col[(r + 12) * n0];
+    }
+    for (; r < rows; r += 4) a0 += col[r * n0];
+  }
+  part_[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && lane < n0) out[t[0] + t[1] * lane] = (part_[l] + part_[64 + l]) + (part_[128 + l] + part_[192 + l]);
+}
+
 // ---- multi-GPU: halo exchange and the one small all-reduce of the path --------------------------
 // One process per GPU; every rank owns a MAILBOX in its HBM that its peers map through HIP IPC
 // (iem_comm_export / iem_comm_connect).  Both kernels PUSH: a rank writes its few doubles straight

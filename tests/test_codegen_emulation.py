@@ -223,3 +223,30 @@ def test_lazy_loads_do_not_change_the_products(name, lazy, lane_fused):
     assert _rel(em.jprod(x, v), om.jprod(x, v)) <= 1e-13
     assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
     assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
+
+
+def test_axis_sums_are_parked_and_summed_in_row_order(lane_fused):
+    """pandemic: u(t) enters every scenario's path rows, so column u(t) of J'v (and of Hv) is a sum over the NON-lane
+    axis xi.  With `det_axis` (default) the kernel parks one addend per (t, xi) and the plan lists an axis sum
+    {c, k0, n0, rows, off} that the runtime's follow-up kernel reduces in row order — no float atomics on that
+    column; with det_axis = 0 it is an atomic add.  Both agree with the oracle."""
+    import re
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core("pandemic_300x7")
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for("pandemic_300x7", om)
+    vc = np.random.default_rng(5).standard_normal(om.ncon)
+    v = np.random.default_rng(6).standard_normal(om.nvar)
+    n_axis = {}
+    for da in (1, 0):
+        with iemlib.options(det_axis=da):
+            em = EmulatedModel(core, blob)
+            plan = iemlib.emit_launch_plan(blob)
+        n_axis[da] = [tuple(int(w) for w in ln.split()[1:]) for ln in plan.splitlines() if ln.startswith("axis ")]
+        assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+        assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
+        assert _rel(em.grad(x), om.grad(x)) <= 1e-14
+    assert not n_axis[0] and len(n_axis[1]) == 2
+    for kind, c, k0, n0, rows, off in n_axis[1]:
+        assert n0 == 310 and rows == 7 and k0 == 1          # 300 + 10 time supports, 7 scenarios
