@@ -665,6 +665,7 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "det_axis") == 0) { o.det_axis = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_loads") == 0) { o.lazy_loads = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_min_loads") == 0) { o.lazy_min_loads = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "name_tag") == 0) { o.name_tag = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_all_kinds") == 0) { o.lazy_all_kinds = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune_min_blocks") == 0) { o.autotune_min_blocks = (int)value; return IEM_OK; }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
@@ -852,6 +853,7 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
     if (big >= m->opt.autotune_min_blocks) {
       iem::Options ob = m->opt;
       ob.lds_slots = 48;
+      ob.name_tag = 48;
       try {
         m->alt.prog = iem::generate(m->model, ob);
       } catch (const std::exception &e) {

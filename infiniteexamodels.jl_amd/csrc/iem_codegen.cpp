@@ -1886,6 +1886,9 @@ Program generate(const Model &m, const Options &opt_in) {
   std::vector<KernelDesc> descs;
 
   auto is_scatter = [](int kind) { return kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD; };
+  // a handle's second code object (the tuner's large store batch) carries a tag in its kernel names, so that a
+  // profile of a run that used both tells them apart
+  const std::string name_tag = opt.name_tag > 0 ? "_b" + std::to_string(opt.name_tag) : std::string();
   for (int pass = 0; pass < (split ? 2 : 1); ++pass)
   for (size_t gi = 0; gi < (pass ? groups_fused.size() : groups.size()); ++gi) {
     const Group &g = pass ? groups_fused[gi] : groups[gi];
@@ -1893,7 +1896,7 @@ Program generate(const Model &m, const Options &opt_in) {
       throw std::runtime_error("support grid too large in dims 2/3 (limit 65535 per dimension for 3-D grids)");
     for (int kind = 0; kind < KK_COUNT; ++kind) {
       if (split && is_scatter(kind) != (pass == 1)) continue;   // pass 1: the scatter kinds on the fused groups
-      std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi);
+      std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi) + name_tag;
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
       if (!kb->build(nullptr)) continue;
       if (kind == KK_HESS && opt.hess_merge) kb->merge_hess(P.nnzh_merged, P.hess_classes);
@@ -2101,7 +2104,7 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     std::stable_sort(ks.begin(), ks.end(), [&](size_t a, size_t b) { return descs[a].n_blocks > descs[b].n_blocks; });
     KernelDesc F;
-    F.name = std::string("iem_") + kname[kind] + "_all";
+    F.name = std::string("iem_") + kname[kind] + "_all" + name_tag;
     F.kind = kind; F.block = opt.block;
     F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
     std::vector<size_t> oip, odp, ofa, oia;   // table offsets of each body

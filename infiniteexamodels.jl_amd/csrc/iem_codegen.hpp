@@ -60,6 +60,7 @@ struct Options {
   int det_axis = 1;       // 1: sums over a non-lane axis are reduced in a fixed order by a follow-up kernel (Program::axis); 0: atomics
   int lazy_loads = 2;     // product and scatter kinds with >= lazy_min_loads loads: 1 load the rows of v / y where first used, 2 every load (0: all loads at the head)
   int lazy_min_loads = 48;
+  int name_tag = 0;         // > 0: kernel names end in _b<tag> (set by the runtime for a handle's second code object)
   int lazy_all_kinds = 0;   // experiment: also cons!/jac_coord!/hess_coord!/obj
   int autotune = 1;    // 1: jac_coord!/hess_coord! of large grids keep a second code object (lds_slots = 48) and pick, per output
                        // buffer, the faster of the two from their first twenty calls (runtime only; the generator ignores it)
