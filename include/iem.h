@@ -148,6 +148,13 @@ int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int wor
 int iem_comm_export(iem_model *m, void *out_handle /* IEM_COMM_HANDLE_BYTES */);
 int iem_comm_connect(iem_model *m, const void *all_handles /* world x IEM_COMM_HANDLE_BYTES, rank order */);
 int iem_halo_exchange(iem_model *m, double *d_x);
+/* The transposed exchange, for a vector in VARIABLE space produced by a transposed operator on this rank's rows
+ * (iem_jtprod): the entries of the halo copies hold what this rank's rows owe to variables the LEFT neighbour owns
+ * (the x_k[a_r - 1] column of the first difference row, src/transform.jl:535-557).  They are sent to the left
+ * neighbour, which ADDS them to its owned entries (one addend per entry: order-independent), and zeroed here.
+ * Entries of replicated variables are summed with iem_allreduce_obj_grad (d_obj may be NULL).  Asynchronous on the
+ * handle's stream, graph-capturable, bounded waits like iem_halo_exchange. */
+int iem_halo_fold(iem_model *m, double *d_vec);
 int iem_allreduce_obj_grad(iem_model *m, double *d_obj /* device scalar, may be NULL */, double *d_g);
 /* synchronises the handle's stream; 0 = every exchange so far completed, else a bit mask of time-outs */
 int iem_comm_status(iem_model *m, int64_t *out_status);

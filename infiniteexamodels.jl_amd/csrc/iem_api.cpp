@@ -154,7 +154,7 @@ struct iem_model {
   // multi-GPU (iem_create_sharded): what was cut, and the mailbox the peers push into
   bool sharded = false;
   iem::ShardInfo shard;
-  hipFunction_t fn_halo = nullptr, fn_reduce = nullptr;
+  hipFunction_t fn_halo = nullptr, fn_reduce = nullptr, fn_fold = nullptr;
   unsigned long long *mailbox = nullptr;   // device memory, exported through HIP IPC
   size_t mailbox_words = 0;
   int mailbox_kind = 0;   // 0 none yet, 1 uncached (fine-grained) device memory, 2 plain hipMalloc
@@ -281,6 +281,7 @@ int compile_or_load(iem_model *m) {
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
   HIP_TRY(hipModuleGetFunction(&m->fn_axis, m->mod, "iem_axis_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_fold, m->mod, "iem_halo_fold_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_allreduce_kernel"));
   return IEM_OK;
 }
@@ -1159,7 +1160,7 @@ std::vector<int64_t> shard_items(const iem::ShardInfo &si) {
 int64_t reduce_chunks(int64_t NR) { return std::min<int64_t>(64, std::max<int64_t>(1, (NR + 1023) / 1024)); }
 size_t mailbox_words(int64_t W, int64_t NH, int64_t NR) {
   const int64_t G = reduce_chunks(NR);
-  return (size_t)(8 + G + 2 * W * G + 2 * NH + 2 * W * NR);
+  return (size_t)(12 + G + 2 * W * G + 2 * NH + 2 * W * NR + 2 * NH);   // header, reduce flags, halo data, reduce data, fold data
 }
 
 struct CommHandle {   // what iem_comm_export writes (IEM_COMM_HANDLE_BYTES)
@@ -1368,6 +1369,22 @@ int iem_halo_exchange(iem_model *m, double *d_x) {
   size_t sz = sizeof A;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
+  return IEM_OK;
+}
+
+int iem_halo_fold(iem_model *m, double *d_vec) {
+  if (!m || !d_vec) return fail(IEM_E_ARG, "null argument");
+  if (!m->connected) return fail(IEM_E_ARG, "iem_halo_fold: not connected (iem_comm_connect)");
+  const iem::ShardInfo &si = m->shard;
+  if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;
+  DevGuard dg_(m->device);
+  struct { double *vec; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G, NR; } A = {
+      d_vec, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
+      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared),
+      (long long)(1 + m->n_shared)};
+  size_t sz = sizeof A;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_fold, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
   return IEM_OK;
 }
 

@@ -579,10 +579,14 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_axis_sum_kernel(doub
 #define IEM_MB_HSEQ 1
 #define IEM_MB_HACK 3
 #define IEM_MB_HFLAG 4
-#define IEM_MB_RSEQ 8
+#define IEM_MB_FSEQ 8     // halo FOLD (the transposed exchange: halo copies -> the left neighbour's owned entries)
+#define IEM_MB_FACK 9
+#define IEM_MB_FFLAG 10   // two parities
+#define IEM_MB_RSEQ 12
 __device__ __forceinline__ long long iem_mb_rflag(long long G) { return IEM_MB_RSEQ + G; }
 __device__ __forceinline__ long long iem_mb_hdata(long long W, long long G) { return IEM_MB_RSEQ + G + 2 * W * G; }
 __device__ __forceinline__ long long iem_mb_rdata(long long W, long long G, long long NH) { return iem_mb_hdata(W, G) + 2 * NH; }
+__device__ __forceinline__ long long iem_mb_fdata(long long W, long long G, long long NH, long long NR) { return iem_mb_rdata(W, G, NH) + 2 * W * NR; }
 __device__ __forceinline__ unsigned long long iem_sys_load(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -651,6 +655,50 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const Ie
   }
   __syncthreads();
   if (threadIdx.x == 0) iem_sys_store(A.mine + IEM_MB_HSEQ, seq);
+}
+
+// The transposed exchange, for vectors in VARIABLE space that a transposed operator produced (J'v): the entries of
+// my halo copies hold what my rows owe to the variables the LEFT neighbour owns.  (1) they go into the left
+// neighbour's mailbox and are zeroed here, (2) what the right neighbour sent is ADDED to my owned entries — one
+// addend per entry, so the result does not depend on arrival order.  Same flags / parity / bounded-wait scheme as
+// iem_halo_kernel, words of its own (IEM_MB_F*).
+struct IemFoldArgs {
+  double *vec;
+  unsigned long long *mine, *left, *right;
+  const long long *src, *dst;                // as in IemHaloArgs: src = my owned rows the right neighbour copies, dst = my halo copies
+  long long NH, W, G, NR;
+};
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_fold_kernel(const IemFoldArgs A) {
+  const unsigned long long seq = iem_sys_load(A.mine + IEM_MB_FSEQ) + 1;
+  const long long par = (long long)(seq & 1);
+  __shared__ int ok_;
+  if (A.left != nullptr) {
+    if (threadIdx.x == 0)
+      ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_FACK, seq - 2, A.mine + IEM_MB_STATUS, 8ULL);
+    __syncthreads();
+    double *data = reinterpret_cast<double *>(A.left + iem_mb_fdata(A.W, A.G, A.NH, A.NR)) + par * A.NH;
+    for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) {
+      iem_sys_stored(data + e, A.vec[A.dst[e]]);
+      A.vec[A.dst[e]] = 0.0;
+    }
+    iem_publish_fence();
+    if (threadIdx.x == 0) iem_sys_store(A.left + IEM_MB_FFLAG + par, seq);
+  }
+  if (A.right != nullptr) {
+    if (threadIdx.x == 0) {
+      ok_ = iem_wait_ge(A.mine + IEM_MB_FFLAG + par, seq, A.mine + IEM_MB_STATUS, 16ULL);
+      __threadfence_system();
+    }
+    __syncthreads();
+    const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_fdata(A.W, A.G, A.NH, A.NR)) + par * A.NH;
+    if (ok_)
+      for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.vec[A.src[e]] += iem_sys_loadd(data + e);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) iem_sys_store(A.right + IEM_MB_FACK, seq);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) iem_sys_store(A.mine + IEM_MB_FSEQ, seq);
 }
 
 struct IemReduceArgs {

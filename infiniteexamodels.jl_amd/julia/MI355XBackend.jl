@@ -151,6 +151,10 @@ end
 # before cons!/jac_coord!/hess_coord!: the stencil neighbours x_k[a_r - 1] from the left rank (transform.jl:535-557)
 halo_exchange!(m::MI355XModel, x::ROCVector{Float64}) =
     (check(ccall((:iem_halo_exchange, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.handle, dptr(x))); x)
+# after jtprod! on this rank's rows: the transposed exchange (halo-copy entries -> the left rank's owned entries), then
+# allreduce_obj_grad! for the entries of replicated variables
+halo_fold!(m::MI355XModel, v::ROCVector{Float64}) =
+    (check(ccall((:iem_halo_fold, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.handle, dptr(v))); v)
 # after obj (device scalar f) / grad!: objective + gradient entries of replicated variables, summed over the ranks
 allreduce_obj_grad!(m::MI355XModel, f::ROCVector{Float64}, g::ROCVector{Float64}) =
     (check(ccall((:iem_allreduce_obj_grad, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), m.handle, dptr(f), dptr(g))); (f, g))

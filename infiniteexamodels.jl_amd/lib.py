@@ -76,7 +76,7 @@ class KernelInfo(C.Structure):
 
 # every symbol include/iem.h declares (tests check the export list against the header)
 SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_info", "iem_shard_var_map", "iem_shard_template_info",
-           "iem_shard_template_items", "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_allreduce_obj_grad", "iem_comm_status",
+           "iem_shard_template_items", "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_halo_fold", "iem_allreduce_obj_grad", "iem_comm_status",
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
@@ -126,6 +126,7 @@ def lib():
     L.iem_comm_export.argtypes = [vp, vp]
     L.iem_comm_connect.argtypes = [vp, vp]
     L.iem_halo_exchange.argtypes = [vp, vp]
+    L.iem_halo_fold.argtypes = [vp, vp]
     L.iem_allreduce_obj_grad.argtypes = [vp, vp, vp]
     L.iem_comm_status.argtypes = [vp, C.POINTER(C.c_int64)]
     L.iem_destroy.argtypes = [vp]

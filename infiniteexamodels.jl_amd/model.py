@@ -336,6 +336,14 @@ class ExaModel:
         _lib.check(self._L.iem_halo_exchange(self._h, _ptr(x)))
         return x
 
+    def halo_fold(self, vec):
+        """Transposed halo exchange for a variable-space vector (``jtprod`` of this rank's rows): halo-copy
+        entries are added to the left neighbour's owned entries and zeroed here; asynchronous."""
+        self._chk(vec, self.meta.nvar, "vec")
+        self._sync_stream()
+        _lib.check(self._L.iem_halo_fold(self._h, _ptr(vec)))
+        return vec
+
     def allreduce_obj_grad(self, obj_dev, g):
         """Sum the device scalar ``obj_dev`` and the replicated entries of ``g`` over the ranks, in place."""
         if g is not None:

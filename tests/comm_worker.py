@@ -61,6 +61,7 @@ def main():
     hv = torch.empty(gm.meta.nnzh, dtype=torch.float64, device="cuda")
     fpre = torch.zeros(1, dtype=torch.float64, device="cuda")
     gpre = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    jt = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
 
     def loop():
         gm.halo_exchange(xd)
@@ -68,6 +69,11 @@ def main():
         gm.obj_device(xd, f); gm.grad(xd, g)
         fpre.copy_(f); gpre.copy_(g)
         gm.allreduce_obj_grad(f, g)
+        # J'v with v = y: each rank's rows, then the transposed halo exchange (what my first difference row owes to
+        # x_k[a_r - 1] goes to the left neighbour) and the sum over the ranks of the replicated variables' entries
+        gm.jtprod(xd, yd, jt)
+        gm.halo_fold(jt)
+        gm.allreduce_obj_grad(None, jt)
 
     graph = None
     for it in range(5):
@@ -79,7 +85,7 @@ def main():
         xl = xg[vm].copy()
         xl[halo] = np.nan                                  # this rank does NOT hold its neighbour's values
         xd.copy_(torch.tensor(xl)); yd.copy_(torch.tensor(yg[row_map]))
-        for out in (c, jv, hv, g):
+        for out in (c, jv, hv, g, jt):
             out.fill_(float("nan"))
         if use_graph and it >= 2:
             if graph is None:                              # iterations 0, 1 ran eagerly (warm-up); capture once, replay after
@@ -94,6 +100,7 @@ def main():
         assert np.array_equal(xd.cpu().numpy(), xg[vm]), "halo entries did not arrive"
         res = dict(c=c.cpu().numpy(), j=jv.cpu().numpy(), h=hv.cpu().numpy(), fpre=fpre.item(), fpost=f.item(),
                    gpre=gpre.cpu().numpy()[repl], gpost=g.cpu().numpy()[repl], gown=g.cpu().numpy()[owned & ~repl],
+                   jtown=jt.cpu().numpy()[owned & ~repl], jtrepl=jt.cpu().numpy()[repl], jthalo=jt.cpu().numpy()[halo],
                    own_idx=vm[owned & ~repl], repl_idx=vm[repl], row_map=row_map, jpos=jpos, hpos=hpos)
         allres = [None] * world if rank == 0 else None
         dist.gather_object(res, allres, dst=0)
@@ -101,6 +108,10 @@ def main():
             xgd, ygd = torch.tensor(xg, device="cuda"), torch.tensor(yg, device="cuda")
             cg, jg, hg = (np.full(n, np.nan) for n in (G.meta.ncon, G.meta.nnzj, G.meta.nnzh))
             gg = np.full(nvg, np.nan)
+            jtg = np.full(nvg, np.nan)
+            for r in allres:
+                jtg[r["own_idx"]] = r["jtown"]; jtg[r["repl_idx"]] = r["jtrepl"]
+                assert not r["jthalo"].size or not np.any(r["jthalo"]), "halo copies are zeroed by the fold"
             for r in allres:
                 cg[r["row_map"]] = r["c"]; jg[r["jpos"]] = r["j"]; hg[r["hpos"]] = r["h"]
                 gg[r["own_idx"]] = r["gown"]
@@ -110,7 +121,7 @@ def main():
             assert np.array_equal(jg, G.jac_coord(xgd).cpu().numpy()), "jac"
             assert np.array_equal(hg, G.hess_coord(xgd, ygd, obj_weight=0.7).cpu().numpy()), "hess"
             # ... and agree with the oracle on the GLOBAL model
-            for got, ref, what in ((cg, O.cons(xg), "cons"), (jg, O.jac_coord(xg), "jac"), (hg, O.hess_coord(xg, yg, 0.7), "hess"), (gg, O.grad(xg), "grad")):
+            for got, ref, what in ((cg, O.cons(xg), "cons"), (jg, O.jac_coord(xg), "jac"), (hg, O.hess_coord(xg, yg, 0.7), "hess"), (gg, O.grad(xg), "grad"), (jtg, O.jtprod(xg, yg), "jtprod")):
                 scale = np.maximum(np.abs(ref), 1e-10 * max(1.0, np.abs(ref).max() if ref.size else 1.0))
                 assert ref.size == 0 or (np.abs(got - ref) / scale).max() <= 1e-10, what
             # all-reduce: rank-order sums, identical bits on every rank
