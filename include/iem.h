@@ -244,6 +244,10 @@ void iem_free(void *p);
  *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs)
  *   "pull_scatter" 1 (default): grad!/jtprod!/hprod! compute a stencil neighbour's addend (x[i-1] of a difference
  *                  row) on the neighbour's lane — exclusive stores, no zero fill; 0: atomics (A/B runs)
+ *   "det_scatter"  1 (default): scatter addends that would still be float atomics AND can meet more than one other addend in
+ *                  their entry (collocation stencils, gathered indices) are parked per item and summed per entry in the
+ *                  order of a plan built at create time (12 bytes of plan + 8 of scratch per addend, at most
+ *                  "det_scatter_max" = 2^28 addends per kind); 2: every remaining atomic; 0: f64 atomics
  *   "det_axis"     1 (default): grad!/jtprod!/hprod! sums over a non-lane axis (an entry that depends on t only, summed over
  *                  scenarios) are parked per item and reduced in row order by a follow-up kernel; 0: f64 atomics
  *   "lazy_loads"   2 (default): product / scatter kernels with >= "lazy_min_loads" (48) loads emit a load where its value

@@ -124,7 +124,9 @@ struct iem_model {
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
   hipFunction_t fn_struct = nullptr, fn_csr = nullptr, fn_axis = nullptr;
-  long long *d_axis[iem::KK_COUNT] = {};   // per scatter kind: table of its axis sums (iem_axis_sum_kernel)
+  long long *d_axis[iem::KK_COUNT] = {};
+  long long *d_gather[iem::KK_COUNT] = {};   // per scatter kind: dest | seg | perm of its plan-driven gather (iem_gather_sum_kernel)
+  hipFunction_t fn_gather = nullptr;   // per scatter kind: table of its axis sums (iem_axis_sum_kernel)
   double *d_theta = nullptr, *d_partials = nullptr, *d_obj = nullptr;
   double *d_red[iem::KK_COUNT] = {};   // per scatter kind: parked shared-entry values + tickets (iem_shared_*)
   // Second code object of jac_coord!/hess_coord! with a larger LDS staging batch (lds_slots = 48: one 96-KB
@@ -280,6 +282,7 @@ int compile_or_load(iem_model *m) {
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
   HIP_TRY(hipModuleGetFunction(&m->fn_axis, m->mod, "iem_axis_sum_kernel"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_gather, m->mod, "iem_gather_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_fold, m->mod, "iem_halo_fold_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_reduce, m->mod, "iem_allreduce_kernel"));
@@ -364,6 +367,16 @@ int launch_kind(iem_model *m, int kind, const double *x, const double *y, double
     for (auto &a : m->prog.axis[kind]) n0 = std::max(n0, a.n0);
     void *args[] = {(void *)&out, (void *)&aux, (void *)&m->d_axis[kind]};
     HIP_TRY(hipModuleLaunchKernel(m->fn_axis, (unsigned)((n0 + 63) / 64), (unsigned)m->prog.axis[kind].size(), 1, 256, 1, 1, 0, m->stream, args, nullptr));   // 64 lanes x 4 row groups per workgroup
+  }
+  if (!m->prog.gather[kind].dest.empty()) {   // what would have been float atomics: parked addends summed per entry in plan order
+    const iem::Program::Gather &G = m->prog.gather[kind];
+    long long n = (long long)G.dest.size();
+    const double *parked = aux + G.aux_off;
+    const long long *dest = m->d_gather[kind], *seg = dest + n;
+    const void *perm = seg + n + 1;
+    int wide = G.park_doubles >= (1LL << 32) ? 1 : 0;
+    void *args[] = {(void *)&out, (void *)&parked, (void *)&dest, (void *)&seg, (void *)&perm, (void *)&n, (void *)&wide};
+    HIP_TRY(hipModuleLaunchKernel(m->fn_gather, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
   }
   return IEM_OK;
 }
@@ -664,6 +677,8 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "autotune") == 0) { o.autotune = (int)value; return IEM_OK; }
   if (std::strcmp(name, "pull_scatter") == 0) { o.pull_scatter = (int)value; return IEM_OK; }
   if (std::strcmp(name, "det_axis") == 0) { o.det_axis = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "det_scatter") == 0) { o.det_scatter = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "det_scatter_max") == 0) { o.det_scatter_max = value; return IEM_OK; }
   if (std::strcmp(name, "lazy_loads") == 0) { o.lazy_loads = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_min_loads") == 0) { o.lazy_min_loads = (int)value; return IEM_OK; }
   if (std::strcmp(name, "name_tag") == 0) { o.name_tag = (int)value; return IEM_OK; }
@@ -704,6 +719,13 @@ int iem_emit_launch_plan(const void *blob, size_t nbytes, char **out_txt) {
     for (int kind = 0; kind < iem::KK_COUNT; ++kind) {   // whole aux buffer of a scatter kind, and its axis sums {c, k0, n0, rows, off}
       if (p.aux_doubles[kind] > 0) os << "aux " << kind << " " << p.aux_doubles[kind] << "\n";
       for (auto &a : p.axis[kind]) os << "axis " << kind << " " << a.c << " " << a.k0 << " " << a.n0 << " " << a.rows << " " << a.off << "\n";
+      const iem::Program::Gather &G = p.gather[kind];
+      if (!G.dest.empty()) {   // plan-driven gather: header, then the three arrays
+        os << "gather " << kind << " " << G.aux_off << " " << G.park_doubles << " " << G.dest.size() << " " << G.perm.size() << "\n";
+        os << "gdest"; for (int64_t v : G.dest) os << " " << v; os << "\n";
+        os << "gseg"; for (int64_t v : G.seg) os << " " << v; os << "\n";
+        os << "gperm"; for (int64_t v : G.perm) os << " " << v; os << "\n";
+      }
     }
     for (int kind = 0; kind < iem::KK_COUNT; ++kind)   // ranges the runtime memsets before launching a scatter kind
       for (auto &z : p.zero_ranges[kind]) os << "zero " << kind << " " << z.first << " " << z.second << "\n";
@@ -833,6 +855,18 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
     if (words == 0) continue;
     if (hipMalloc((void **)&m->d_red[kind], words * 8) != hipSuccess || hipMemset(m->d_red[kind], 0, words * 8) != hipSuccess)
       return bail(fail(IEM_E_HIP, "hipMalloc reduction buffer"));
+    if (!m->prog.gather[kind].dest.empty()) {
+      const iem::Program::Gather &G = m->prog.gather[kind];
+      const size_t nd = G.dest.size(), np = G.perm.size();
+      const bool wide = G.park_doubles >= (1LL << 32);   // parked positions fit 32 bits otherwise: half the plan traffic
+      std::vector<uint32_t> p32;
+      if (!wide) { p32.resize(np); for (size_t k = 0; k < np; ++k) p32[k] = (uint32_t)G.perm[k]; }
+      if (hipMalloc((void **)&m->d_gather[kind], (2 * nd + 1) * 8 + np * (wide ? 8 : 4)) != hipSuccess ||
+          hipMemcpy(m->d_gather[kind], G.dest.data(), nd * 8, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(m->d_gather[kind] + nd, G.seg.data(), (nd + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(m->d_gather[kind] + 2 * nd + 1, wide ? (const void *)G.perm.data() : (const void *)p32.data(), np * (wide ? 8 : 4), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(IEM_E_HIP, "hipMalloc gather plan"));
+    }
     if (!m->prog.axis[kind].empty()) {
       std::vector<long long> tab;
       for (auto &a : m->prog.axis[kind]) { tab.push_back(a.c); tab.push_back(a.k0); tab.push_back(a.n0); tab.push_back(a.rows); tab.push_back(a.off); }
@@ -889,6 +923,7 @@ int iem_destroy(iem_model *m) {
   if (m->d_obj) hipFree(m->d_obj);
   for (double *r : m->d_red) if (r) hipFree(r);
   for (long long *r : m->d_axis) if (r) hipFree(r);
+  for (long long *r : m->d_gather) if (r) hipFree(r);
   for (void *p : m->ipc_opened) hipIpcCloseMemHandle(p);
   if (m->mailbox) hipFree(m->mailbox);
   if (m->d_peers) hipFree(m->d_peers);

@@ -1078,6 +1078,9 @@ class KernelBuilder {
   // gradient store classification (needs every objective slot of the model)
   std::vector<Output> &outputs() { return outs_; }
   const std::vector<IdxVal> &idxvals() const { return idx_; }
+  const std::vector<ILoad> &iloads() const { return iloads_; }
+  const std::vector<int> &ia_arrays() const { return iav_; }
+  const Group &group() const { return g_; }
 
   // ---- emission -----------------------------------------------------------------
   std::string aff_str(const AffQ &a) {
@@ -1419,6 +1422,11 @@ class KernelBuilder {
             int mode = o.grad_mode[s];
             if (mode == 3 || mode < 0) continue;   // parked below (deterministic shared-entry reduction) / folded into another slot
             if (mode == 0) tail << "  if (" << g << ") OUT[i" << o.grad_idx[s] << "] = v" << o.vals[s] << ";\n";
+            else if (mode == 5) {   // parked for the plan-driven gather: one slot of the aux buffer per lane of the launch domain
+              if (o.scalar) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << "] = v" << o.vals[s] << ";\n";
+              else if (g_.flat) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q] = v" << o.vals[s] << ";\n";
+              else tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0 + " << ip(g_.ext[0], 6) << " * (q1 + " << ip(g_.ext[1], 6) << " * q2)] = v" << o.vals[s] << ";\n";
+            }
             else if (mode == 4) {
               // row = position in dims 1, 2 of this output's box, lane = position in dim 0
               const int64_t n0 = o.qhi[0] - o.qlo[0], n1 = o.qhi[1] - o.qlo[1];
@@ -1880,7 +1888,7 @@ Program generate(const Model &m, const Options &opt_in) {
 
   // gradient slot classification needs a global view of every objective slot's index range
   struct GSlot { int kind; int kernel; int out; int slot; int64_t lo, hi; bool injective, uniform0; AffQ aff; bool pure; int64_t count = 0;
-                 int64_t box_lo[3] = {0, 0, 0}, box_n[3] = {1, 1, 1}; bool axis_ok = false; };
+                 int64_t box_lo[3] = {0, 0, 0}, box_n[3] = {1, 1, 1}; bool axis_ok = false; bool empty = false; };
   std::vector<GSlot> gslots;
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
@@ -1919,6 +1927,8 @@ Program generate(const Model &m, const Options &opt_in) {
             if (outs[oi].grad_mode[s] < 0) continue;   // folded into another slot (merge_scatter)
             const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
             GSlot gs{kind, (int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
+            for (int d = 0; d < 3; ++d) { gs.box_lo[d] = scalar ? 0 : outs[oi].qlo[d]; gs.box_n[d] = box_n[d]; if (!scalar && outs[oi].qhi[d] <= outs[oi].qlo[d]) gs.empty = true; }
+            gs.count = gs.empty ? 0 : box_items;
             if (gs.pure) {
               int64_t lo = iv.aff.c, hi = iv.aff.c;
               // q range of this template: q_d in [origin-lo, origin-lo+dims)
@@ -1954,6 +1964,7 @@ Program generate(const Model &m, const Options &opt_in) {
     }
   }
   bool accumulates[KK_COUNT] = {};
+  std::vector<int> atomic_slots[KK_COUNT];   // gslots that ended as atomics (modes 1, 2)
   // Entries MANY items share (one constant destination: finite / first-stage variables): when every
   // slot of the kind that can reach the entry is such a constant slot, the entry is reduced
   // deterministically (grad_mode 3) and written once by the last workgroup of the call.
@@ -2010,7 +2021,76 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     if (mode == 2 && a.pure && a.uniform0) mode = 1;
     builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = mode;
-    if (!(mode == 0 && a.hi - a.lo + 1 == a.count)) accumulates[a.kind] = true;
+    if (mode == 1 || mode == 2) atomic_slots[a.kind].push_back((int)i);
+    else if (!(mode == 0 && a.hi - a.lo + 1 == a.count)) accumulates[a.kind] = true;
+  }
+  // What is still an atomic (entries written from two support grids of a call, collocation stencils, gathered
+  // indices): with `det_scatter` every such addend is PARKED — aux[off + lane of the launch domain], a coalesced
+  // exclusive store — and a follow-up kernel sums each entry's addends in a fixed order from a plan built here, on
+  // the host, from the index expressions (entry -> parked positions).  No float atomics remain, every kind is
+  // bitwise reproducible on every model; the price is 8 bytes of plan and of scratch per addend.
+  for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
+    auto &as = atomic_slots[kind];
+    if (as.empty()) continue;
+    int64_t total = 0;
+    for (int i : as) total += gslots[i].count;
+    if (!opt.det_scatter || total > opt.det_scatter_max) { accumulates[kind] = true; continue; }
+    Program::Gather &G = P.gather[kind];
+    std::vector<int64_t> dest_of, pos_of;
+    dest_of.reserve((size_t)total); pos_of.reserve((size_t)total);
+    int64_t park = 0;   // relative to the start of the gather region of the aux buffer
+    std::vector<std::pair<int, int64_t>> park_of;
+    for (int i : as) {
+      const GSlot &a = gslots[i];
+      KernelBuilder &kb = *builders[a.kernel];
+      Output &o = kb.outputs()[a.out];
+      const Group &g = kb.group();
+      const int64_t lanes = o.scalar ? 1 : g.ext[0] * g.ext[1] * g.ext[2];
+      park_of.emplace_back(i, park);
+      const IdxVal &iv = kb.idxvals()[o.grad_idx[a.slot]];
+      int64_t q[3];
+      if (!a.empty)
+      for (q[2] = a.box_lo[2]; q[2] < a.box_lo[2] + a.box_n[2]; ++q[2])
+        for (q[1] = a.box_lo[1]; q[1] < a.box_lo[1] + a.box_n[1]; ++q[1])
+          for (q[0] = a.box_lo[0]; q[0] < a.box_lo[0] + a.box_n[0]; ++q[0]) {
+            int64_t d = iv.aff.c + iv.aff.k[0] * q[0] + iv.aff.k[1] * q[1] + iv.aff.k[2] * q[2];
+            for (auto &t : iv.ind) {
+              const ILoad &il = kb.iloads()[t.second];
+              const int64_t p = il.pos.c + il.pos.k[0] * q[0] + il.pos.k[1] * q[1] + il.pos.k[2] * q[2];
+              const ArrayDesc &arr = m.arrs[kb.ia_arrays()[il.ia_slot]];
+              if (p < 0 || p >= arr.n) throw std::runtime_error("index array position out of range");
+              d += t.first * arr.i(p);
+            }
+            if (d < 0 || d >= m.nvar) throw std::runtime_error("scatter destination out of range");
+            dest_of.push_back(d);
+            pos_of.push_back(park + (o.scalar ? 0 : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
+          }
+      park += lanes;
+    }
+    // counting sort by entry; within an entry the addends keep slot order, then item order: a fixed order
+    std::vector<int64_t> cnt((size_t)m.nvar + 1, 0);
+    for (int64_t d : dest_of) ++cnt[(size_t)d + 1];
+    // at most TWO addends per entry (pandemic's initial conditions next to its path rows): a + b = b + a, the atomics
+    // are already order-independent — and cheaper than a second launch
+    if (opt.det_scatter < 2 && *std::max_element(cnt.begin(), cnt.end()) <= 2) { accumulates[kind] = true; continue; }
+    for (auto &pr : park_of) {
+      const GSlot &a = gslots[pr.first];
+      Output &o = builders[a.kernel]->outputs()[a.out];
+      o.grad_mode[a.slot] = 5;
+      o.axis_off[a.slot] = pr.second;   // made absolute below
+    }
+    for (int64_t d = 0; d < m.nvar; ++d) if (cnt[(size_t)d + 1]) G.dest.push_back(d);
+    std::vector<int64_t> start((size_t)m.nvar + 1, 0);
+    for (int64_t d = 0; d < m.nvar; ++d) start[(size_t)d + 1] = start[(size_t)d] + cnt[(size_t)d + 1];
+    G.perm.assign(dest_of.size(), 0);
+    {
+      std::vector<int64_t> fill(start.begin(), start.end() - 1);
+      for (size_t e = 0; e < dest_of.size(); ++e) G.perm[(size_t)fill[(size_t)dest_of[e]]++] = pos_of[e];
+    }
+    G.seg.reserve(G.dest.size() + 1);
+    for (int64_t d : G.dest) G.seg.push_back(start[(size_t)d]);
+    G.seg.push_back((int64_t)dest_of.size());
+    G.park_doubles = park;
   }
   for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD})
     for (auto &kv : dest_slots[kind]) P.covered[kind].emplace_back(kv.first, kv.first);   // written (not accumulated) by the last workgroup
@@ -2084,6 +2164,14 @@ Program generate(const Model &m, const Options &opt_in) {
       ax.off = base;
       builders[a.kernel]->outputs()[a.out].axis_off[a.slot] = base;
       base += ax.n0 * ax.rows;
+    }
+    if (P.gather[kind].park_doubles > 0) {   // parked addends of the plan-driven gather: offsets become absolute
+      P.gather[kind].aux_off = base;
+      for (int i : atomic_slots[kind]) {
+        const GSlot &a = gslots[i];
+        builders[a.kernel]->outputs()[a.out].axis_off[a.slot] += base;
+      }
+      base += P.gather[kind].park_doubles;
     }
     P.aux_doubles[kind] = base;
   }

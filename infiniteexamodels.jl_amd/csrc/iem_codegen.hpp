@@ -57,6 +57,10 @@ struct Options {
   int pull_scatter = 1;   // 1: scatter kinds (grad!/jtprod!/hprod!): an addend that lands on a neighbour lane's entry (x[i-1] of a
                           // difference row) is computed by that lane through a shifted clone of the template — exclusive stores, no
                           // zero fill — instead of an atomic (0: A/B)
+  int det_scatter = 1;    // 1: what would still be a float atomic AND can meet more than one other addend in its entry is parked and
+                          // summed in a fixed order from a host-built plan (Program::Gather) — every kind bitwise reproducible on
+                          // every model; 2: also when every entry gets at most two addends; 0: f64 atomics
+  int64_t det_scatter_max = 1LL << 28;   // ... unless a kind has more addends than this (plan + scratch: 16 bytes each)
   int det_axis = 1;       // 1: sums over a non-lane axis are reduced in a fixed order by a follow-up kernel (Program::axis); 0: atomics
   int lazy_loads = 2;     // product and scatter kinds with >= lazy_min_loads loads: 1 load the rows of v / y where first used, 2 every load (0: all loads at the head)
   int lazy_min_loads = 48;
@@ -99,6 +103,10 @@ struct Program {
   // row order — deterministic, no atomics.  `off` counts doubles from the start of the kind's aux buffer.
   struct AxisSum { int64_t c, k0, n0, rows, off; };
   std::vector<AxisSum> axis[KK_COUNT];
+  // What would still be a float atomic (Options::det_scatter): every addend is parked at aux[aux_off + position] and
+  // iem_gather_sum_kernel writes out[dest[i]] = sum of aux[aux_off + perm[k]], k in [seg[i], seg[i+1]) — in that order.
+  struct Gather { std::vector<int64_t> dest, seg, perm; int64_t aux_off = 0, park_doubles = 0; };
+  Gather gather[KK_COUNT];
   int64_t aux_doubles[KK_COUNT] = {};   // whole aux buffer of the kind: shared-entry part (values*wgs + ticket words), then the axis rows
 };
 

@@ -558,6 +558,26 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_axis_sum_kernel(doub
   if (g == 0 && lane < n0) out[t[0] + t[1] * lane] = (part_[l] + part_[64 + l]) + (part_[128 + l] + part_[192 + l]);
 }
 
+// ---- plan-driven gather of parked addends (Program::Gather) -------------------------------------------
+// One thread per output entry: its addends were parked by the kind's kernels (exclusive coalesced stores), the plan
+// (built on the host from the index expressions) lists where; summed in plan order, written once — the form every
+// scatter addend takes that is neither exclusive, nor a shared entry, nor an axis sum.  No atomics, reproducible.
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_gather_sum_kernel(double *__restrict__ out, const double *__restrict__ parked,
+                                                                             const long long *__restrict__ dest, const long long *__restrict__ seg,
+                                                                             const void *__restrict__ perm, long long n, int wide) {
+  const long long i = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  if (wide) {   // positions beyond 2^31: 64-bit plan
+    const long long *__restrict__ p = static_cast<const long long *>(perm);
+    for (long long k = seg[i]; k < seg[i + 1]; ++k) acc += parked[p[k]];
+  } else {
+    const unsigned int *__restrict__ p = static_cast<const unsigned int *>(perm);
+    for (long long k = seg[i]; k < seg[i + 1]; ++k) acc += parked[p[k]];
+  }
+  out[dest[i]] = acc;
+}
+
 // ---- multi-GPU: halo exchange and the one small all-reduce of the path --------------------------
 // One process per GPU; every rank owns a MAILBOX in its HBM that its peers map through HIP IPC
 // (iem_comm_export / iem_comm_connect).  Both kernels PUSH: a rank writes its few doubles straight

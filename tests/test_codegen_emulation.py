@@ -194,7 +194,7 @@ def test_stencil_neighbours_are_pulled_not_scattered(name, lane_fused):
     v = np.random.default_rng(6).standard_normal(om.nvar)
     atomics = {}
     for ps in (1, 0):
-        with iemlib.options(pull_scatter=ps):
+        with iemlib.options(pull_scatter=ps, det_scatter=0):     # det_scatter = 0: what is not pulled stays a float atomic, and can be counted
             em = EmulatedModel(core, blob)
         seg = "".join(re.findall(r"iem_jtprod_g\d+.*?(?=\nextern|\Z)", em.source, flags=re.S))
         atomics[ps] = seg.count("iem_grad_atomic(")
@@ -250,3 +250,35 @@ def test_axis_sums_are_parked_and_summed_in_row_order(lane_fused):
     assert not n_axis[0] and len(n_axis[1]) == 2
     for kind, c, k0, n0, rows, off in n_axis[1]:
         assert n0 == 310 and rows == 7 and k0 == 1          # 300 + 10 time supports, 7 scenarios
+
+
+@pytest.mark.parametrize("name", ["quadrotor_oc3_40", "kinetic_20", "irregular", "pandemic_20x3", "test_problem_1_oc3", "hovercraft_oc4"])
+def test_no_float_atomics_remain(name, grid_mode):
+    """`det_scatter`: whatever is neither an exclusive store, a shared entry nor an axis sum — collocation stencils,
+    entries reached from two support grids, gathered indices — is parked per item and summed per entry in the order of
+    a host-built plan (launch plan: gather / gdest / gseg / gperm) when an entry can get MORE than two addends
+    (default 1: two addends commute, those atomics stay) or always (2: the generated source contains no float atomic
+    at all).  grad! / jtprod! / hprod! agree with the oracle in every setting."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    vc = np.random.default_rng(5).standard_normal(om.ncon)
+    v = np.random.default_rng(6).standard_normal(om.nvar)
+    n_atomics = {}
+    for ds in (2, 1, 0):
+        with iemlib.options(det_scatter=ds):
+            em = EmulatedModel(core, blob)
+            plan = iemlib.emit_launch_plan(blob)
+        n_atomics[ds] = em.source.count("iem_grad_atomic(OUT") + em.source.count("iem_grad_wave_uniform(OUT")     # calls, not the definitions
+        if ds == 2:
+            assert n_atomics[2] == 0 and "\ngather " in plan
+        if ds == 0:
+            assert "\ngather " not in plan and n_atomics[0] > 0
+        assert _rel(em.grad(x), om.grad(x)) <= 1e-13
+        assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+        assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
+    assert n_atomics[1] <= n_atomics[0]
+    if name in ("quadrotor_oc3_40", "kinetic_20"):       # collocation: boundary-node entries get more than two addends
+        assert n_atomics[1] < n_atomics[0]

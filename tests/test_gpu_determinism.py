@@ -5,7 +5,9 @@ share (first-stage variables of the farmer and of the stochastic OPF) are reduce
 summed by the last workgroup in a fixed order (iem_device.h: iem_shared_*) — no floating-point
 atomics whose arrival order could change the rounding; sums over a non-lane axis (pandemic: the u(t) column of
 J'v and Hv gets one addend per scenario) are parked row by row and summed in row order by a follow-up kernel
-(iem_axis_sum_kernel).  Ten calls must give identical bits."""
+(iem_axis_sum_kernel); whatever would still be a float atomic (collocation stencils, entries reached from two
+support grids) is parked per item and summed per entry in the order of a host-built plan (iem_gather_sum_kernel).
+Ten calls must give identical bits."""
 import numpy as np
 import pytest
 
@@ -16,11 +18,12 @@ def _model(name):
     from infiniteexamodels.jl_amd import transcribe, workloads
     mk = {"farmer_40000": lambda: workloads.farmer(40_000), "farmer_900": lambda: workloads.farmer(900),
           "opf_40000": lambda: workloads.opf(40_000), "opf_700": lambda: workloads.opf(700),
-          "quadrotor_50000": lambda: workloads.quadrotor(50_000), "pandemic_600x40": lambda: workloads.pandemic(590, 40)}[name]
+          "quadrotor_50000": lambda: workloads.quadrotor(50_000), "pandemic_600x40": lambda: workloads.pandemic(590, 40),
+          "quadrotor_oc3_30000": lambda: workloads.quadrotor(30_000, collocation=3), "kinetic_20000": lambda: workloads.kinetic_control(20_000)}[name]
     return transcribe.exa_core(mk())
 
 
-@pytest.mark.parametrize("name", ["farmer_40000", "farmer_900", "opf_40000", "opf_700", "quadrotor_50000", "pandemic_600x40"])
+@pytest.mark.parametrize("name", ["farmer_40000", "farmer_900", "opf_40000", "opf_700", "quadrotor_50000", "pandemic_600x40", "quadrotor_oc3_30000", "kinetic_20000"])
 def test_ten_calls_identical_bits(name, built):
     import torch
     from infiniteexamodels.jl_amd.model import ExaModel
@@ -31,6 +34,8 @@ def test_ten_calls_identical_bits(name, built):
     om = OracleModel(blob)
     om.set_threads(min(om.max_threads(), 16))
     x = om.x0 + 0.1 * np.random.default_rng(0).standard_normal(om.nvar)
+    if name.startswith("kinetic"):
+        x = om.x0.copy()
     if name.startswith("farmer") or name.startswith("pandemic"):
         x = np.abs(x) + 0.05
     y = np.random.default_rng(1).standard_normal(om.ncon)
