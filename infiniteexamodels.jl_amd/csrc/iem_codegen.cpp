@@ -2067,29 +2067,44 @@ Program generate(const Model &m, const Options &opt_in) {
           }
       park += lanes;
     }
-    // counting sort by entry; within an entry the addends keep slot order, then item order: a fixed order
-    std::vector<int64_t> cnt((size_t)m.nvar + 1, 0);
-    for (int64_t d : dest_of) ++cnt[(size_t)d + 1];
+    // sort by entry; within an entry the addends keep slot order, then item order: a fixed order.  Counting sort when
+    // the variable space is comparable to the number of addends, a stable comparison sort otherwise (a model — or a
+    // crafted blob — with few addends in a huge variable space must not allocate by nvar)
+    const size_t na = dest_of.size();
+    int64_t max_per_entry = 0;
+    if (m.nvar <= 4 * (int64_t)na + (1 << 20)) {
+      std::vector<int64_t> start((size_t)m.nvar + 1, 0);
+      for (int64_t d : dest_of) ++start[(size_t)d + 1];
+      for (int64_t d = 0; d < m.nvar; ++d) {
+        max_per_entry = std::max(max_per_entry, start[(size_t)d + 1]);
+        if (start[(size_t)d + 1]) G.dest.push_back(d);
+        start[(size_t)d + 1] += start[(size_t)d];
+      }
+      G.perm.assign(na, 0);
+      for (int64_t d : G.dest) G.seg.push_back(start[(size_t)d]);
+      G.seg.push_back((int64_t)na);
+      for (size_t e = 0; e < na; ++e) G.perm[(size_t)start[(size_t)dest_of[e]]++] = pos_of[e];
+    } else {
+      std::vector<size_t> order(na);
+      for (size_t e = 0; e < na; ++e) order[e] = e;
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dest_of[a] < dest_of[b]; });
+      G.perm.reserve(na);
+      for (size_t k = 0; k < na; ++k) {
+        if (k == 0 || dest_of[order[k]] != dest_of[order[k - 1]]) { G.dest.push_back(dest_of[order[k]]); G.seg.push_back((int64_t)k); }
+        G.perm.push_back(pos_of[order[k]]);
+      }
+      G.seg.push_back((int64_t)na);
+      for (size_t i2 = 0; i2 + 1 < G.seg.size(); ++i2) max_per_entry = std::max(max_per_entry, G.seg[i2 + 1] - G.seg[i2]);
+    }
     // at most TWO addends per entry (pandemic's initial conditions next to its path rows): a + b = b + a, the atomics
     // are already order-independent — and cheaper than a second launch
-    if (opt.det_scatter < 2 && *std::max_element(cnt.begin(), cnt.end()) <= 2) { accumulates[kind] = true; continue; }
+    if (opt.det_scatter < 2 && max_per_entry <= 2) { G = Program::Gather(); accumulates[kind] = true; continue; }
     for (auto &pr : park_of) {
       const GSlot &a = gslots[pr.first];
       Output &o = builders[a.kernel]->outputs()[a.out];
       o.grad_mode[a.slot] = 5;
       o.axis_off[a.slot] = pr.second;   // made absolute below
     }
-    for (int64_t d = 0; d < m.nvar; ++d) if (cnt[(size_t)d + 1]) G.dest.push_back(d);
-    std::vector<int64_t> start((size_t)m.nvar + 1, 0);
-    for (int64_t d = 0; d < m.nvar; ++d) start[(size_t)d + 1] = start[(size_t)d] + cnt[(size_t)d + 1];
-    G.perm.assign(dest_of.size(), 0);
-    {
-      std::vector<int64_t> fill(start.begin(), start.end() - 1);
-      for (size_t e = 0; e < dest_of.size(); ++e) G.perm[(size_t)fill[(size_t)dest_of[e]]++] = pos_of[e];
-    }
-    G.seg.reserve(G.dest.size() + 1);
-    for (int64_t d : G.dest) G.seg.push_back(start[(size_t)d]);
-    G.seg.push_back((int64_t)dest_of.size());
     G.park_doubles = park;
   }
   for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD})
