@@ -202,6 +202,9 @@ int iem_hess_structure_device(iem_model *m, int64_t *d_rows, int64_t *d_cols, in
  * deterministic (fixed summation order, no atomics). */
 int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int64_t *d_perm, const double *d_coo,
                    double *d_csr);
+/* the same with 32-bit plan words (all COO positions < 2^32): half the plan traffic */
+int iem_csr_values32(iem_model *m, int64_t n_csr, const uint32_t *d_seg, const uint32_t *d_perm, const double *d_coo,
+                     double *d_csr);
 
 /* ---- kernel generation (no device needed) ---------------------------------------
  * The evaluator of a model is specialised HIP source generated from its templates

@@ -47,6 +47,11 @@ class CsrAssembler:
         self.perm, self.seg, self.rowptr, self.colind = build_plan(r, c, *self.shape)
         self.nnz = int(self.colind.numel())
         self.n_coo = int(r.numel())
+        # 32-bit plan words when every COO position fits: the plan is half of what the assembly kernel reads
+        # (torch has no uint32 arithmetic; int32 holds the same bits for values < 2^31, which is the bound used)
+        self.narrow = self.n_coo < 2 ** 31
+        if self.narrow:
+            self.perm32, self.seg32 = self.perm.to(torch.int32), self.seg.to(torch.int32)
 
     def values(self, coo_vals: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """CSR values of the current COO values (duplicates summed)."""
@@ -55,8 +60,12 @@ class CsrAssembler:
             raise ValueError("coo_vals must be the float64 CUDA output of jac_coord/hess_coord")
         out = out if out is not None else torch.empty(self.nnz, dtype=torch.float64, device=coo_vals.device)
         m._sync_stream()
-        _lib.check(m._L.iem_csr_values(m._h, self.nnz, self.seg.data_ptr(), self.perm.data_ptr(),
-                                       coo_vals.data_ptr(), out.data_ptr()))
+        if self.narrow:
+            _lib.check(m._L.iem_csr_values32(m._h, self.nnz, self.seg32.data_ptr(), self.perm32.data_ptr(),
+                                             coo_vals.data_ptr(), out.data_ptr()))
+        else:
+            _lib.check(m._L.iem_csr_values(m._h, self.nnz, self.seg.data_ptr(), self.perm.data_ptr(),
+                                           coo_vals.data_ptr(), out.data_ptr()))
         return out
 
     def torch_csr(self, coo_vals: torch.Tensor):

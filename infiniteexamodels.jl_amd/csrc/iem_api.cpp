@@ -123,7 +123,7 @@ struct iem_model {
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
-  hipFunction_t fn_struct = nullptr, fn_csr = nullptr, fn_axis = nullptr;
+  hipFunction_t fn_struct = nullptr, fn_csr = nullptr, fn_csr32 = nullptr, fn_axis = nullptr;
   long long *d_axis[iem::KK_COUNT] = {};
   long long *d_gather[iem::KK_COUNT] = {};   // per scatter kind: dest | seg | perm of its plan-driven gather (iem_gather_sum_kernel)
   hipFunction_t fn_gather = nullptr;   // per scatter kind: table of its axis sums (iem_axis_sum_kernel)
@@ -281,6 +281,7 @@ int compile_or_load(iem_model *m) {
   if (rc) return rc;
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_csr32, m->mod, "iem_csr_gather_sum32"));
   HIP_TRY(hipModuleGetFunction(&m->fn_axis, m->mod, "iem_axis_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_gather, m->mod, "iem_gather_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
@@ -1153,6 +1154,16 @@ int iem_csr_values(iem_model *m, int64_t n_csr, const int64_t *d_seg, const int6
   return IEM_OK;
 }
 
+int iem_csr_values32(iem_model *m, int64_t n_csr, const uint32_t *d_seg, const uint32_t *d_perm, const double *d_coo,
+                     double *d_csr) {
+  if (!m || n_csr < 0 || (n_csr && (!d_seg || !d_perm || !d_coo || !d_csr))) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
+  if (n_csr == 0) return IEM_OK;
+  long long n = n_csr;
+  void *args[] = {(void *)&d_seg, (void *)&d_perm, (void *)&d_coo, (void *)&d_csr, (void *)&n};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_csr32, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
+  return IEM_OK;
+}
 
 /* ---- sharding (multi-GPU) ------------------------------------------------------------------- */
 namespace {

@@ -531,6 +531,18 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum(const
   csr[i] = acc;
 }
 
+// the same with 32-bit plan words (COO entries < 2^32): the plan is half of what the kernel reads
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum32(const unsigned int *__restrict__ seg,
+                                                                            const unsigned int *__restrict__ perm,
+                                                                            const double *__restrict__ coo,
+                                                                            double *__restrict__ csr, long long n) {
+  const long long i = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (unsigned int k = seg[i]; k < seg[i + 1]; ++k) acc += coo[perm[k]];
+  csr[i] = acc;
+}
+
 // ---- sums over a non-lane axis of a scatter kind (Program::AxisSum) ----------------------------------
 // The kind's kernels parked one addend per item at aux[off + row*n0 + lane]; entry e (blockIdx.y) writes
 // out[c + k0*lane] = the sum of the lane's column.  A workgroup takes 64 lanes x 4 row groups: thread (l, g) adds

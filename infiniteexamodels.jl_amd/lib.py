@@ -80,7 +80,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
 
@@ -149,6 +149,7 @@ def lib():
     for f in ("iem_jac_structure", "iem_hess_structure", "iem_jac_structure_device", "iem_hess_structure_device"):
         getattr(L, f).argtypes = [vp, vp, vp, i32]
     L.iem_csr_values.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.iem_csr_values32.argtypes = [vp, i64, vp, vp, vp, vp]
     L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     L.iem_emit_source.restype = i32
     L.iem_free.argtypes = [vp]
