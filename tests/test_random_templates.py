@@ -148,6 +148,12 @@ def test_random_model_oracle_vs_autograd_vs_generated(seed, grid_mode):
     assert rel(em.grad(x), om.grad(x)) <= 1e-12
     assert rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-13
     assert rel(em.hess_coord(x, y, 0.6, om.nnzh), om.hess_coord(x, y, 0.6)) <= 1e-12
+    # matrix-free products: the scatter kinds go through every store form of the generator (exclusive, pulled
+    # neighbours, shared entries, axis sums, plan-driven gather) on these shifted / strided / gathered index maps
+    v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+    assert rel(em.jprod(x, v), om.jprod(x, v)) <= 1e-12
+    assert rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-12
+    assert rel(em.hprod(x, y, v, 0.6), om.hprod(x, y, v, 0.6)) <= 1e-12
 
 
 @pytest.mark.gpu
@@ -179,6 +185,14 @@ def test_random_model_gpu(seed, grid_mode):
     _close(gm.grad(xd, gv).cpu().numpy(), om.grad(x), "grad")
     _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac")
     _close(gm.hess_coord(xd, yd, obj_weight=0.6).cpu().numpy(), om.hess_coord(x, y, 0.6), "hess")
+    v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+    vd, vcd = torch.tensor(v, device="cuda"), torch.tensor(vc, device="cuda")
+    _close(gm.jprod(xd, vd, torch.full((om.ncon,), nan, device="cuda", dtype=torch.float64)).cpu().numpy(), om.jprod(x, v), "jprod")
+    jt = [gm.jtprod(xd, vcd, torch.full((om.nvar,), nan, device="cuda", dtype=torch.float64)).cpu().numpy() for _ in range(3)]
+    hp = [gm.hprod(xd, yd, vd, torch.full((om.nvar,), nan, device="cuda", dtype=torch.float64), obj_weight=0.6).cpu().numpy() for _ in range(3)]
+    _close(jt[0], om.jtprod(x, vc), "jtprod")
+    _close(hp[0], om.hprod(x, y, v, 0.6), "hprod")
+    assert all(np.array_equal(jt[0], a) for a in jt[1:]) and all(np.array_equal(hp[0], a) for a in hp[1:]), "products changed between calls"
     gm.close()
 
 
