@@ -19,9 +19,11 @@
 //     partial per workgroup; the last workgroup to finish sums the partials in a fixed order
 //     (bitwise reproducible, no second launch);
 //   * gradient / J'v / Hv entries shared by many items (finite / first-stage variables): the same
-//     scheme per entry (iem_shared_park / iem_shared_totals) — deterministic, no atomics; atomics
-//     remain only for genuinely scattered index maps; entries nothing writes are zeroed by the
-//     kernel itself (iem_zero_fill) when no slot accumulates.
+//     scheme per entry (iem_shared_park / iem_shared_totals) — deterministic, no atomics; sums over a
+//     non-lane axis are parked row by row and reduced by iem_axis_sum_kernel, what would still need more
+//     than two atomics per entry is parked per item and summed by iem_gather_sum_kernel in the order of a
+//     host-built plan; f64 atomics remain only where at most two addends can meet (they commute).
+//     Entries nothing writes are zeroed by the kernel itself (iem_zero_fill) when no slot accumulates.
 //
 // wave = 64 lanes on CDNA4; the generated kernels run IEM_TILE (default 512) lanes per workgroup.
 #ifndef IEM_DEVICE_H
