@@ -271,11 +271,11 @@ int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double 
  * hess_coord! (kind 1) uses for output buffer d_vals — -1 still measuring (or tuner off / buffer not seen),
  * 0 the default code object, 1 the large-batch one.  Introspection only; results never depend on it. */
 int iem_tuner_choice(iem_model *m, int kind, const double *d_vals, int *out_choice);
-/* Decide NOW for these output buffers (either may be NULL): runs the tuner's measurement calls — complete
- * evaluations of jac_coord!(x) into d_jac and hess_coord!(x, y; obj_weight) into d_hess — and synchronises the
- * handle's stream, so that the next call already uses the chosen code object.  A host calls it once after
- * allocating its COO value buffers (solver set-up); without it the first twenty calls of the solve measure.
- * No-op (IEM_OK) on handles without a second code object. */
+/* Decide NOW for these output buffers (either may be NULL): per kind, twelve launches of each of the handle's two
+ * code objects — complete evaluations of jac_coord!(x) into d_jac / hess_coord!(x, y; obj_weight) into d_hess, ten of
+ * them timed between one pair of events — then a stream synchronise; the next call uses the faster object.  A host
+ * calls it once after allocating its COO value buffers (solver set-up); without it the first twenty calls of the solve
+ * into a buffer measure.  No-op (IEM_OK) on handles without a second code object. */
 int iem_tune(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_jac, double *d_hess);
 
 const char *iem_last_error(void);

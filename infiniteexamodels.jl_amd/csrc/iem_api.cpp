@@ -133,8 +133,8 @@ struct iem_model {
   // workgroup per CU, a third of the concurrently open store streams) and the tuner that picks, per kind and
   // per OUTPUT BUFFER, whichever of the two is faster there — how a COO buffer's physical pages fall onto the HBM
   // channels decides that, and both variants write identical bytes, so the first twenty calls into a
-  // buffer alternate between them under HIP events and every call is a valid evaluation.
-#define IEM_TUNE_CALLS 20   // measured calls per output buffer: ten per variant, alternating
+  // buffer run ten with one, ten with the other, under HIP events, and every call is a valid evaluation.
+#define IEM_TUNE_CALLS 20   // measured calls per output buffer: a block of ten per variant
   struct Alt {
     bool on = false;
     iem::Program prog;
@@ -392,7 +392,8 @@ int launch_kind_alt(iem_model *m, int kind, const double *x, const double *y, do
 }
 
 // jac_coord! / hess_coord! through the tuner (struct Alt): the first IEM_TUNE_CALLS calls into an output buffer
-// alternate default / alt under events, then the faster variant (medians; alt only if > 2 % faster) is kept.
+// run ten with the default, then ten with the alt object, under events; then the faster variant (medians of the last
+// eight of each block; alt only if > 2 % faster) is kept.
 int launch_tuned(iem_model *m, int which, int kind, const double *x, const double *y, double *out, double w) {
   if (!m->alt.on) return launch_kind(m, kind, x, y, out, w);
   iem_model::TuneSet &S = m->tune[which];
@@ -414,7 +415,7 @@ int launch_tuned(iem_model *m, int which, int kind, const double *x, const doubl
       for (auto &e : T.ev) for (auto &q : e) HIP_TRY(hipEventCreate(&q));
       T.have_events = true;
     }
-    const int v = T.calls & 1;
+    const int v = T.calls >= IEM_TUNE_CALLS / 2 ? 1 : 0;   // a block of each: alternating single launches measures the switch, not the variant
     HIP_TRY(hipEventRecord(T.ev[T.calls][0], m->stream));
     int rc = v ? launch_kind_alt(m, kind, x, y, out, w) : launch_kind(m, kind, x, y, out, w);
     HIP_TRY(hipEventRecord(T.ev[T.calls][1], m->stream));
@@ -425,9 +426,11 @@ int launch_tuned(iem_model *m, int which, int kind, const double *x, const doubl
     // single launches time to +-5 % and the first ones of a process run cold: median of each variant's last
     // eight samples; the large batch must win by 2 %
     std::vector<float> s[2];
-    for (int c = 4; c < IEM_TUNE_CALLS; ++c) {
+    for (int c = 0; c < IEM_TUNE_CALLS; ++c) {
+      const int v = c >= IEM_TUNE_CALLS / 2 ? 1 : 0;
+      if (c - v * (IEM_TUNE_CALLS / 2) < 2) continue;   // the first two launches of a block: cold instruction cache, the other variant's tail
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, T.ev[c][0], T.ev[c][1]) == hipSuccess) s[c & 1].push_back(ms);
+      if (hipEventElapsedTime(&ms, T.ev[c][0], T.ev[c][1]) == hipSuccess) s[v].push_back(ms);
     }
     float med[2] = {0.f, 1e30f};
     for (int v = 0; v < 2; ++v)
@@ -435,7 +438,7 @@ int launch_tuned(iem_model *m, int which, int kind, const double *x, const doubl
     T.choice = med[1] < 0.98f * med[0] ? 1 : 0;
     if (getenv("IEM_TUNER_LOG")) {
       fprintf(stderr, "iem tuner: kind %d buffer %p:", kind, (const void *)out);
-      for (int c = 0; c < IEM_TUNE_CALLS; ++c) { float ms = -1.f; (void)hipEventElapsedTime(&ms, T.ev[c][0], T.ev[c][1]); fprintf(stderr, " %s%.4f", c & 1 ? "a" : "d", ms); }
+      for (int c = 0; c < IEM_TUNE_CALLS; ++c) { float ms = -1.f; (void)hipEventElapsedTime(&ms, T.ev[c][0], T.ev[c][1]); fprintf(stderr, " %s%.4f", c >= IEM_TUNE_CALLS / 2 ? "a" : "d", ms); }
       fprintf(stderr, " medians %.4f / %.4f -> %s\n", med[0], med[1], T.choice ? "alt" : "default");
     }
     return T.choice ? launch_kind_alt(m, kind, x, y, out, w) : launch_kind(m, kind, x, y, out, w);
@@ -1473,14 +1476,41 @@ int iem_tune(iem_model *m, const double *d_x, const double *d_y, double obj_weig
   if (!m || !d_x || (d_hess && !d_y)) return fail(IEM_E_ARG, "bad argument");
   if (!m->alt.on) return IEM_OK;
   DevGuard dg_(m->device);
-  for (int round = 0; round < 2; ++round) {   // the measured calls, then (events complete) the call that decides
-    for (int i = 0; i < (round ? 1 : IEM_TUNE_CALLS); ++i) {
-      if (d_jac) { int rc = iem_jac_coord(m, d_x, d_jac); if (rc) return rc; }
-      if (d_hess) { int rc = iem_hess_coord(m, d_x, d_y, obj_weight, d_hess); if (rc) return rc; }
+  // Per kind and variant: six warm launches, then ten launches between ONE pair of events — the steady state of that
+  // kernel into that buffer.  (Events around every single launch, as the implicit tuner of a running solve uses,
+  // perturb a pipeline of un-synchronised launches, the large-batch object more than the default: measured
+  // 0.112 ms where ten back-to-back launches take 0.090 — profiles/r02_ab_autotune.txt.)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return fail(IEM_E_HIP, "hipEventCreate"); }
+  int rc = IEM_OK;
+  for (int which = 0; which < 2 && rc == IEM_OK; ++which) {
+    double *out = which ? d_hess : d_jac;
+    if (!out) continue;
+    const int kind = which ? iem::KK_HESS : iem::KK_JAC;
+    float ms[2] = {0.f, 0.f};
+    for (int v = 0; v < 2 && rc == IEM_OK; ++v) {
+      auto go = [&]() { return v ? launch_kind_alt(m, kind, d_x, d_y, out, obj_weight) : launch_kind(m, kind, d_x, d_y, out, obj_weight); };
+      for (int i = 0; i < 6 && rc == IEM_OK; ++i) rc = go();   // warm: the first launches of a code object run cold
+      if (rc == IEM_OK && hipEventRecord(e0, m->stream) != hipSuccess) rc = fail(IEM_E_HIP, "hipEventRecord");
+      for (int i = 0; i < 10 && rc == IEM_OK; ++i) rc = go();
+      if (rc == IEM_OK && (hipEventRecord(e1, m->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                           hipEventElapsedTime(&ms[v], e0, e1) != hipSuccess)) rc = fail(IEM_E_HIP, "event timing");
     }
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (rc != IEM_OK) break;
+    iem_model::TuneSet &S = m->tune[which];
+    iem_model::Tune *hit = nullptr;
+    for (auto &t : S.slot) if (t.out == out) hit = &t;
+    if (!hit) { hit = &S.slot[S.next]; S.next = (S.next + 1) % 4; hit->out = out; }
+    hit->calls = IEM_TUNE_CALLS;
+    hit->choice = ms[1] < 0.98f * ms[0] ? 1 : 0;
+    if (getenv("IEM_TUNER_LOG"))
+      fprintf(stderr, "iem tuner (iem_tune): kind %d buffer %p: default %.4f ms, large batch %.4f ms -> %s\n", kind, (const void *)out,
+              ms[0] / 10, ms[1] / 10, hit->choice ? "large batch" : "default");
   }
-  return IEM_OK;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc == IEM_OK) HIP_TRY(hipStreamSynchronize(m->stream));
+  return rc;
 }
 
 int iem_time_kernels(iem_model *m, const double *d_x, const double *d_y, double *d_jac, double *d_hess, int iters,

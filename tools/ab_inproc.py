@@ -43,5 +43,16 @@ for rnd in range(3):
                 m.jac_coord(xd, jb); m.hess_coord(xd, yd, hb)
                 torch.cuda.synchronize()
             ms_j, ms_h = m.time_kernels(xd, yd, jb, hb, iters=50)
-            row.append(f"{ms_j:.4f}/{ms_h:.4f}")
+            cell = f"{ms_j:.4f}/{ms_h:.4f}"
+            if os.environ.get("IEM_AB_PAIRLOOP"):     # also the bench's pattern: jac, hess, jac, hess, ... with no synchronisation in between
+                step = m.raw_pair(xd, yd, jb, hb, obj_weight=1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(100):
+                    step()
+                e1.record(); torch.cuda.synchronize()
+                cell += f" pair {e0.elapsed_time(e1) / 100:.4f}"
+            row.append(cell)
         print(f"round {rnd} {v:28s} jac/hess ms into 3 buffer pairs: " + "  ".join(row), flush=True)
