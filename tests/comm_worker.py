@@ -62,6 +62,9 @@ def main():
     fpre = torch.zeros(1, dtype=torch.float64, device="cuda")
     gpre = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
     jt = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    vd = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    hp = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    jp = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
 
     def loop():
         gm.halo_exchange(xd)
@@ -74,6 +77,12 @@ def main():
         gm.jtprod(xd, yd, jt)
         gm.halo_fold(jt)
         gm.allreduce_obj_grad(None, jt)
+        # J v and H v with a DISTRIBUTED v: its halo copies arrive like x's; H v folds back like J'v
+        gm.halo_exchange(vd)
+        gm.jprod(xd, vd, jp)
+        gm.hprod(xd, yd, vd, hp, obj_weight=0.7)
+        gm.halo_fold(hp)
+        gm.allreduce_obj_grad(None, hp)
 
     graph = None
     for it in range(5):
@@ -85,7 +94,11 @@ def main():
         xl = xg[vm].copy()
         xl[halo] = np.nan                                  # this rank does NOT hold its neighbour's values
         xd.copy_(torch.tensor(xl)); yd.copy_(torch.tensor(yg[row_map]))
-        for out in (c, jv, hv, g, jt):
+        vg = np.random.default_rng(300 + it).standard_normal(nvg)
+        vl = vg[vm].copy()
+        vl[halo] = np.nan
+        vd.copy_(torch.tensor(vl))
+        for out in (c, jv, hv, g, jt, hp, jp):
             out.fill_(float("nan"))
         if use_graph and it >= 2:
             if graph is None:                              # iterations 0, 1 ran eagerly (warm-up); capture once, replay after
@@ -101,6 +114,7 @@ def main():
         res = dict(c=c.cpu().numpy(), j=jv.cpu().numpy(), h=hv.cpu().numpy(), fpre=fpre.item(), fpost=f.item(),
                    gpre=gpre.cpu().numpy()[repl], gpost=g.cpu().numpy()[repl], gown=g.cpu().numpy()[owned & ~repl],
                    jtown=jt.cpu().numpy()[owned & ~repl], jtrepl=jt.cpu().numpy()[repl], jthalo=jt.cpu().numpy()[halo],
+                   hpown=hp.cpu().numpy()[owned & ~repl], hprepl=hp.cpu().numpy()[repl], jp=jp.cpu().numpy(),
                    own_idx=vm[owned & ~repl], repl_idx=vm[repl], row_map=row_map, jpos=jpos, hpos=hpos)
         allres = [None] * world if rank == 0 else None
         dist.gather_object(res, allres, dst=0)
@@ -109,8 +123,10 @@ def main():
             cg, jg, hg = (np.full(n, np.nan) for n in (G.meta.ncon, G.meta.nnzj, G.meta.nnzh))
             gg = np.full(nvg, np.nan)
             jtg = np.full(nvg, np.nan)
+            hpg, jpg = np.full(nvg, np.nan), np.full(G.meta.ncon, np.nan)
             for r in allres:
                 jtg[r["own_idx"]] = r["jtown"]; jtg[r["repl_idx"]] = r["jtrepl"]
+                hpg[r["own_idx"]] = r["hpown"]; hpg[r["repl_idx"]] = r["hprepl"]; jpg[r["row_map"]] = r["jp"]
                 assert not r["jthalo"].size or not np.any(r["jthalo"]), "halo copies are zeroed by the fold"
             for r in allres:
                 cg[r["row_map"]] = r["c"]; jg[r["jpos"]] = r["j"]; hg[r["hpos"]] = r["h"]
@@ -121,7 +137,8 @@ def main():
             assert np.array_equal(jg, G.jac_coord(xgd).cpu().numpy()), "jac"
             assert np.array_equal(hg, G.hess_coord(xgd, ygd, obj_weight=0.7).cpu().numpy()), "hess"
             # ... and agree with the oracle on the GLOBAL model
-            for got, ref, what in ((cg, O.cons(xg), "cons"), (jg, O.jac_coord(xg), "jac"), (hg, O.hess_coord(xg, yg, 0.7), "hess"), (gg, O.grad(xg), "grad"), (jtg, O.jtprod(xg, yg), "jtprod")):
+            for got, ref, what in ((cg, O.cons(xg), "cons"), (jg, O.jac_coord(xg), "jac"), (hg, O.hess_coord(xg, yg, 0.7), "hess"), (gg, O.grad(xg), "grad"), (jtg, O.jtprod(xg, yg), "jtprod"),
+                                   (jpg, O.jprod(xg, vg), "jprod"), (hpg, O.hprod(xg, yg, vg, 0.7), "hprod")):
                 scale = np.maximum(np.abs(ref), 1e-10 * max(1.0, np.abs(ref).max() if ref.size else 1.0))
                 assert ref.size == 0 or (np.abs(got - ref) / scale).max() <= 1e-10, what
             # all-reduce: rank-order sums, identical bits on every rank
