@@ -20,7 +20,13 @@ Scaling: STRONG by default (SURVEY.md §7 "Strong scaling to >= 6x"): the headli
 10^6 supports in total — is cut into N shards of 10^6/N supports (+ halo); `value` = evaluation
 pairs per second of that fixed problem, so value(N)/value(1) is the speed-up.  For N > 1 the same
 run also measures the weak form (every rank a full 10^6-support shard of an N*10^6 horizon)
-outside the headline timed region and reports it under the key "weak".
+outside the headline timed region and reports it under the key "weak", and — also outside the timed
+region, in child processes so that nothing there can void the line — wires the C-ABI's mailboxes and
+checks / times the halo exchange and the objective all-reduce on this machine's links (key "comm").
+
+Set-up before the W warm-up steps: iem_tune decides, for THESE output buffers, which of the handle's two code
+objects writes them faster (large grids only; config.store_batch_tuner says what it chose).  The timed region is
+exactly K pairs of complete evaluations.
 """
 from __future__ import annotations
 
