@@ -1965,6 +1965,7 @@ Program generate(const Model &m, const Options &opt_in) {
   }
   bool accumulates[KK_COUNT] = {};
   std::vector<int> atomic_slots[KK_COUNT];   // gslots that ended as atomics (modes 1, 2)
+  std::vector<int> parked_slots[KK_COUNT];   // gslots whose addends go through the plan-driven gather (mode 5)
   // Entries MANY items share (one constant destination: finite / first-stage variables): when every
   // slot of the kind that can reach the entry is such a constant slot, the entry is reduced
   // deterministically (grad_mode 3) and written once by the last workgroup of the call.
@@ -1988,15 +1989,40 @@ Program generate(const Model &m, const Options &opt_in) {
         dest_slots[kind][kv.first] = kv.second;
       }
     }
-  // classify gradient slots: exclusive iff injective and its range meets no other slot's range
+  // A FEW items against many (pandemic: the initial conditions on the xi grid hit s(0, xi), which the path rows on the
+  // t x xi grid write too — another workgroup of the same launch): instead of turning the big slot's coalesced stores
+  // into atomics, the small slots are DEFERRED — parked like the plan-driven gather's addends and ADDED to the entries
+  // after the kind's kernels, in plan order.  A slot is small when it has at most 1/32 of the items of the kind's
+  // largest slot (and at most 65536); a big injective slot that only small slots reach keeps its exclusive stores.
+  std::vector<char> deferred(gslots.size(), 0);
+  if (opt.det_scatter >= 1) {
+    int64_t maxcount[KK_COUNT] = {};
+    for (const GSlot &b : gslots) maxcount[b.kind] = std::max(maxcount[b.kind], b.count);
+    auto is_small = [&](const GSlot &b) { return b.pure && b.count > 0 && b.count <= 65536 && b.count * 32 <= maxcount[b.kind]; };
+    for (size_t i = 0; i < gslots.size(); ++i) {
+      const GSlot &a = gslots[i];
+      if (shared_dest[i] || !a.pure || !a.injective || a.count == 0 || is_small(a)) continue;
+      bool big_clash = false;
+      std::vector<size_t> smalls;
+      for (size_t j = 0; j < gslots.size() && !big_clash; ++j) {
+        const GSlot &b = gslots[j];
+        if (i == j || b.kind != a.kind || b.hi < a.lo || b.lo > a.hi) continue;
+        if (shared_dest[j] || !is_small(b)) big_clash = true; else smalls.push_back(j);
+      }
+      if (!big_clash) for (size_t j : smalls) deferred[j] = 1;
+    }
+  }
+  std::vector<int> deferred_slots[KK_COUNT];
+  // classify gradient slots: exclusive iff injective and its range meets no other (non-deferred) slot's range
   for (size_t i = 0; i < gslots.size(); ++i) {
     GSlot &a = gslots[i];
     if (shared_dest[i]) { builders[a.kernel]->outputs()[a.out].grad_mode[a.slot] = 3; continue; }
+    if (deferred[i]) { deferred_slots[a.kind].push_back((int)i); continue; }   // mode 5 below, with the accumulate flag
     int mode = 2;
     bool clash = false;
     if (a.pure)
       for (size_t j = 0; j < gslots.size() && !clash; ++j) {
-        if (i == j) continue;
+        if (i == j || deferred[j]) continue;
         const GSlot &b = gslots[j];
         if (b.kind != a.kind) continue;   // different output vectors
         if (!(b.hi < a.lo || b.lo > a.hi)) clash = true;
@@ -2031,22 +2057,17 @@ Program generate(const Model &m, const Options &opt_in) {
   // bitwise reproducible on every model; the price is 8 bytes of plan and of scratch per addend.
   for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD}) {
     auto &as = atomic_slots[kind];
-    if (as.empty()) continue;
+    auto &ds = deferred_slots[kind];
+    if (as.empty() && ds.empty()) continue;
     int64_t total = 0;
     for (int i : as) total += gslots[i].count;
-    if (!opt.det_scatter || total > opt.det_scatter_max) { accumulates[kind] = true; continue; }
-    Program::Gather &G = P.gather[kind];
-    std::vector<int64_t> dest_of, pos_of;
-    dest_of.reserve((size_t)total); pos_of.reserve((size_t)total);
-    int64_t park = 0;   // relative to the start of the gather region of the aux buffer
-    std::vector<std::pair<int, int64_t>> park_of;
-    for (int i : as) {
+    bool park_atomics = !as.empty() && opt.det_scatter && total <= opt.det_scatter_max;
+    // destinations of one slot's items, in item order; `park` = the slot's first position in the gather region
+    auto collect = [&](int i, int64_t park, std::vector<int64_t> &dest_of, std::vector<int64_t> *pos_of) {
       const GSlot &a = gslots[i];
       KernelBuilder &kb = *builders[a.kernel];
-      Output &o = kb.outputs()[a.out];
+      const Output &o = kb.outputs()[a.out];
       const Group &g = kb.group();
-      const int64_t lanes = o.scalar ? 1 : g.ext[0] * g.ext[1] * g.ext[2];
-      park_of.emplace_back(i, park);
       const IdxVal &iv = kb.idxvals()[o.grad_idx[a.slot]];
       int64_t q[3];
       if (!a.empty)
@@ -2063,48 +2084,61 @@ Program generate(const Model &m, const Options &opt_in) {
             }
             if (d < 0 || d >= m.nvar) throw std::runtime_error("scatter destination out of range");
             dest_of.push_back(d);
-            pos_of.push_back(park + (o.scalar ? 0 : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
+            if (pos_of) pos_of->push_back(park + (o.scalar ? 0 : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
           }
-      park += lanes;
+      return o.scalar ? (int64_t)1 : g.ext[0] * g.ext[1] * g.ext[2];
+    };
+    if (park_atomics && opt.det_scatter < 2) {
+      // at most TWO addends per entry: a + b = b + a, those atomics are already order-independent — and cheaper than
+      // a second launch
+      std::vector<int64_t> d0;
+      d0.reserve((size_t)total);
+      for (int i : as) collect(i, 0, d0, nullptr);
+      std::sort(d0.begin(), d0.end());
+      int64_t run = 0, best = 0;
+      for (size_t e = 0; e < d0.size(); ++e) { run = (e && d0[e] == d0[e - 1]) ? run + 1 : 1; best = std::max(best, run); }
+      if (best <= 2) park_atomics = false;
     }
-    // sort by entry; within an entry the addends keep slot order, then item order: a fixed order.  Counting sort when
-    // the variable space is comparable to the number of addends, a stable comparison sort otherwise (a model — or a
-    // crafted blob — with few addends in a huge variable space must not allocate by nvar)
-    const size_t na = dest_of.size();
-    int64_t max_per_entry = 0;
-    if (m.nvar <= 4 * (int64_t)na + (1 << 20)) {
-      std::vector<int64_t> start((size_t)m.nvar + 1, 0);
-      for (int64_t d : dest_of) ++start[(size_t)d + 1];
-      for (int64_t d = 0; d < m.nvar; ++d) {
-        max_per_entry = std::max(max_per_entry, start[(size_t)d + 1]);
-        if (start[(size_t)d + 1]) G.dest.push_back(d);
-        start[(size_t)d + 1] += start[(size_t)d];
-      }
-      G.perm.assign(na, 0);
-      for (int64_t d : G.dest) G.seg.push_back(start[(size_t)d]);
-      G.seg.push_back((int64_t)na);
-      for (size_t e = 0; e < na; ++e) G.perm[(size_t)start[(size_t)dest_of[e]]++] = pos_of[e];
-    } else {
-      std::vector<size_t> order(na);
-      for (size_t e = 0; e < na; ++e) order[e] = e;
-      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dest_of[a] < dest_of[b]; });
-      G.perm.reserve(na);
-      for (size_t k = 0; k < na; ++k) {
-        if (k == 0 || dest_of[order[k]] != dest_of[order[k - 1]]) { G.dest.push_back(dest_of[order[k]]); G.seg.push_back((int64_t)k); }
-        G.perm.push_back(pos_of[order[k]]);
-      }
-      G.seg.push_back((int64_t)na);
-      for (size_t i2 = 0; i2 + 1 < G.seg.size(); ++i2) max_per_entry = std::max(max_per_entry, G.seg[i2 + 1] - G.seg[i2]);
-    }
-    // at most TWO addends per entry (pandemic's initial conditions next to its path rows): a + b = b + a, the atomics
-    // are already order-independent — and cheaper than a second launch
-    if (opt.det_scatter < 2 && max_per_entry <= 2) { G = Program::Gather(); accumulates[kind] = true; continue; }
-    for (auto &pr : park_of) {
-      const GSlot &a = gslots[pr.first];
+    if (!as.empty() && !park_atomics) accumulates[kind] = true;
+    std::vector<std::pair<int, bool>> chosen;   // (gslot, accumulate onto what the kernels stored)
+    for (int i : ds) chosen.emplace_back(i, true);
+    if (park_atomics) for (int i : as) chosen.emplace_back(i, false);
+    if (chosen.empty()) continue;
+    Program::Gather &G = P.gather[kind];
+    std::vector<int64_t> dest_of, pos_of;
+    std::vector<char> acc_of;
+    int64_t park = 0;   // relative to the start of the gather region of the aux buffer
+    for (auto &ch : chosen) {
+      const GSlot &a = gslots[ch.first];
       Output &o = builders[a.kernel]->outputs()[a.out];
       o.grad_mode[a.slot] = 5;
-      o.axis_off[a.slot] = pr.second;   // made absolute below
+      o.axis_off[a.slot] = park;   // made absolute below
+      const size_t before = dest_of.size();
+      park += collect(ch.first, park, dest_of, &pos_of);
+      acc_of.insert(acc_of.end(), dest_of.size() - before, ch.second ? 1 : 0);
+      parked_slots[kind].push_back(ch.first);
     }
+    // sort by entry; within an entry the addends keep slot order, then item order: a fixed order (a stable sort; a
+    // model — or a crafted blob — with few addends in a huge variable space must not allocate by nvar)
+    const size_t na = dest_of.size();
+    std::vector<size_t> order(na);
+    for (size_t e = 0; e < na; ++e) order[e] = e;
+    if (m.nvar <= 4 * (int64_t)na + (1 << 20)) {   // counting sort
+      std::vector<int64_t> start((size_t)m.nvar + 1, 0);
+      for (int64_t d : dest_of) ++start[(size_t)d + 1];
+      for (int64_t d = 0; d < m.nvar; ++d) start[(size_t)d + 1] += start[(size_t)d];
+      for (size_t e = 0; e < na; ++e) order[(size_t)start[(size_t)dest_of[e]]++] = e;
+    } else {
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dest_of[a] < dest_of[b]; });
+    }
+    G.perm.reserve(na);
+    for (size_t k = 0; k < na; ++k) {
+      const size_t e = order[k];
+      if (k == 0 || dest_of[e] != dest_of[order[k - 1]]) { G.dest.push_back(dest_of[e]); G.seg.push_back((int64_t)k); }
+      if (acc_of[e] && G.dest.back() >= 0) G.dest.back() = ~G.dest.back();   // an entry with a deferred addend: ADD to what the kernels stored
+      G.perm.push_back(pos_of[e]);
+    }
+    G.seg.push_back((int64_t)na);
     G.park_doubles = park;
   }
   for (int kind : {(int)KK_GRAD, (int)KK_JTPROD, (int)KK_HPROD})
@@ -2182,7 +2216,7 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     if (P.gather[kind].park_doubles > 0) {   // parked addends of the plan-driven gather: offsets become absolute
       P.gather[kind].aux_off = base;
-      for (int i : atomic_slots[kind]) {
+      for (int i : parked_slots[kind]) {
         const GSlot &a = gslots[i];
         builders[a.kernel]->outputs()[a.out].axis_off[a.slot] += base;
       }

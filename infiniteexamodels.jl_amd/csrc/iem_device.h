@@ -576,6 +576,7 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_axis_sum_kernel(doub
 // One thread per output entry: its addends were parked by the kind's kernels (exclusive coalesced stores), the plan
 // (built on the host from the index expressions) lists where; summed in plan order, written once — the form every
 // scatter addend takes that is neither exclusive, nor a shared entry, nor an axis sum.  No atomics, reproducible.
+// dest[i] < 0 (= ~entry): the entry also has an exclusive writer among the kind's kernels; the sum is ADDED to it.
 extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_gather_sum_kernel(double *__restrict__ out, const double *__restrict__ parked,
                                                                              const long long *__restrict__ dest, const long long *__restrict__ seg,
                                                                              const void *__restrict__ perm, long long n, int wide) {
@@ -589,7 +590,9 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_gather_sum_kernel(do
     const unsigned int *__restrict__ p = static_cast<const unsigned int *>(perm);
     for (long long k = seg[i]; k < seg[i + 1]; ++k) acc += parked[p[k]];
   }
-  out[dest[i]] = acc;
+  const long long d = dest[i];
+  if (d >= 0) out[d] = acc;      // nobody else writes the entry
+  else out[~d] += acc;           // deferred addends of a few items: added to what the kind's kernels stored there
 }
 
 // ---- multi-GPU: halo exchange and the one small all-reduce of the path --------------------------

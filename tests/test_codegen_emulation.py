@@ -282,3 +282,27 @@ def test_no_float_atomics_remain(name, grid_mode):
     assert n_atomics[1] <= n_atomics[0]
     if name in ("quadrotor_oc3_40", "kinetic_20"):       # collocation: boundary-node entries get more than two addends
         assert n_atomics[1] < n_atomics[0]
+
+
+def test_a_few_items_against_many_are_deferred(lane_fused):
+    """pandemic: the initial conditions s(0, xi) = s0 live on the xi grid (7 items per template), the path rows that write
+    the same entries on the t x xi grid (2170) — another workgroup of the same launch.  The big slots keep their exclusive
+    coalesced stores; the few items are parked and ADDED after the kernels by the plan-driven gather (negative = ~entry
+    in gdest): no float atomic in the source, no memset in the plan, same J'v."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core("pandemic_300x7")
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for("pandemic_300x7", om)
+    vc = np.random.default_rng(5).standard_normal(om.ncon)
+    em = EmulatedModel(core, blob)
+    plan = iemlib.emit_launch_plan(blob)
+    assert em.source.count("iem_grad_atomic(OUT") == 0
+    gdest = [int(v) for ln in plan.splitlines() if ln.startswith("gdest") for v in ln.split()[1:]]
+    assert len(gdest) == 4 * 7 * 3 // 3 and all(d < 0 for d in gdest)       # 4 initial conditions x 7 scenarios (J'v only: one plan)
+    assert not [ln for ln in plan.splitlines() if ln.startswith("zero 6 ")]    # kind 6 = jtprod: nothing left to memset
+    assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    with iemlib.options(det_scatter=0):
+        em0 = EmulatedModel(core, blob)
+    assert em0.source.count("iem_grad_atomic(OUT") > 0
+    assert _rel(em0.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
