@@ -24,9 +24,10 @@ outside the headline timed region and reports it under the key "weak", and — a
 region, in child processes so that nothing there can void the line — wires the C-ABI's mailboxes and
 checks / times the halo exchange and the objective all-reduce on this machine's links (key "comm").
 
-Set-up before the W warm-up steps: iem_tune decides, for THESE output buffers, which of the handle's two code
-objects writes them faster (large grids only; config.store_batch_tuner says what it chose).  The timed region is
-exactly K pairs of complete evaluations.
+Set-up before the W warm-up steps: iem_tune — a no-op unless the opt-in second code object is enabled (--opt autotune=1),
+in which case it decides, for THESE output buffers, which of the handle's two code objects writes them faster
+(config.store_batch_tuner says what it chose; -1 = one code object).  The timed region is exactly K pairs of complete
+evaluations.
 """
 from __future__ import annotations
 

@@ -255,7 +255,7 @@ void iem_free(void *p);
  *                  scenarios) are parked per item and reduced in row order by a follow-up kernel; 0: f64 atomics
  *   "lazy_loads"   2 (default): product / scatter kernels with >= "lazy_min_loads" (48) loads emit a load where its value
  *                  is first used instead of at the head of the kernel (register pressure); 1: only rows of v / y; 0: never
- *   "autotune"     1 (default): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups
+ *   "autotune"     0 (default) / 1 (opt-in): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups
  *                  keep a second code object with a 48-slot LDS store batch and choose per output buffer,
  *                  from the first twenty calls into it (HIP events, every call a valid evaluation), which of
  *                  the two writes that buffer faster (the buffer's physical placement decides,

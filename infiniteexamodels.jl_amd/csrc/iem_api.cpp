@@ -1476,7 +1476,7 @@ int iem_tune(iem_model *m, const double *d_x, const double *d_y, double obj_weig
   if (!m || !d_x || (d_hess && !d_y)) return fail(IEM_E_ARG, "bad argument");
   if (!m->alt.on) return IEM_OK;
   DevGuard dg_(m->device);
-  // Per kind and variant: six warm launches, then ten launches between ONE pair of events — the steady state of that
+  // Per kind and variant, twice: six warm launches, then ten launches between ONE pair of events (the faster block counts) — the steady state of that
   // kernel into that buffer.  (Events around every single launch, as the implicit tuner of a running solve uses,
   // perturb a pipeline of un-synchronised launches, the large-batch object more than the default: measured
   // 0.112 ms where ten back-to-back launches take 0.090 — profiles/r02_ab_autotune.txt.)
@@ -1488,14 +1488,18 @@ int iem_tune(iem_model *m, const double *d_x, const double *d_y, double obj_weig
     double *out = which ? d_hess : d_jac;
     if (!out) continue;
     const int kind = which ? iem::KK_HESS : iem::KK_JAC;
-    float ms[2] = {0.f, 0.f};
+    float ms[2] = {1e30f, 1e30f};
+    for (int round = 0; round < 2 && rc == IEM_OK; ++round)   // default, large batch, default, large batch: the first blocks of a process run on a GPU that is still ramping up
     for (int v = 0; v < 2 && rc == IEM_OK; ++v) {
       auto go = [&]() { return v ? launch_kind_alt(m, kind, d_x, d_y, out, obj_weight) : launch_kind(m, kind, d_x, d_y, out, obj_weight); };
       for (int i = 0; i < 6 && rc == IEM_OK; ++i) rc = go();   // warm: the first launches of a code object run cold
       if (rc == IEM_OK && hipEventRecord(e0, m->stream) != hipSuccess) rc = fail(IEM_E_HIP, "hipEventRecord");
       for (int i = 0; i < 10 && rc == IEM_OK; ++i) rc = go();
+      float t = 0.f;
       if (rc == IEM_OK && (hipEventRecord(e1, m->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                           hipEventElapsedTime(&ms[v], e0, e1) != hipSuccess)) rc = fail(IEM_E_HIP, "event timing");
+                           hipEventElapsedTime(&t, e0, e1) != hipSuccess)) rc = fail(IEM_E_HIP, "event timing");
+      ms[v] = std::min(ms[v], t);
+      if (getenv("IEM_TUNER_LOG")) fprintf(stderr, "iem tuner (iem_tune): kind %d round %d variant %d block %.4f ms per launch\n", kind, round, v, t / 10);
     }
     if (rc != IEM_OK) break;
     iem_model::TuneSet &S = m->tune[which];

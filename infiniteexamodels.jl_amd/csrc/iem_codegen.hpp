@@ -66,7 +66,7 @@ struct Options {
   int lazy_min_loads = 48;
   int name_tag = 0;         // > 0: kernel names end in _b<tag> (set by the runtime for a handle's second code object)
   int lazy_all_kinds = 0;   // experiment: also cons!/jac_coord!/hess_coord!/obj
-  int autotune = 1;    // 1: jac_coord!/hess_coord! of large grids keep a second code object (lds_slots = 48) and pick, per output
+  int autotune = 0;    // opt-in (measured gains depend on the process).  1: jac_coord!/hess_coord! of large grids keep a second code object (lds_slots = 48) and pick, per output
                        // buffer, the faster of the two from their first twenty calls (runtime only; the generator ignores it)
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)
   int obj_unroll = 1;  // 2: the objective's tile walk takes two tiles per trip (single-body kernels)

@@ -424,8 +424,8 @@ def test_store_batch_tuner_is_invisible_in_the_results(torch_cuda):
     S = 260_000                                   # 525 workgroups: above autotune_min_blocks
     core = transcribe.exa_core(workloads.quadrotor(S))
     blob = core.to_blob()
-    tuned = ExaModel(core, device=0, blob=blob)
-    plain = ExaModel(core, device=0, blob=blob, options={"autotune": 0})
+    tuned = ExaModel(core, device=0, blob=blob, options={"autotune": 1})     # opt-in
+    plain = ExaModel(core, device=0, blob=blob)
     om = OracleModel(blob)
     om.set_threads(min(om.max_threads(), 16))
     x = tuned.meta.x0 + 0.1 * np.random.default_rng(0).standard_normal(tuned.meta.nvar)

@@ -16,7 +16,7 @@ t0 = time.perf_counter()
 core = transcribe.exa_core(workloads.quadrotor(S))
 blob = core.to_blob()
 t_build = time.perf_counter() - t0
-gm = ExaModel(core, device=0, blob=blob)
+gm = ExaModel(core, device=0, blob=blob, options={"autotune": 1})   # opt-in second code object: its store path beyond 2^31 too
 print("model", gm.meta.nvar, gm.meta.ncon, gm.meta.nnzj, gm.meta.nnzh, "build %.1fs" % t_build, flush=True)
 rng = np.random.default_rng(0)
 x = gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)
