@@ -459,3 +459,31 @@ def test_store_batch_tuner_is_invisible_in_the_results(torch_cuda):
     assert np.array_equal(jb2.cpu().numpy(), jref) and np.array_equal(hb2.cpu().numpy(), href)
     assert plain.tune(xd, yd, jb2, hb2) == {"jac": -1, "hess": -1}
     tuned.close(); plain.close()
+
+
+def test_misuse_is_an_error_code_not_a_crash(torch_cuda):
+    """C-ABI misuse on a live handle comes back as a negative code + message (the wrapper raises IemError): the
+    multi-GPU calls on an unsharded handle, null / missing arguments, an unknown per-handle option — and the handle
+    still evaluates afterwards."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    core = cases.build_core("quadrotor_100")
+    blob = core.to_blob()
+    gm = ExaModel(core, device=0, blob=blob)
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for("quadrotor_100", om)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    g = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
+    L = iemlib.lib()
+    for call in (lambda: gm.halo_exchange(xd), lambda: gm.halo_fold(g), lambda: gm.allreduce_obj_grad(None, g), lambda: gm.comm_export()):
+        with pytest.raises(iemlib.IemError):
+            call()
+    assert L.iem_jac_coord(gm._h, None, None) < 0
+    assert L.iem_tune(gm._h, xd.data_ptr(), None, 1.0, None, g.data_ptr()) < 0          # a Hessian buffer without y
+    assert L.iem_csr_values32(gm._h, 5, None, None, None, None) < 0
+    with pytest.raises(KeyError):          # the wrapper knows the option names; the C-ABI itself answers IEM_E_ARG (tests/test_abi.py)
+        ExaModel(core, device=0, blob=blob, options={"no_such_option": 1})
+    _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac after misuse")
+    gm.close()
