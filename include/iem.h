@@ -64,7 +64,7 @@ typedef struct iem_template_info_t {
  * line of bench.py is computed from */
 typedef struct iem_kernel_info_t {
   char name[64];
-  int32_t kind; /* 0 cons, 1 jac, 2 hess, 3 obj, 4 grad */
+  int32_t kind; /* 0 cons, 1 jac, 2 hess, 3 obj, 4 grad, 5 jprod, 6 jtprod, 7 hprod */
   int32_t jit;  /* 1 if this model's code object was compiled by hiprtc (cache miss) */
   int64_t grid[3];
   int64_t lds_bytes;
@@ -101,7 +101,8 @@ int iem_create_opts(const void *blob, size_t nbytes, int device, const iem_optio
  *   iem_allreduce_obj_grad   after obj / grad!: the scalar objective and the gradient entries of
  *                            replicated variables, summed over ranks in rank order (bitwise equal
  *                            on every rank)
- * Both are one small kernel that writes straight into the peers' mailboxes (HIP IPC; xGMI between
+ *   (iem_halo_fold           the transpose of the first, for J'v / Hv on a rank's rows)
+ * Each is one small kernel that writes straight into the peers' mailboxes (HIP IPC; xGMI between
  * GPUs) and waits on its own — asynchronous on the handle's stream, graph-replayable, every wait
  * bounded (iem_comm_status reports a time-out).  Wiring: every rank calls iem_comm_export, the host
  * all-gathers the IEM_COMM_HANDLE_BYTES-byte handles (MPI / torch.distributed / a pipe — like an
