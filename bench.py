@@ -18,16 +18,26 @@ this process makes any GPU call — and rank 0 prints the one JSON line.
 
 Scaling: STRONG by default (SURVEY.md §7 "Strong scaling to >= 6x"): the headline problem —
 10^6 supports in total — is cut into N shards of 10^6/N supports (+ halo); `value` = evaluation
-pairs per second of that fixed problem, so value(N)/value(1) is the speed-up.  For N > 1 the same
-run also measures the weak form (every rank a full 10^6-support shard of an N*10^6 horizon)
-outside the headline timed region and reports it under the key "weak", and — also outside the timed
-region, in child processes so that nothing there can void the line — wires the C-ABI's mailboxes and
-checks / times the halo exchange and the objective all-reduce on this machine's links (key "comm").
+pairs per second of that fixed problem, so value(N)/value(1) is the speed-up.
 
-Set-up before the W warm-up steps: iem_tune — a no-op unless the opt-in second code object is enabled (--opt autotune=1),
-in which case it decides, for THESE output buffers, which of the handle's two code objects writes them faster
-(config.store_batch_tuner says what it chose; -1 = one code object).  The timed region is exactly K pairs of complete
-evaluations.
+N > 1, what the timed step is: every solver iteration moves x, so the stencil neighbours x_k[a_r - 1] must cross
+the shard boundary before the rows that read them are evaluated.  The timed step is therefore
+`iem_halo_exchange_async(x); jac_coord!; hess_coord!` — the exchange INSIDE the timed region (key "halo_in_timed_loop").
+The library runs it on its comm stream and orders each evaluation call against it by what the call's kernels load
+(csrc/iem_api.cpp: halo_before / halo_after); the communication-free pair is reported beside it ("pair_no_halo").
+Before the ranks wire their mailboxes in-process, the same wiring + one checked exchange + one checked all-reduce
+run in CHILD processes (key "comm": peer-mapped memory is the one part that the one-GPU box can only rehearse with all
+ranks on one device — whatever it does on a real xGMI node must end in an entry of the line, never in a lost line).  If
+the children fail, or a rank cannot wire its mailbox, the timed step falls back to the communication-free pair and the
+line says so ("halo_in_timed_loop": false, "comm_fallback": reason); the torch.distributed (RCCL) fallback of the two
+exchanges is shard.ShardComm.  The weak form of the same run is reported under "weak".
+
+Inputs: x and y are resident in HBM and re-used every step (a solver's iterate); `roofline.frac_cold_inputs` is the same
+pair with K = 4 distinct (x, y) sets cycled per call (> 256 MiB in total: nothing of a call's inputs can sit in the
+Infinity Cache from the call before) — measured outside the timed region.
+
+Generator options go through iem_create_opts (per HANDLE; `--opt name=value`), never the process defaults.  The staging
+batch of jac_coord! / hess_coord! is a function of the grid size (config.lds_slots reports what each kernel got).
 """
 from __future__ import annotations
 
@@ -45,7 +55,19 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_PROFILE = "r02_final_rocprof_quadrotor_1e6.json"   # committed rocprofv3 --pmc passes of this command (static, not live)
+PMC_PROFILE = "pmc_quadrotor_1e6.json"   # committed rocprofv3 --pmc passes of this command (tools/profile_gpu.sh; static, not live)
+
+
+def csrc_fingerprint() -> str:
+    """sha256 over the library's sources (csrc/*.cpp, *.hpp, *.h): the PMC profile records it, so a profile taken from
+    another csrc tree is visible in the line (`roofline.traffic_stale`).  (No git on the GPU box: content, not commit.)"""
+    import hashlib
+    d = os.path.join(ROOT, "infiniteexamodels.jl_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".cpp", ".hpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def eval_point(nvar, ncon, x0, S_local, seed=0):
@@ -125,7 +147,7 @@ def spawn_ranks(n: int, script: str = None) -> int:
     return rc
 
 
-def comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, iters):
+def comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, iters, connect=True):
     """Multi-GPU data path around the pair, through the library's own mailboxes (iem_comm_export / _connect,
     iem_halo_exchange, iem_allreduce_obj_grad).  Every stage is agreed on by all ranks (MIN over an ok flag)
     before the next one starts, and the device-side waits are bounded, so a failure yields an "error" entry
@@ -136,19 +158,20 @@ def comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, iter
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
 
-    out, err = {}, ""
-    try:
-        mine = gm.comm_export()
-    except Exception as e:     # noqa: BLE001 — reported in the line
-        mine, err = b"", f"export: {e}"
-    handles = [None] * world
-    dist.all_gather_object(handles, mine)
-    ok = all(isinstance(h, (bytes, bytearray)) and len(h) == len(handles[0]) and len(h) > 0 for h in handles)
-    if ok:
+    out, err, ok = {}, "", True
+    if connect:     # (False: the ranks of this process are wired already)
         try:
-            gm.comm_connect(b"".join(handles))
-        except Exception as e:     # noqa: BLE001
-            ok, err = False, f"connect: {e}"
+            mine = gm.comm_export()
+        except Exception as e:     # noqa: BLE001 — reported in the line
+            mine, err = b"", f"export: {e}"
+        handles = [None] * world
+        dist.all_gather_object(handles, mine)
+        ok = all(isinstance(h, (bytes, bytearray)) and len(h) == len(handles[0]) and len(h) > 0 for h in handles)
+        if ok:
+            try:
+                gm.comm_connect(b"".join(handles))
+            except Exception as e:     # noqa: BLE001
+                ok, err = False, f"connect: {e}"
     if not agreed(ok):
         return {"error": err or "a peer could not export / map a mailbox"}
     try:
@@ -191,8 +214,8 @@ def comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, iter
         out["halo_exchange_us"] = timed(lambda: gm.halo_exchange(xc))
         out["allreduce_obj_us"] = timed(lambda: gm.allreduce_obj_grad(fo, None))
         us = timed(lambda: (gm.halo_exchange(xc), step()))
-        out["pair_with_halo"] = {"ms_per_step": us / 1e3, "note": "halo exchange of x before every pair (what a solver iteration adds); "
-                                 "device time, max over ranks; not the headline value"}
+        out["pair_behind_blocking_halo"] = {"ms_per_step": us / 1e3, "note": "stream-ordered iem_halo_exchange in front of every pair (round-2 form; the "
+                                            "headline step uses the asynchronous exchange); device time, max over ranks"}
         ok = gm.comm_status() == 0
     except Exception as e:     # noqa: BLE001
         ok, err = False, f"timing: {e}"
@@ -218,7 +241,7 @@ def comm_isolated(args, dist, rank, world, local_rank, barrier):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--comm-child", "--gpus", str(world), "--dist-backend", "gloo", "--supports", str(args.supports),
            "--scaling", args.scaling, "--steps", str(min(args.steps, 200)), "--warmup", "3", "--store-mode", str(args.store_mode),
-           "--hess-layout", args.hess_layout] + (["--same-device"] if args.same_device else []) + [a for kv in args.opt for a in ("--opt", kv)]
+           "--hess-layout", args.hess_layout, "--no-cold"] + (["--same-device"] if args.same_device else []) + (["--fused"] if args.fused else []) + [a for kv in args.opt for a in ("--opt", kv)]
     out, rc = "", -1
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -263,6 +286,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the jac+hess pair from a captured HIP graph instead of eager launches")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the (untimed) check of the halo exchange / objective all-reduce")
     ap.add_argument("--comm-child", action="store_true", help=argparse.SUPPRESS)   # internal: run ONLY the comm section (see comm_isolated)
+    ap.add_argument("--fused", action="store_true", help="the timed step is iem_jac_hess_coord (one launch) instead of the two calls; the other form is reported beside it")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-input measurement (K rotating x / y sets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -319,16 +344,27 @@ def main():
         if rank == 0:
             iemlib.build_library()
         barrier()
-    iemlib.set_option("store_mode", args.store_mode)
-    iemlib.set_option("nt_stores", args.nt)
-    iemlib.set_option("fp_contract", args.fma)
+    # generator options of THIS run's handles (iem_create_opts): nothing process-global
+    hopts = {"store_mode": args.store_mode, "nt_stores": args.nt, "fp_contract": args.fma}
     for kv in args.opt:
         k, v = kv.split("=")
-        iemlib.set_option(k, int(v))
+        hopts[k] = int(v)
 
-    def measure(scaling: str, steps: int, warmup: int):
-        """Build this rank's shard for `scaling`, run `warmup` untimed + exactly `steps` timed
-        jac+hess pairs between barriers, return (max-over-ranks seconds, supports all ranks own, state)."""
+    # N > 1: the comm path is first exercised in child processes (see the module docstring); only when every child came
+    # back clean do the ranks of THIS process wire their mailboxes and put the exchange into the timed step
+    comm = None
+    want_halo = world > 1 and use_dist and not args.no_comm and not args.emulate_shard and not args.comm_child
+    if want_halo and not (args.same_device and 2 * world > 6):
+        comm = comm_isolated(args, dist, rank, world, local_rank, barrier)
+        ok = [comm is None or "error" not in comm]
+        if use_dist:
+            dist.broadcast_object_list(ok, src=0)
+        want_halo = bool(ok[0])
+
+    def measure(scaling: str, steps: int, warmup: int, with_halo: bool):
+        """Build this rank's shard for `scaling`, run `warmup` untimed + exactly `steps` timed steps between barriers,
+        return (max-over-ranks seconds, supports all ranks own, state).  A step is one jac_coord! + one hess_coord!
+        (`--fused`: the one-launch form), preceded on a wired multi-GPU run by the asynchronous halo exchange of x."""
         if scaling == "weak":
             S_global = args.supports * world
         else:
@@ -342,30 +378,39 @@ def main():
         core = transcribe.exa_core(workloads.quadrotor(S_global))
         blob = core.to_blob()
         if ew == 1:
-            gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout)
+            gm = ExaModel(core, device=local_rank, blob=blob, hess_layout=args.hess_layout, options=hopts)
             S_local = S_global
         else:
             del core
-            gm = ExaModel.sharded(blob, 1, er, ew, device=local_rank, hess_layout=args.hess_layout)
+            gm = ExaModel.sharded(blob, 1, er, ew, device=local_rank, hess_layout=args.hess_layout, options=hopts)
             S_local = gm.shard_info()["own_n"]
         del blob
         x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22, seed=rank * 2)
         xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
         jac = torch.empty(gm.meta.nnzj, dtype=torch.float64, device=dev)
         hess = torch.empty(gm.meta.nnzh, dtype=torch.float64, device=dev)
+        halo_state = {"in_loop": False}
+        if with_halo:
+            # the library's own mailboxes or nothing: a rank that cannot wire them makes every rank time the
+            # communication-free pair, and the line says why (the RCCL fallback of the exchanges exists — shard.ShardComm —
+            # but a host-driven send/recv inside a 25-us step is not what this line measures)
+            sc = shard.ShardComm(gm, dist)
+            halo_state.update(kind=sc.kind, why=sc.why, in_loop=sc.kind == "own", mailbox_kind=gm.shard_info()["mailbox_kind"] if sc.kind == "own" else 0)
 
-        # one step = iem_jac_coord + iem_hess_coord through the C-ABI; argument checks and the stream lookup of
-        # the Python wrapper are done once (ExaModel.raw_pair) — at 8 GPUs a step is 25 us of device time
-        step = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0)
-        # solver set-up, before the warm-up: which of the handle's two code objects writes THESE buffers faster
-        # (iem_tune; large grids only, -1 = the handle has one code object).  Without it the first twenty pairs
-        # of the run would be the measurement.
-        gm._tuned = gm.tune(xd, yd, jac, hess, obj_weight=1.0)
+        # one step through the C-ABI; argument checks and the stream lookup of the Python wrapper are done once
+        # (ExaModel.raw_pair) — at 8 GPUs a step is 25 us of device time
+        step = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=halo_state["in_loop"])
+        gm._tuned = gm.tune(xd, yd, jac, hess, obj_weight=1.0)   # no-op unless --opt autotune=1
 
         if args.graph:
             def eager():      # the wrappers follow torch's CURRENT stream, which the capture needs
-                gm.jac_coord(xd, jac)
-                gm.hess_coord(xd, yd, hess, obj_weight=1.0)
+                if halo_state["in_loop"]:
+                    gm.halo_exchange_async(xd)
+                if args.fused:
+                    gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0)
+                else:
+                    gm.jac_coord(xd, jac)
+                    gm.hess_coord(xd, yd, hess, obj_weight=1.0)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -385,6 +430,8 @@ def main():
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+        if halo_state["in_loop"]:
+            halo_state["status"] = gm.comm_status()     # 0: every exchange of the timed loop completed
         if use_dist:
             t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -394,27 +441,74 @@ def main():
             supports_total = float(sl.item())
         else:
             supports_total = float(S_local)
-        return dt, supports_total, (gm, S_local, xd, yd, jac, hess, step)
+        return dt, supports_total, (gm, S_local, xd, yd, jac, hess, step, halo_state)
 
-    dt, supports_total, (gm, S_local, xd, yd, jac, hess, step) = measure(args.scaling, args.steps, args.warmup)
+    dt, supports_total, (gm, S_local, xd, yd, jac, hess, step, halo_state) = measure(args.scaling, args.steps, args.warmup, want_halo)
 
     if args.comm_child:
-        comm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, min(args.steps, 200))
+        ccomm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, min(args.steps, 200))
         if rank == 0:
-            print("COMM " + json.dumps(comm), flush=True)
+            print("COMM " + json.dumps(ccomm), flush=True)
         barrier()
         dist.destroy_process_group()
         return
 
-    # distribution of single pairs (median, p10/p90), HIP events on the
+    def timed_loop(fn, n):
+        """max-over-ranks seconds of n calls of fn between barriers (secondary measurements, outside the headline region)"""
+        for _ in range(5):
+            fn()
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(); barrier()
+        d = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([d], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
+    n2 = min(args.steps, 200)
+    secondary = {}
+    # the other launch form of the same pair, and (N > 1) the same step without the exchange
+    other = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=not args.fused, halo=halo_state["in_loop"])
+    secondary["fused_pair" if not args.fused else "separate_calls"] = {"ms_per_step": timed_loop(other, n2) / n2 * 1e3}
+    if halo_state["in_loop"]:
+        nohalo = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=False)
+        secondary["pair_no_halo"] = {"ms_per_step": timed_loop(nohalo, n2) / n2 * 1e3}
+
+    # distribution of single steps (SURVEY §8(d) config 2: median, p10/p90), HIP events on the
     # launch stream, outside the timed region
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(min(args.steps, 200) + 1)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n2 + 1)]
     ev[0].record()
     for e in ev[1:]:
         step()
         e.record()
     torch.cuda.synchronize()
     pair_ms = np.array([a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])])
+
+    # the same pair with COLD inputs: K distinct (x, y) sets, > 256 MiB in total, cycled per call — per-kernel events
+    cold = None
+    if world == 1 and not args.no_cold and not args.graph:
+        K = max(4, int(np.ceil(300e6 / (8.0 * (gm.meta.nvar + gm.meta.ncon)))))
+        K = min(K, 64)
+        xs = [xd] + [xd + 1e-3 * (i + 1) for i in range(K - 1)]
+        ys = [yd] + [yd * (1.0 + 1e-3 * (i + 1)) for i in range(K - 1)]
+        nc = 20 * K if gm.meta.nvar < 5_000_000 else 4 * K
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nc)]
+        for i in range(K):
+            gm.jac_coord(xs[i], jac); gm.hess_coord(xs[i], ys[i], hess, obj_weight=1.0)
+        torch.cuda.synchronize()
+        for i in range(nc):
+            evs[i][0].record(); gm.jac_coord(xs[i % K], jac)
+            evs[i][1].record(); gm.hess_coord(xs[i % K], ys[i % K], hess, obj_weight=1.0)
+            evs[i][2].record()
+        torch.cuda.synchronize()
+        cold = {"sets": K, "input_bytes_total": int(8 * K * (gm.meta.nvar + gm.meta.ncon)),
+                "jac_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
+                "hess_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))}
+        del xs, ys
 
     line = None
     if rank == 0:
@@ -431,20 +525,35 @@ def main():
         ms_dom = ms_hess if dom == "hess" else ms_jac
         achieved = alg / (ms_dom * 1e-3) / 1e9
         pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())
-        # HBM bytes per launch from the PMC counters cannot be collected inside this process
-        # (they need rocprofv3 passes of their own): a STATIC figure read from the committed
-        # profile of the same command and size (tools/profile_gpu.sh → profiles/), null otherwise.
-        traffic, traffic_src = None, None
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process (they need rocprofv3
+        # passes of their own): read from the committed profile of the same command and size (tools/profile_gpu.sh →
+        # profiles/), which records the fingerprint of the csrc tree it was taken from — `traffic_stale` says whether
+        # that is THIS tree.
+        traffic, traffic_src, stale = None, None, None
         prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
         if os.path.exists(prof) and S_local == 1_000_000 and world == 1:
             try:
                 pj = json.load(open(prof))
                 traffic = pj["pmc"][kd["name"]]["hbm_bytes_per_launch"]
+                stale = pj.get("csrc_fingerprint") != csrc_fingerprint()
                 traffic_src = (f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                               f"profiled at commit {pj.get('commit', 'n/a')})")
+                               f"csrc fingerprint {pj.get('csrc_fingerprint', 'n/a')}, commit {pj.get('commit', 'n/a')})")
             except Exception:
                 traffic = None
         par = f"support-sharded x{world}, {args.scaling} scaling" + (f", shard {args.emulate_shard} emulated on one GPU" if args.emulate_shard else "")
+        step_txt = ("iem_jac_hess_coord (one launch)" if args.fused else "iem_jac_coord + iem_hess_coord") + \
+                   (" behind iem_halo_exchange_async(x)" if halo_state["in_loop"] else "")
+        roof = {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
+                "traffic_stale": stale, "traffic_source": traffic_src, "csrc_fingerprint": csrc_fingerprint(),
+                "alg_bytes": alg, "kernel_ms": ms_dom,
+                "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
+                "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if cold:
+            cms = cold["hess_ms"] if dom == "hess" else cold["jac_ms"]
+            roof["frac_cold_inputs"] = alg / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["pair_frac_cold_inputs"] = pair_alg / ((cold["jac_ms"] + cold["hess_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["cold_inputs"] = cold
         line = {
             "metric": "jac_coord!+hess_coord! evals/sec, quadrotor 1e6 supports; % HBM roofline",
             "value": value, "unit": "jac+hess pairs/s (1e6-support quadrotor equivalent)",
@@ -455,41 +564,45 @@ def main():
                                    f"{S_local} per GPU, jac_coord!+hess_coord! only, seed 0/1 inputs resident in HBM",
                        "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
                        "store_mode": args.store_mode, "hess_layout": args.hess_layout, "parallelism": par,
+                       "step": step_txt, "options": "per handle (iem_create_opts)",
                        "launch": "hipGraph replay" if args.graph else "eager",
-                       "store_batch_tuner": {**gm._tuned, "meaning": "-1 one code object, 0 default kept, 1 large LDS batch chosen for this output buffer (iem_tune at set-up)"},
+                       "lds_bytes": {k: v["lds_bytes"] for k, v in ks.items()},
+                       "store_batch_tuner": {**gm._tuned, "meaning": "-1 tuner off (default: the staging batch is a function of kind and grid size)"},
                        "kernels_from": "hiprtc at run time (code-object cache miss)" if any(k["jit"] for k in gm.kernels()) else "in-tree code-object cache"},
-            "roofline": {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
-                         "traffic_source": traffic_src,
-                         "alg_bytes": alg, "kernel_ms": ms_dom,
-                         "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
-                         "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": roof,
         }
         line["pair_ms"] = {"median": float(np.median(pair_ms)), "p10": float(np.percentile(pair_ms, 10)),
                            "p90": float(np.percentile(pair_ms, 90)), "n": int(pair_ms.size)}
-    # N > 1, outside the headline timed region and never able to void it: the data path a solver adds around the
-    # pair — the halo exchange of x (every iteration moves x) and the one collective (objective all-reduce) —
-    # wired through the C-ABI's own mailboxes, checked for correctness and timed on this machine's links
-    if world > 1 and use_dist and not args.no_comm and not args.emulate_shard and not args.comm_child:
-        if args.same_device and 2 * world > 6:     # one-GPU rehearsal: parents + children would exceed the box's per-GPU process limit
-            comm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, min(args.steps, 200))
-        else:
-            comm = comm_isolated(args, dist, rank, world, local_rank, barrier)
+        for k, v in secondary.items():
+            v["value"] = supports_total / 1e6 / (v["ms_per_step"] * 1e-3)
+            line[k] = v
+        if world > 1:
+            line["halo_in_timed_loop"] = bool(halo_state["in_loop"])
+            if halo_state["in_loop"]:
+                line["halo"] = {"exchange": "iem_halo_exchange_async (own mailbox kernels, comm stream)", "mailbox_kind": halo_state.get("mailbox_kind"),
+                                "status_after_timed_loop": halo_state.get("status"), "reads_halo": {k: v[0] for k, v in gm.halo_reads().items() if k in ("cons", "jac", "hess", "pair")}}
+            elif not args.no_comm and not args.emulate_shard:
+                line["comm_fallback"] = (comm or {}).get("error") or halo_state.get("why") or "not attempted"
+            if comm is not None:
+                line["comm"] = comm
+    # one-GPU rehearsal with many ranks: parents + children would exceed the box's per-GPU process limit — the checked
+    # comm section runs in-process there
+    if world > 1 and use_dist and not args.no_comm and not args.emulate_shard and args.same_device and 2 * world > 6:
+        ccomm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, n2, connect=not halo_state["in_loop"])
         if rank == 0:
-            if "pair_with_halo" in comm:
-                comm["pair_with_halo"]["value"] = supports_total / 1e6 / (comm["pair_with_halo"]["ms_per_step"] * 1e-3)
-            line["comm"] = comm
+            line["comm"] = ccomm
     # secondary measurement, outside the headline timed region: the weak form of the same run
     # (every rank a full `--supports` shard of an N-times longer horizon)
     if world > 1 and args.scaling == "strong" and not args.no_weak and not args.emulate_shard:
-        del gm, xd, yd, jac, hess, step
+        del gm, xd, yd, jac, hess, step, other
+        secondary.clear()
         torch.cuda.empty_cache()
-        wdt, wsupports, state = measure("weak", max(10, args.steps // 4), max(3, args.warmup // 4))
+        wdt, wsupports, state = measure("weak", max(10, args.steps // 4), max(3, args.warmup // 4), False)
         if rank == 0:
             wsteps = max(10, args.steps // 4)
             line["weak"] = {"value": wsupports / 1e6 * wsteps / wdt, "ms_per_step": wdt / wsteps * 1e3, "steps": wsteps,
                             "supports_total": int(wsupports), "supports_per_gpu": int(state[1]),
-                            "note": "every rank owns a full shard; no data-path collective, so this is Nx by construction"}
+                            "note": "every rank owns a full shard; communication-free pair, so this is Nx by construction"}
         del state
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

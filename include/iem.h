@@ -37,7 +37,10 @@ enum {
   IEM_E_HIP = -2,     /* HIP runtime error                                */
   IEM_E_COMPILE = -3, /* kernel generation / hiprtc failure               */
   IEM_E_ARG = -4,     /* bad argument                                     */
-  IEM_E_NODEVICE = -5 /* no usable gfx950 device                          */
+  IEM_E_NODEVICE = -5,/* no usable gfx950 device                          */
+  IEM_E_COMM = -6     /* a mailbox wait (halo exchange / fold / all-reduce) timed out since the last check: a peer did not take
+                         part.  The kernels have set what they should have delivered to NaN; reported once, by the next host
+                         synchronisation point (iem_obj, iem_obj_end, iem_synchronize), then cleared                         */
 };
 
 /* mirrors NLPModels' `meta` fields the reference reads
@@ -64,7 +67,7 @@ typedef struct iem_template_info_t {
  * line of bench.py is computed from */
 typedef struct iem_kernel_info_t {
   char name[64];
-  int32_t kind; /* 0 cons, 1 jac, 2 hess, 3 obj, 4 grad, 5 jprod, 6 jtprod, 7 hprod */
+  int32_t kind; /* 0 cons, 1 jac, 2 hess, 3 obj, 4 grad, 5 jprod, 6 jtprod, 7 hprod, 8 jac + hess in one launch (iem_jac_hess_coord) */
   int32_t jit;  /* 1 if this model's code object was compiled by hiprtc (cache miss) */
   int64_t grid[3];
   int64_t lds_bytes;
@@ -149,6 +152,20 @@ int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int wor
 int iem_comm_export(iem_model *m, void *out_handle /* IEM_COMM_HANDLE_BYTES */);
 int iem_comm_connect(iem_model *m, const void *all_handles /* world x IEM_COMM_HANDLE_BYTES, rank order */);
 int iem_halo_exchange(iem_model *m, double *d_x);
+/* The same exchange OFF the critical path.  It starts on the handle's internal comm stream as soon as the work already
+ * enqueued on the handle's stream (whatever produced x) has finished, and the library orders the evaluation calls that
+ * follow against it by what their kernels actually load: a call that can touch a halo entry of d_x (cons! of a model with
+ * difference rows: x_k[a_r - 1], transform.jl:535-557) waits for the exchange; a call that cannot (obj, grad!, and
+ * jac_coord! / hess_coord! whenever the stencil rows are linear — their partials are item data) is launched at once and
+ * overlaps it.  The handle's stream re-joins the exchange behind the FIRST evaluation call that follows (or iem_halo_wait,
+ * iem_synchronize), so everything enqueued after that call is ordered behind the exchange as usual.  Contract: between this
+ * call and that first evaluation call / iem_halo_wait the caller enqueues nothing that reads or writes d_x.  One exchange
+ * is outstanding at a time (a second call joins the first).  Graph-capturable (the comm stream forks from and joins the
+ * capturing stream).  iem_halo_reads reports what the handle derived: does kernel kind `kind` (iem_kernel_info_t.kind) touch
+ * a halo entry through x / through a variable-space v. */
+int iem_halo_exchange_async(iem_model *m, double *d_x);
+int iem_halo_wait(iem_model *m);
+int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v);
 /* The transposed exchange, for a vector in VARIABLE space produced by a transposed operator on this rank's rows
  * (iem_jtprod): the entries of the halo copies hold what this rank's rows owe to variables the LEFT neighbour owns
  * (the x_k[a_r - 1] column of the first difference row, src/transform.jl:535-557).  They are sent to the left
@@ -157,7 +174,10 @@ int iem_halo_exchange(iem_model *m, double *d_x);
  * handle's stream, graph-capturable, bounded waits like iem_halo_exchange. */
 int iem_halo_fold(iem_model *m, double *d_vec);
 int iem_allreduce_obj_grad(iem_model *m, double *d_obj /* device scalar, may be NULL */, double *d_g);
-/* synchronises the handle's stream; 0 = every exchange so far completed, else a bit mask of time-outs */
+/* synchronises the handle's stream; 0 = every exchange so far completed, else a bit mask of time-outs (1 / 2 halo ack / data,
+ * 4 all-reduce, 8 / 16 fold ack / data).  A time-out never hangs and never goes unnoticed: the kernel that ran into it writes
+ * NaN instead of the data that did not arrive, and the next iem_obj / iem_obj_end / iem_synchronize returns IEM_E_COMM (and
+ * clears the mask).  The bound is the per-handle option "comm_timeout_ms" (default 5000). */
 int iem_comm_status(iem_model *m, int64_t *out_status);
 
 int iem_destroy(iem_model *m);
@@ -177,10 +197,21 @@ int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_va
  * the solvers (ext/InfiniteExaModelsIpopt.jl:49, ext/InfiniteExaModelsMadNLP.jl:50). */
 int iem_obj(iem_model *m, const double *d_x, double *h_out);
 int iem_obj_device(iem_model *m, const double *d_x, double *d_out); /* async variant */
+/* iem_obj in two halves: begin enqueues the objective kernel (its last workgroup writes the scalar into mapped host memory) and
+ * returns at once, end waits for the value.  A solver that evaluates obj, grad!, cons!, jac_coord!, hess_coord! at one point
+ * (ext/InfiniteExaModelsIpopt.jl:48-49) calls begin first and end after its last launch: the host round trip of the scalar
+ * (~8 us of the ~14 us iem_obj takes on a small model) overlaps the other four calls.  One begin outstanding per handle. */
+int iem_obj_begin(iem_model *m, const double *d_x);
+int iem_obj_end(iem_model *m, double *h_out);
 int iem_grad(iem_model *m, const double *d_x, double *d_g);
 int iem_cons(iem_model *m, const double *d_x, double *d_c);
 int iem_jac_coord(iem_model *m, const double *d_x, double *d_vals);
 int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_vals);
+/* jac_coord!(m, x, jac) + hess_coord!(m, x, y, hess; obj_weight) in ONE launch: the two are independent given x and y
+ * (MadNLP evaluates both at every accepted point, ext/InfiniteExaModelsMadNLP.jl:49-50,64).  Identical bytes to the two
+ * calls; one launch ramp and drain instead of two, and on a shard-sized grid (about one workgroup per CU and kind) both
+ * kinds are resident together. */
+int iem_jac_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_jac, double *d_hess);
 
 /* matrix-free products (NLPModels jprod! / jtprod! / hprod!; ExaModels' `prod = true` path —
  * not used by the reference's solvers): Jv (ncon), J'v (nvar), Hv (nvar) with
@@ -256,6 +287,13 @@ void iem_free(void *p);
  *                  scenarios) are parked per item and reduced in row order by a follow-up kernel; 0: f64 atomics
  *   "lazy_loads"   2 (default): product / scatter kernels with >= "lazy_min_loads" (48) loads emit a load where its value
  *                  is first used instead of at the head of the kernel (register pressure); 1: only rows of v / y; 0: never
+ *   "big_batch_jac", "big_batch_hess", "big_batch_slots"   jac_coord! / hess_coord! kernels of a grid with at least this many
+ *                  workgroups (defaults 400 / 4000, 0: never) stage "big_batch_slots" (48) values per barrier pair instead of
+ *                  "lds_slots" — one 96-KB workgroup per CU instead of three: a third of the concurrently open store streams.
+ *                  A function of kind and grid size only (never of a timer): jac_coord!'s 18 narrow streams are
+ *                  placement-insensitive in that form, hess_coord! gains above the Infinity Cache
+ *   "pair_kernel"  1 (default): the handle also carries the fused jac + hess launch behind iem_jac_hess_coord
+ *   "comm_timeout_ms"  bound of every mailbox wait of this handle's exchange kernels (default 5000)
  *   "autotune"     0 (default) / 1 (opt-in): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups
  *                  keep a second code object with a 48-slot LDS store batch and choose per output buffer,
  *                  from the first twenty calls into it (HIP events, every call a valid evaluation), which of

@@ -115,6 +115,7 @@ class ExaTranscriptionBackend:
 
     def warmstart_backend_start_values(self) -> None:
         """``InfiniteOpt.warmstart_backend_start_values`` (:595-615)."""
+        self._refuse_sharded("warmstart_backend_start_values")
         if self.results is None:
             import warnings
             warnings.warn("No previous solution values found. Unable to warmstart backend.")
@@ -122,8 +123,22 @@ class ExaTranscriptionBackend:
         self.core.x0[:] = np.asarray(_to_numpy(self.results.solution))
         self._y0 = np.asarray(_to_numpy(self.results.multipliers))
 
+    def _refuse_sharded(self, what: str) -> None:
+        """A backend built with ``MI355XBackend(shard = (group, rank, world))`` holds ONE rank's shard: its model has
+        the rank's local variables (halo copies included), ``core`` the global ones.  It is a build-and-evaluate plug
+        point — the evaluation calls, ``halo_exchange`` and ``allreduce_obj_grad`` of ``self.model``, the global θ /
+        start-value hooks.  Driving a solver needs one that is itself distributed over the ranks (its KKT solve spans
+        the shards); the single-process solver slot of the reference (``:259-271``) cannot do that, so it is refused
+        loudly instead of handing a global ``x0`` to a local model."""
+        if isinstance(self.backend, MI355XBackend) and self.backend.shard is not None:
+            raise NotImplementedError(
+                f"{what}: this backend holds rank {self.backend.shard[1]} of {self.backend.shard[2]} of a sharded model "
+                "(build-and-evaluate only); solve on an unsharded backend, or drive the shards' evaluation calls "
+                "(model.halo_exchange / allreduce_obj_grad) from a distributed solver")
+
     # JuMP.optimize!(backend) (:259-271)
     def optimize(self):
+        self._refuse_sharded("optimize")
         if self.solver is None:
             raise RuntimeError("No solver attached to the backend")
         if self.model is None:

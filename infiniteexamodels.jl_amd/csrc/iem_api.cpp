@@ -168,6 +168,20 @@ struct iem_model {
   int64_t n_shared = 0;
   double *h_obj = nullptr;   // pinned + mapped host scalar
   double *d_hobj = nullptr;  // its device address
+  bool obj_armed = false;    // iem_obj_begin launched, iem_obj_end not yet called
+  // a mailbox wait that timed out (iem_device.h: IemCommErr) also lands here — mapped pinned host memory the host
+  // synchronisation points read without a copy (h_obj + 1)
+  volatile unsigned long long *h_status = nullptr;
+  unsigned long long *d_hstatus = nullptr;
+  // asynchronous halo exchange (iem_halo_exchange_async): the exchange kernel runs on `comm_stream` behind `ev_x`
+  // (= everything enqueued on the handle's stream when it was called); evaluation calls that can touch a halo entry
+  // of the exchanged vector wait for `ev_halo` first, the others are launched and THEN join — they overlap it
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+  bool halo_pending = false;
+  const void *halo_vec = nullptr;
+  bool reads_halo_x[iem::KK_PAIR + 1] = {}, reads_halo_v[iem::KK_PAIR + 1] = {};
+  uint64_t nonce = 0;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
   std::vector<void *> d_tables;    // per kernel: device copy of {ip, dp, fa, ia} when they do not fit the argument block
@@ -357,7 +371,45 @@ int launch(iem_model *m, size_t k, const double *x, const double *y, double *out
   return launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], x, y, out, w, v, aux);
 }
 
+// A mailbox wait timed out since the last check: the kernels poisoned what they delivered (NaN) and recorded it in
+// mapped host memory.  Host synchronisation points (iem_obj / iem_obj_end / iem_synchronize) report it once and clear it.
+int comm_check(iem_model *m) {
+  if (!m->h_status || *m->h_status == 0) return IEM_OK;
+  const unsigned long long bits = *m->h_status;
+  *m->h_status = 0;
+  if (m->mailbox) { const unsigned long long z = 0; (void)hipMemcpy(m->mailbox, &z, 8, hipMemcpyHostToDevice); (void)hipGetLastError(); }
+  return fail(IEM_E_COMM, "a mailbox wait timed out (status bits " + std::to_string(bits) + ": 1/2 halo ack/data, 4 all-reduce, 8/16 fold ack/data): "
+                          "a peer did not take part in the exchange; the halo entries / reduced values it should have delivered were set to NaN");
+}
+
+// Ordering of an evaluation call against a pending asynchronous halo exchange (iem_halo_exchange_async): a kind that can
+// touch a halo entry of the exchanged vector waits for it BEFORE its launch; any other kind is launched first and the
+// handle's stream joins the exchange AFTER it — that call overlaps the exchange, everything later is ordered behind it.
+int halo_before(iem_model *m, int kind, const void *x, const void *v) {
+  if (!m->halo_pending) return IEM_OK;
+  const bool need = (x == m->halo_vec && m->reads_halo_x[kind]) || (v && v == m->halo_vec && m->reads_halo_v[kind]);
+  if (!need) return IEM_OK;
+  HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_halo, 0));
+  m->halo_pending = false;
+  return IEM_OK;
+}
+int halo_after(iem_model *m) {
+  if (!m->halo_pending) return IEM_OK;
+  HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_halo, 0));
+  m->halo_pending = false;
+  return IEM_OK;
+}
+
+int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux);
+
 int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
+  int rc = halo_before(m, kind, x, v);
+  if (rc == IEM_OK) rc = launch_kind_raw(m, kind, x, y, out, w, v, aux);
+  if (rc == IEM_OK) rc = halo_after(m);
+  return rc;
+}
+
+int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux) {
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     if (m->prog.kernels[k].kind == kind) {
       int rc = launch(m, k, x, y, out, w, v, aux);
@@ -383,12 +435,14 @@ int launch_kind(iem_model *m, int kind, const double *x, const double *y, double
 }
 
 int launch_kind_alt(iem_model *m, int kind, const double *x, const double *y, double *out, double w) {
+  int rc = halo_before(m, kind, x, nullptr);
+  if (rc) return rc;
   for (size_t k = 0; k < m->alt.prog.kernels.size(); ++k)
     if (m->alt.prog.kernels[k].kind == kind) {
-      int rc = launch_one(m, m->alt.prog.kernels[k], m->alt.fns[k], m->alt.argbuf[k], x, y, out, w, nullptr, nullptr);
+      rc = launch_one(m, m->alt.prog.kernels[k], m->alt.fns[k], m->alt.argbuf[k], x, y, out, w, nullptr, nullptr);
       if (rc) return rc;
     }
-  return IEM_OK;
+  return halo_after(m);
 }
 
 // jac_coord! / hess_coord! through the tuner (struct Alt): the first IEM_TUNE_CALLS calls into an output buffer
@@ -688,6 +742,16 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "name_tag") == 0) { o.name_tag = (int)value; return IEM_OK; }
   if (std::strcmp(name, "lazy_all_kinds") == 0) { o.lazy_all_kinds = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune_min_blocks") == 0) { o.autotune_min_blocks = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "big_batch_slots") == 0) { o.big_batch_slots = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "big_batch_jac") == 0) { o.big_batch_jac = value; return IEM_OK; }
+  if (std::strcmp(name, "big_batch_hess") == 0) { o.big_batch_hess = value; return IEM_OK; }
+  if (std::strcmp(name, "pair_kernel") == 0) { o.pair_kernel = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "store_wait") == 0) { o.store_wait = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "comm_timeout_ms") == 0) {
+    if (value < 1 || value > 600000) return fail(IEM_E_ARG, "comm_timeout_ms must be in 1..600000");
+    o.comm_timeout_ms = (int)value;
+    return IEM_OK;
+  }
   return fail(IEM_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -880,8 +944,35 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
     }
   }
   if (hipMalloc((void **)&m->d_obj, 8) != hipSuccess) return bail(fail(IEM_E_HIP, "hipMalloc obj"));
-  if (hipHostMalloc((void **)&m->h_obj, 8, hipHostMallocMapped) != hipSuccess ||
+  if (hipHostMalloc((void **)&m->h_obj, 16, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&m->d_hobj, m->h_obj, 0) != hipSuccess) return bail(fail(IEM_E_HIP, "hipHostMalloc"));
+  m->h_status = reinterpret_cast<volatile unsigned long long *>(m->h_obj + 1);   // second word: comm time-outs (IemCommErr::hstatus)
+  m->d_hstatus = reinterpret_cast<unsigned long long *>(m->d_hobj + 1);
+  *m->h_status = 0;
+  if (m->sharded) {
+    // which kinds can touch a halo entry of x / of a variable-space v: from the live loads of the generated kernels
+    const auto &flag = m->shard.var_flag;
+    std::vector<int64_t> pre(flag.size() + 1, 0);
+    for (size_t i = 0; i < flag.size(); ++i) pre[i + 1] = pre[i] + ((flag[i] & 4) ? 1 : 0);
+    auto hits = [&](const std::vector<std::pair<int64_t, int64_t>> &rs) {
+      for (auto &r : rs) {
+        const int64_t lo = std::max<int64_t>(0, r.first), hi = std::min<int64_t>((int64_t)flag.size() - 1, r.second);
+        if (lo <= hi && pre[(size_t)hi + 1] - pre[(size_t)lo] > 0) return true;
+      }
+      return false;
+    };
+    for (const iem::KernelDesc &kd : m->prog.kernels) {
+      if (kd.kind < 0 || kd.kind > iem::KK_PAIR) continue;
+      m->reads_halo_x[kd.kind] = m->reads_halo_x[kd.kind] || hits(kd.x_ranges);
+      m->reads_halo_v[kd.kind] = m->reads_halo_v[kd.kind] || hits(kd.v_ranges);
+    }
+    // the exchange kernel is one workgroup that may spin on a peer's flag: its own stream, ahead of the evaluation kernels
+    int lo_pri = 0, hi_pri = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess) { (void)hipGetLastError(); hi_pri = 0; }
+    if (hipStreamCreateWithPriority(&m->comm_stream, hipStreamNonBlocking, hi_pri) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_x, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_halo, hipEventDisableTiming) != hipSuccess) return bail(fail(IEM_E_HIP, "comm stream / events"));
+  }
   if ((rc = prepare_program(m, m->prog, m->d_tables, m->argbuf)) != IEM_OK) return bail(rc);
   // second code object for the tuner: only for block-store models with a large jac/hess grid (below ~2e5 supports
   // the larger batch loses), never for the experiment knobs
@@ -909,7 +1000,10 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
     // stream): one memset launch instead of two around pandemic's u(t) slab (grad! 11.5 -> 6 us of memsets)
     auto &zr = m->zero_ranges[kind];
     for (auto &z : m->prog.zero_ranges[kind]) {
-      if (!zr.empty() && z.first - zr.back().second <= std::max<int64_t>(8192, (z.second - zr.front().first) / 16)) zr.back().second = z.second;
+      // the gap is measured against the two NEIGHBOURING ranges (never the whole span so far) and capped: a memset
+      // never swallows more than 64 K doubles that a kernel is about to overwrite anyway
+      const int64_t near = zr.empty() ? 0 : std::min<int64_t>(65536, std::max<int64_t>(8192, ((zr.back().second - zr.back().first) + (z.second - z.first)) / 16));
+      if (!zr.empty() && z.first - zr.back().second <= near) zr.back().second = z.second;
       else zr.push_back(z);
     }
   }
@@ -935,6 +1029,9 @@ int iem_destroy(iem_model *m) {
   if (m->d_halo_dst) hipFree(m->d_halo_dst);
   if (m->d_shared) hipFree(m->d_shared);
   if (m->h_obj) hipHostFree(m->h_obj);
+  if (m->comm_stream) { hipStreamSynchronize(m->comm_stream); hipStreamDestroy(m->comm_stream); }
+  if (m->ev_x) hipEventDestroy(m->ev_x);
+  if (m->ev_halo) hipEventDestroy(m->ev_halo);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
   for (void *t : m->d_tables) if (t) hipFree(t);
   for (void *t : m->alt.d_tables) if (t) hipFree(t);
@@ -1016,8 +1113,9 @@ int iem_set_stream(iem_model *m, void *hip_stream) {
 int iem_synchronize(iem_model *m) {
   if (!m) return fail(IEM_E_ARG, "null handle");
   DevGuard dg_(m->device);
+  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }   // the asynchronous exchange belongs to what the caller waits for
   HIP_TRY(hipStreamSynchronize(m->stream));
-  return IEM_OK;
+  return comm_check(m);
 }
 
 int iem_set_parameter(iem_model *m, int64_t off, int64_t len, const double *h_vals) {
@@ -1041,31 +1139,51 @@ int iem_obj_device(iem_model *m, const double *d_x, double *d_out) {
   return launch_kind(m, iem::KK_OBJ, d_x, nullptr, m->d_partials, 0.0, nullptr, d_out);
 }
 
-int iem_obj(iem_model *m, const double *d_x, double *h_out) {
-  if (!m || !h_out) return fail(IEM_E_ARG, "null argument");
-  if (m->prog.n_partials == 0) { *h_out = 0.0; return d_x ? IEM_OK : fail(IEM_E_ARG, "null argument"); }
-  // The last workgroup writes the scalar straight into mapped pinned host memory.  The host does
-  // not wait for the STREAM (hipStreamSynchronize costs ~12 us on top of a ~7 us kernel): it arms
-  // the slot with a sentinel NaN and polls it; the 8-byte store is atomic, so the first value that
-  // is not the sentinel is the result.  After ~200 us of polling (large models, or a result that
-  // happens to BE the sentinel) it falls back to synchronising the stream.
-  static const uint64_t kSentinel = 0x7ff8dead0bad0b1eULL;
-  volatile uint64_t *slot = reinterpret_cast<volatile uint64_t *>(m->h_obj);
-  *slot = kSentinel;
+// The objective as a host scalar, in two halves (a solver that evaluates obj, grad!, cons!, jac_coord!, hess_coord! at one
+// point — ext/InfiniteExaModelsIpopt.jl:48-49 — needs the VALUE only after the five launches are enqueued):
+//   iem_obj_begin   arms the mapped host slot with a sentinel NaN and enqueues the objective kernel; returns at once
+//   iem_obj_end     waits for the slot (polling, ~200 us, then a stream synchronise) and returns the value
+// The last workgroup writes the scalar straight into mapped pinned host memory; the 8-byte store is atomic, so the first
+// value that is not the sentinel is the result.  iem_obj = begin + end (the host round trip of one launch: ~14 us).
+static const uint64_t kObjSentinel = 0x7ff8dead0bad0b1eULL;
+
+int iem_obj_begin(iem_model *m, const double *d_x) {
+  if (!m || !d_x) return fail(IEM_E_ARG, "null argument");
+  if (m->obj_armed) return fail(IEM_E_ARG, "iem_obj_begin: the previous iem_obj_begin has not been collected (iem_obj_end)");
+  if (m->prog.n_partials == 0) { m->obj_armed = true; return IEM_OK; }
+  *reinterpret_cast<volatile uint64_t *>(m->h_obj) = kObjSentinel;
   int rc = iem_obj_device(m, d_x, m->d_hobj);
   if (rc) return rc;
+  m->obj_armed = true;
+  return IEM_OK;
+}
+
+int iem_obj_end(iem_model *m, double *h_out) {
+  if (!m || !h_out) return fail(IEM_E_ARG, "null argument");
+  if (!m->obj_armed) return fail(IEM_E_ARG, "iem_obj_end without iem_obj_begin");
+  m->obj_armed = false;
+  if (m->prog.n_partials == 0) { *h_out = 0.0; return comm_check(m); }
+  DevGuard dg_(m->device);
+  volatile uint64_t *slot = reinterpret_cast<volatile uint64_t *>(m->h_obj);
   bool got = false;
   if (m->poll_obj) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int spin = 0;; ++spin) {
-      if (*slot != kSentinel) { got = true; break; }
+      if (*slot != kObjSentinel) { got = true; break; }
       if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
     }
   }
-  if (!got) HIP_TRY(hipStreamSynchronize(m->stream));
+  if (!got) HIP_TRY(hipStreamSynchronize(m->stream));   // large models, or a result that happens to BE the sentinel
   uint64_t bits = *slot;
   std::memcpy(h_out, &bits, 8);
-  return IEM_OK;
+  return comm_check(m);
+}
+
+int iem_obj(iem_model *m, const double *d_x, double *h_out) {
+  if (!m || !h_out) return fail(IEM_E_ARG, "null argument");
+  int rc = iem_obj_begin(m, d_x);
+  if (rc) return rc;
+  return iem_obj_end(m, h_out);
 }
 
 int iem_grad(iem_model *m, const double *d_x, double *d_g) {
@@ -1117,6 +1235,25 @@ int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double ob
   if (!m || !d_x || (!d_y && m->model.ncon) || (!d_vals && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
   DevGuard dg_(m->device);
   return launch_tuned(m, 1, iem::KK_HESS, d_x, d_y, d_vals, obj_weight);
+}
+
+/* jac_coord!(m, x, jac) and hess_coord!(m, x, y, hess; obj_weight) in ONE launch (kernel kind KK_PAIR): the two calls are
+ * independent given x and y, so their workgroups share a launch — one ramp and one drain, and on a shard-sized grid both
+ * kinds are resident together.  Identical bytes to the two separate calls.  Handles without a fused kernel (option
+ * "pair_kernel" = 0, or only one of the two kinds exists) make the two calls. */
+int iem_jac_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_jac, double *d_hess) {
+  if (!m || !d_x || (!d_y && m->model.ncon) || (!d_jac && m->model.nnzj) || (!d_hess && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    if (m->prog.kernels[k].kind == iem::KK_PAIR) {
+      int rc = halo_before(m, iem::KK_PAIR, d_x, nullptr);
+      if (rc == IEM_OK) rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], d_x, d_y, d_jac, obj_weight, nullptr, d_hess);
+      if (rc == IEM_OK) rc = halo_after(m);
+      return rc;
+    }
+  int rc = iem_jac_coord(m, d_x, d_jac);
+  if (rc == IEM_OK) rc = iem_hess_coord(m, d_x, d_y, obj_weight, d_hess);
+  return rc;
 }
 
 int iem_jac_structure(iem_model *m, int64_t *h_rows, int64_t *h_cols, int base) {
@@ -1218,7 +1355,19 @@ struct CommHandle {   // what iem_comm_export writes (IEM_COMM_HANDLE_BYTES)
   int64_t words;
   uint64_t local_ptr;
   char bus[16];       // PCI bus id of the GPU the mailbox lives on ("0000:05:00.0"): device ordinals are per process
+  uint64_t nonce;     // per-process random word: "same process" = same pid AND same nonce (pids repeat across PID namespaces)
 };
+
+uint64_t process_nonce() {
+  static uint64_t n = 0;
+  if (n == 0) {
+    uint64_t v = 0;
+    if (FILE *f = std::fopen("/dev/urandom", "rb")) { if (std::fread(&v, 8, 1, f) != 1) v = 0; std::fclose(f); }
+    if (v == 0) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ULL ^ ((uint64_t)getpid() << 32);
+    n = v | 1;
+  }
+  return n;
+}
 static_assert(sizeof(CommHandle) <= IEM_COMM_HANDLE_BYTES, "comm handle too large");
 
 }  // namespace
@@ -1334,6 +1483,7 @@ int iem_comm_export(iem_model *m, void *out_handle) {
   h.pid = (int32_t)getpid(); h.device = m->device; h.rank = si.rank; h.world = si.world; h.words = (int64_t)m->mailbox_words;
   h.kind = m->mailbox_kind;
   h.local_ptr = (uint64_t)(uintptr_t)m->mailbox;
+  h.nonce = process_nonce();
   {
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, m->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
@@ -1353,6 +1503,20 @@ int iem_comm_connect(iem_model *m, const void *all_handles) {
   m->peers.assign((size_t)si.world, nullptr);
   CommHandle mine;
   std::memcpy(&mine, (const char *)all_handles + (size_t)si.rank * IEM_COMM_HANDLE_BYTES, sizeof mine);
+  {
+    // One process may drive several handles (one per GPU).  More than two on ONE device cannot work: their exchange
+    // kernels spin on each other's flags and the streams of one process share hardware queues from the third on, so
+    // a spinning kernel starves the peer it waits for (each call would end in the bounded time-out).  Refused here.
+    int same = 0;
+    for (int r = 0; r < si.world; ++r) {
+      CommHandle h;
+      std::memcpy(&h, (const char *)all_handles + (size_t)r * IEM_COMM_HANDLE_BYTES, sizeof h);
+      if (h.pid == mine.pid && h.nonce == mine.nonce && std::strncmp(h.bus, mine.bus, sizeof h.bus) == 0) ++same;
+    }
+    if (same > 2)
+      return fail(IEM_E_ARG, "iem_comm_connect: " + std::to_string(same) + " ranks of this communicator are handles of ONE process on ONE device; "
+                             "at most two can exchange (one process per GPU is the supported form)");
+  }
   for (int r = 0; r < si.world; ++r) {
     CommHandle h;
     std::memcpy(&h, (const char *)all_handles + (size_t)r * IEM_COMM_HANDLE_BYTES, sizeof h);
@@ -1364,7 +1528,7 @@ int iem_comm_connect(iem_model *m, const void *all_handles) {
       return fail(IEM_E_HIP, "iem_comm_connect: this runtime gave no fine-grained IPC memory for the mailboxes; "
                              "ranks on different GPUs cannot use them — fall back to the host's collective (RCCL) for obj/grad and copy the halo");
     if (r == si.rank) { m->peers[r] = m->mailbox; continue; }
-    if (h.pid == (int32_t)getpid()) {   // same process (one process driving several handles): the pointer itself
+    if (h.pid == (int32_t)getpid() && h.nonce == process_nonce()) {   // same process (one process driving several handles): the pointer itself
       if ((int)h.device != m->device) {
         hipError_t e = hipDeviceEnablePeerAccess((int)h.device, 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(IEM_E_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
@@ -1406,18 +1570,56 @@ int iem_comm_connect(iem_model *m, const void *all_handles) {
   return IEM_OK;
 }
 
+static int halo_launch(iem_model *m, double *d_x, hipStream_t stream) {
+  const iem::ShardInfo &si = m->shard;
+  struct { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G; unsigned long long *hstatus; long long ticks; } A = {
+      d_x, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
+      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared),
+      m->d_hstatus, (long long)m->opt.comm_timeout_ms * 100000LL};
+  size_t sz = sizeof A;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, stream, nullptr, cfg));
+  return IEM_OK;
+}
+
 int iem_halo_exchange(iem_model *m, double *d_x) {
   if (!m || !d_x) return fail(IEM_E_ARG, "null argument");
   if (!m->connected) return fail(IEM_E_ARG, "iem_halo_exchange: not connected (iem_comm_connect)");
   const iem::ShardInfo &si = m->shard;
   if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;   // no stencil crosses the shard boundary
   DevGuard dg_(m->device);
-  struct { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G; } A = {
-      d_x, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
-      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared)};
-  size_t sz = sizeof A;
-  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
+  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }   // one exchange at a time (the mailbox has two parity slots)
+  return halo_launch(m, d_x, m->stream);
+}
+
+int iem_halo_exchange_async(iem_model *m, double *d_x) {
+  if (!m || !d_x) return fail(IEM_E_ARG, "null argument");
+  if (!m->connected) return fail(IEM_E_ARG, "iem_halo_exchange_async: not connected (iem_comm_connect)");
+  const iem::ShardInfo &si = m->shard;
+  if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;
+  DevGuard dg_(m->device);
+  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }
+  // behind everything enqueued so far on the handle's stream (the producer of x), concurrent with what follows
+  HIP_TRY(hipEventRecord(m->ev_x, m->stream));
+  HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->ev_x, 0));
+  int rc = halo_launch(m, d_x, m->comm_stream);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(m->ev_halo, m->comm_stream));
+  m->halo_pending = true;
+  m->halo_vec = d_x;
+  return IEM_OK;
+}
+
+int iem_halo_wait(iem_model *m) {
+  if (!m) return fail(IEM_E_ARG, "null handle");
+  DevGuard dg_(m->device);
+  return halo_after(m);
+}
+
+int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v) {
+  if (!m || kind < 0 || kind > iem::KK_PAIR) return fail(IEM_E_ARG, "bad argument");
+  if (out_x) *out_x = m->reads_halo_x[kind] ? 1 : 0;
+  if (out_v) *out_v = m->reads_halo_v[kind] ? 1 : 0;
   return IEM_OK;
 }
 
@@ -1427,10 +1629,11 @@ int iem_halo_fold(iem_model *m, double *d_vec) {
   const iem::ShardInfo &si = m->shard;
   if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;
   DevGuard dg_(m->device);
-  struct { double *vec; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G, NR; } A = {
+  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }
+  struct { double *vec; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G, NR; unsigned long long *hstatus; long long ticks; } A = {
       d_vec, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
       m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared),
-      (long long)(1 + m->n_shared)};
+      (long long)(1 + m->n_shared), m->d_hstatus, (long long)m->opt.comm_timeout_ms * 100000LL};
   size_t sz = sizeof A;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fn_fold, 1, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
@@ -1444,8 +1647,9 @@ int iem_allreduce_obj_grad(iem_model *m, double *d_obj, double *d_g) {
   DevGuard dg_(m->device);
   const iem::ShardInfo &si = m->shard;
   const long long G = (long long)reduce_chunks(1 + m->n_shared);
-  struct { double *obj, *g; const long long *shared; unsigned long long *const *peers; long long NR, NH, W, rank, G; } A = {
-      d_obj, d_g, m->d_shared, m->d_peers, (long long)(1 + m->n_shared), (long long)si.halo_doubles, (long long)si.world, (long long)si.rank, G};
+  struct { double *obj, *g; const long long *shared; unsigned long long *const *peers; long long NR, NH, W, rank, G; unsigned long long *hstatus; long long ticks; } A = {
+      d_obj, d_g, m->d_shared, m->d_peers, (long long)(1 + m->n_shared), (long long)si.halo_doubles, (long long)si.world, (long long)si.rank, G,
+      m->d_hstatus, (long long)m->opt.comm_timeout_ms * 100000LL};
   size_t sz = sizeof A;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(m->fn_reduce, (unsigned)G, 1, 1, 256, 1, 1, 0, m->stream, nullptr, cfg));
@@ -1456,6 +1660,7 @@ int iem_comm_status(iem_model *m, int64_t *out_status) {
   if (!m || !out_status) return fail(IEM_E_ARG, "null argument");
   if (!m->mailbox) return fail(IEM_E_ARG, "no mailbox");
   DevGuard dg_(m->device);
+  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(m->stream));
   unsigned long long st = 0;
   HIP_TRY(hipMemcpy(&st, m->mailbox, 8, hipMemcpyDeviceToHost));

@@ -1316,6 +1316,7 @@ class KernelBuilder {
       if (pending_flush.empty()) return;
       tail << "  __syncthreads();\n";
       for (auto &f : pending_flush) tail << f;
+      if (opt_.store_wait) tail << "  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n";
       tail << "  __syncthreads();\n";
       pending_flush.clear();
       batch_slots = 0;
@@ -1529,6 +1530,13 @@ class KernelBuilder {
       if (!iv.ind.empty()) { lo = 0; hi = g_.ext[0] * g_.ext[1] * g_.ext[2] - 1; }
       int akey = l.arr == 3 ? 100 + l.slot : l.arr;   // 0 x, 1 theta, 2 y, 4 v, 100+ item columns
       ranges_[akey].emplace_back(lo, hi);
+      // what a sharded handle needs to know: can this kernel touch a halo entry of x (or of a variable-space v)?
+      const bool var_space_v = l.arr == 4 && (kind_ == KK_JPROD || kind_ == KK_HPROD);
+      if (l.arr == 0 || var_space_v) {
+        auto &dst = l.arr == 0 ? kd.x_ranges : kd.v_ranges;
+        if (iv.ind.empty()) dst.emplace_back(lo, hi);
+        else dst.emplace_back(0, std::max<int64_t>(m_.nvar, 1) - 1);   // a gathered index: anywhere
+      }
     }
     {
       int64_t elems = 0;
@@ -1855,6 +1863,29 @@ static int choose_block(const Model &m, const Options &opt) {
   return lanes[1] < lanes[0] - 0.02 * items ? 256 : 512;
 }
 
+// workgroups of a kernel over support grid g that advances `qs` grid points per workgroup along dim 0
+static void launch_grid(const Group &g, int64_t qs, KernelDesc &kd) {
+  kd.grid[0] = (g.ext[0] + qs - 1) / qs; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
+  if (g.flat) { kd.grid[0] = (g.ext[0] * g.ext[1] * g.ext[2] + qs - 1) / qs; kd.grid[1] = kd.grid[2] = 1; }
+  if (!g.flat && g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
+  kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
+}
+
+// The options one kernel is generated with: the handle's, except that jac_coord! / hess_coord! of a LARGE grid stage
+// Options::big_batch_slots values per barrier pair — one 96-KB workgroup per CU instead of three 48-KB ones.  The choice
+// is a function of the kind and the grid size alone (Options::big_batch_jac / big_batch_hess workgroups), so that a
+// handle's code never depends on a timer or on the process it runs in.
+static Options kind_options(const Options &opt, const Group &g, int kind) {
+  Options ko = opt;
+  if ((kind != KK_JAC && kind != KK_HESS) || opt.store_mode != 2 || opt.no_fuse || opt.big_batch_slots <= opt.lds_slots) return ko;
+  const int64_t thr = kind == KK_JAC ? opt.big_batch_jac : opt.big_batch_hess;
+  if (thr <= 0) return ko;
+  KernelDesc probe;
+  launch_grid(g, (opt.overlap && opt.block >= 256) ? opt.block - 16 : opt.block, probe);
+  if (probe.n_blocks >= thr) ko.lds_slots = opt.big_batch_slots;
+  return ko;
+}
+
 Program generate(const Model &m, const Options &opt_in) {
   validate_indices(m);
   Options opt = opt_in;
@@ -1892,6 +1923,7 @@ Program generate(const Model &m, const Options &opt_in) {
   std::vector<GSlot> gslots;
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
+  std::vector<Options> kopts;   // the options each builder was made with (kind_options)
 
   auto is_scatter = [](int kind) { return kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD; };
   // a handle's second code object (the tuner's large store batch) carries a tag in its kernel names, so that a
@@ -1905,18 +1937,16 @@ Program generate(const Model &m, const Options &opt_in) {
     for (int kind = 0; kind < KK_COUNT; ++kind) {
       if (split && is_scatter(kind) != (pass == 1)) continue;   // pass 1: the scatter kinds on the fused groups
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi) + name_tag;
-      auto kb = std::make_unique<KernelBuilder>(m, g, kind, opt, name);
+      const Options ko = kind_options(opt, g, kind);
+      auto kb = std::make_unique<KernelBuilder>(m, g, kind, ko, name);
       if (!kb->build(nullptr)) continue;
       if (kind == KK_HESS && opt.hess_merge) kb->merge_hess(P.nnzh_merged, P.hess_classes);
       KernelDesc kd;
       kd.name = name;
       kd.kind = kind;
       kd.block = opt.block;
-      const int64_t qs = kb->qstep();
-      kd.grid[0] = (g.ext[0] + qs - 1) / qs; kd.grid[1] = g.ext[1]; kd.grid[2] = g.ext[2];
-      if (g.flat) { kd.grid[0] = (g.ext[0] * g.ext[1] * g.ext[2] + qs - 1) / qs; kd.grid[1] = kd.grid[2] = 1; }
-      if (!g.flat && g.nd == 2 && g.ext[1] > 65535) { kd.grid[1] = 65535; kd.grid[2] = (g.ext[1] + 65534) / 65535; }
-      kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
+      kd.lds_slots = ko.lds_slots;
+      launch_grid(g, kb->qstep(), kd);
       if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {
         auto &outs = kb->outputs();
         for (size_t oi = 0; oi < outs.size(); ++oi) {
@@ -1961,6 +1991,7 @@ Program generate(const Model &m, const Options &opt_in) {
       }
       builders.push_back(std::move(kb));
       descs.push_back(kd);
+      kopts.push_back(ko);
     }
   }
   bool accumulates[KK_COUNT] = {};
@@ -2256,6 +2287,9 @@ Program generate(const Model &m, const Options &opt_in) {
       F.grid[0] += d.n_blocks;
       F.lds_bytes = std::max(F.lds_bytes, d.lds_bytes);
       F.alg_bytes_read += d.alg_bytes_read; F.alg_bytes_written += d.alg_bytes_written;
+      F.x_ranges.insert(F.x_ranges.end(), d.x_ranges.begin(), d.x_ranges.end());
+      F.v_ranges.insert(F.v_ranges.end(), d.v_ranges.begin(), d.v_ranges.end());
+      F.lds_slots = std::max(F.lds_slots, d.lds_slots);
     }
     if (F.grid[0] > 2147483647LL) throw std::runtime_error("support grids too large for one launch");
     const int64_t n_tiles = F.grid[0];
@@ -2378,6 +2412,107 @@ Program generate(const Model &m, const Options &opt_in) {
     if (si) src << KernelBuilder::shared_epilogue(*si, "A.ip + " + std::to_string(sh_tbl), "wg_", "lds_blk", sh_lds);
     src << "}\n\n";
     P.kernels.push_back(F);
+  }
+  // jac_coord! + hess_coord! in ONE launch (KK_PAIR; iem_jac_hess_coord).  The two calls are independent given x (and y):
+  // behind one workgroup-id dispatcher their bodies share a launch — one ramp and one drain instead of two, and on a grid
+  // of about one workgroup per CU (a 1/8 shard of the headline problem: 252 + 252 workgroups) both kinds are resident
+  // together, 16 waves per CU instead of 8.  `out` = Jacobian values, `aux` = Hessian values; every body is generated
+  // again by a builder of its own (a builder emits once), with the options its stand-alone twin got.
+  if (opt.pair_kernel && !opt.no_fuse) {
+    std::vector<size_t> ks;
+    bool have[2] = {false, false};
+    for (size_t k = 0; k < descs.size(); ++k)
+      if (descs[k].kind == KK_JAC || descs[k].kind == KK_HESS) { ks.push_back(k); have[descs[k].kind == KK_HESS] = true; }
+    if (have[0] && have[1]) {
+      std::vector<std::unique_ptr<KernelBuilder>> pb;
+      std::vector<KernelDesc> pd;
+      int64_t nnz_again = 0;
+      std::vector<HessClass> classes_again;
+      for (size_t k : ks) {   // in the order of the first pass: the merged Hessian layout's offsets are running counters
+        KernelDesc kd;
+        kd.name = descs[k].name + "_p"; kd.kind = descs[k].kind; kd.block = descs[k].block; kd.lds_slots = descs[k].lds_slots;
+        for (int d = 0; d < 3; ++d) kd.grid[d] = descs[k].grid[d];
+        kd.n_blocks = descs[k].n_blocks;
+        auto kb = std::make_unique<KernelBuilder>(m, builders[k]->group(), kd.kind, kopts[k], kd.name);
+        if (!kb->build(nullptr)) throw std::runtime_error("internal: pair body without outputs");
+        if (kd.kind == KK_HESS && opt.hess_merge) kb->merge_hess(nnz_again, classes_again);
+        pb.push_back(std::move(kb));
+        pd.push_back(kd);
+      }
+      std::vector<size_t> ord(pd.size());
+      for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return pd[a].n_blocks > pd[b].n_blocks; });
+      KernelDesc F;
+      F.name = std::string("iem_pair_all") + name_tag;
+      F.kind = KK_PAIR; F.block = opt.block;
+      F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
+      std::vector<size_t> oip, odp, ofa, oia;
+      for (size_t j : ord) {
+        src << pb[j]->emit(pd[j], true);
+        const KernelDesc &d = pd[j];
+        oip.push_back(F.ip.size()); odp.push_back(F.dp.size()); ofa.push_back(F.fa.size()); oia.push_back(F.ia.size());
+        F.ip.insert(F.ip.end(), d.ip.begin(), d.ip.end());
+        F.dp.insert(F.dp.end(), d.dp.begin(), d.dp.end());
+        F.fa.insert(F.fa.end(), d.fa.begin(), d.fa.end());
+        F.ia.insert(F.ia.end(), d.ia.begin(), d.ia.end());
+        F.grid[0] += d.n_blocks;
+        F.lds_bytes = std::max(F.lds_bytes, d.lds_bytes);
+        F.alg_bytes_read += d.alg_bytes_read; F.alg_bytes_written += d.alg_bytes_written;
+        F.x_ranges.insert(F.x_ranges.end(), d.x_ranges.begin(), d.x_ranges.end());
+        F.lds_slots = std::max(F.lds_slots, d.lds_slots);
+      }
+      if (F.grid[0] <= 2147483647LL) {   // (larger: the two calls stay separate launches)
+        F.n_blocks = F.grid[0];
+        const size_t dec = F.ip.size();
+        int64_t first = 0;
+        for (size_t j : ord) {
+          F.ip.push_back(first); F.ip.push_back(pd[j].grid[0]); F.ip.push_back(pd[j].grid[1]); F.ip.push_back(pd[j].grid[2]);
+          first += pd[j].n_blocks;
+        }
+        const size_t tbl = F.ip.size();
+        const bool table = ord.size() > 4 && F.grid[0] <= (1 << 18);   // many bodies (templates side by side): workgroup -> body table, one scalar load
+        if (table)
+          for (size_t jj = 0; jj < ord.size(); ++jj) F.ip.insert(F.ip.end(), (size_t)pd[ord[jj]].n_blocks, (int64_t)jj);
+        const size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
+        const size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
+        F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > tbl;
+        src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
+        if (F.tables_in_memory)
+          src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
+        else
+          src << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
+        src << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt.min_waves > 0 ? ", " + std::to_string(opt.min_waves) : std::string())
+            << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
+        if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
+        else src << "  double* lds_blk = nullptr;\n";
+        src << "  double* lds4 = nullptr;\n  const long long b = blockIdx.x;\n";
+        auto call = [&](size_t jj, const std::string &ind) {
+          const KernelDesc &d = pd[ord[jj]];
+          std::ostringstream c;
+          c << ind << d.name << "_body(A.x, A.th, A.y, A.v, " << (d.kind == KK_JAC ? "A.out" : "A.aux") << ", A.w, nullptr, A.ip + " << oip[jj] << ", A.dp + " << odp[jj]
+            << ", A.fa + " << ofa[jj] << ", A.ia + " << oia[jj] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n";
+          return c.str();
+        };
+        if (ord.size() > 4) {
+          if (table) src << "  const int lo_ = (int)A.ip[" << tbl << " + b];\n";
+          else src << "  int lo_ = 0, hi_ = " << ord.size() << ";\n"
+                   << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n";
+          src << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
+              << "  const long long lb = b - A.ip[" << dec << " + 4 * lo_];\n  switch (lo_) {\n";
+          for (size_t jj = 0; jj < ord.size(); ++jj) src << "    case " << jj << ":\n" << call(jj, "      ") << "      break;\n";
+          src << "  }\n";
+        } else
+          for (size_t jj = 0; jj < ord.size(); ++jj) {
+            const size_t e = dec + 4 * jj;
+            src << "  " << (jj ? "else " : "");
+            if (jj + 1 < ord.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
+            src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
+                << "    const long long lb = b - A.ip[" << e << "];\n" << call(jj, "    ") << "  }\n";
+          }
+        src << "}\n\n";
+        P.kernels.push_back(F);
+      }
+    }
   }
   P.source = src.str();
   P.key = fnv1a64(P.source);

@@ -9,7 +9,10 @@
 
 namespace iem {
 
-enum KernelKind { KK_CONS = 0, KK_JAC = 1, KK_HESS = 2, KK_OBJ = 3, KK_GRAD = 4, KK_JPROD = 5, KK_JTPROD = 6, KK_HPROD = 7, KK_COUNT = 8 };
+enum KernelKind { KK_CONS = 0, KK_JAC = 1, KK_HESS = 2, KK_OBJ = 3, KK_GRAD = 4, KK_JPROD = 5, KK_JTPROD = 6, KK_HPROD = 7, KK_COUNT = 8,
+                  // jac_coord! + hess_coord! in ONE launch (iem_jac_hess_coord): the bodies of both kinds behind one workgroup-id
+                  // dispatcher; `out` = the Jacobian values, `aux` = the Hessian values.  Not a per-kind table index (KK_COUNT stays 8).
+                  KK_PAIR = 8 };
 
 struct KernelDesc {
   std::string name;
@@ -27,6 +30,11 @@ struct KernelDesc {
   int64_t n_blocks = 1;
   // bookkeeping for the roofline line
   int64_t alg_bytes_read = 0, alg_bytes_written = 0;
+  // 0-based index ranges [lo, hi] of x (and of v, for the kinds whose v lives in variable space) the kernel's LIVE loads
+  // can touch over its launch domain — a sharded handle derives from them which kinds read a halo entry, i.e. which
+  // calls must wait for an asynchronous halo exchange (iem_halo_exchange_async) and which may overlap it
+  std::vector<std::pair<int64_t, int64_t>> x_ranges, v_ranges;
+  int lds_slots = 0;        // the staging batch this kernel was generated with (Options::lds_slots or its large-grid override)
 };
 
 struct Options {
@@ -71,6 +79,16 @@ struct Options {
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)
   int obj_unroll = 1;  // 2: the objective's tile walk takes two tiles per trip (single-body kernels)
   int det_shared = 1;  // 1: scatter entries shared by many items are reduced deterministically (iem_shared_*), 0: one f64 atomic per wave
+  // Large grids stage a LARGER batch per barrier pair (one 96-KB workgroup per CU instead of three 48-KB ones: a third of
+  // the concurrently open store streams).  Chosen from the GRID SIZE, per kind, never from a timer: jac_coord! with its
+  // 18 narrow streams from `big_batch_jac` workgroups on (placement-insensitive there), hess_coord! from
+  // `big_batch_hess` on (its 7 wide streams only gain above the Infinity Cache).  0: never.
+  int big_batch_slots = 48;
+  int64_t big_batch_jac = 400, big_batch_hess = 4000;
+  int pair_kernel = 1;     // 1: also emit the fused jac_coord! + hess_coord! launch (KK_PAIR, iem_jac_hess_coord)
+  int store_wait = 0;      // experiment: s_waitcnt vmcnt(0) behind every flushed batch (paces a wave's outstanding stores)
+  // runtime only (the generator ignores them)
+  int comm_timeout_ms = 5000;   // bound of every mailbox wait (halo exchange / fold / all-reduce kernels)
 };
 
 // one block of the merged Hessian layout: `nslots` values per item, position o + nslots*k + s;

@@ -603,15 +603,16 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_gather_sum_kernel(do
 // bytes for the all-reduce, 8*reach doubles per sharded slab for the halo).  All traffic is
 // system-scope (write-through stores, cache-bypassing loads); data is ordered before its flag by
 // vmcnt(0) on every storing thread, a workgroup barrier and a system release fence.  Every wait is
-// bounded (IEM_COMM_TIMEOUT ticks of the 100 MHz wall clock): on expiry the kernel records an error
-// in the mailbox's status word and RUNS ON — no wave ever spins forever.  Sequence numbers live in
+// bounded (option "comm_timeout_ms", default 5 s, counted on the 100 MHz wall clock): on expiry the kernel records
+// an error (IemCommErr), POISONS what it was to deliver — NaN into the halo entries / the folded entries / the
+// objective and the replicated gradient entries, so nothing downstream can consume stale data silently — and
+// RUNS ON: no wave ever spins forever.  Sequence numbers live in
 // the mailbox and are advanced by the kernels themselves, so both calls can be graph-replayed.
 //
 // mailbox words (8 bytes each):   [0] status  [1] halo seq  [3] halo ack (from the right)
 //   [4,6) halo flags (from the left, one per parity)   [8, 8+G) all-reduce seq per chunk
 //   [8+G, 8+G+2WG) all-reduce flags [parity][peer][chunk]
 //   then halo data [2][NH] and all-reduce data [2][W][NR]     (W = world, G = chunks, NH, NR as passed)
-#define IEM_COMM_TIMEOUT 500000000LL   // 5 s
 #define IEM_MB_STATUS 0
 #define IEM_MB_HSEQ 1
 #define IEM_MB_HACK 3
@@ -632,14 +633,26 @@ __device__ __forceinline__ void iem_sys_store(unsigned long long *p, unsigned lo
 }
 __device__ __forceinline__ double iem_sys_loadd(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void iem_sys_stored(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// bounded wait until *p >= want; false (and the status bit set) on time-out
-__device__ __forceinline__ bool iem_wait_ge(const unsigned long long *p, unsigned long long want, unsigned long long *status,
+// Where a time-out is recorded: the mailbox's status word (device memory; iem_comm_status) and a word of mapped
+// host memory the library's next host synchronisation point reads WITHOUT a copy (iem_obj, iem_obj_end,
+// iem_synchronize return IEM_E_COMM and clear both).  `ticks`: the bound in ticks of the 100 MHz wall clock.
+struct IemCommErr {
+  unsigned long long *status;    // mailbox word 0
+  unsigned long long *hstatus;   // mapped pinned host word (may be nullptr)
+  long long ticks;
+};
+__device__ __forceinline__ void iem_comm_fail(const IemCommErr &E, unsigned long long err_bit) {
+  const unsigned long long old = __hip_atomic_fetch_or(E.status, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (E.hstatus) __hip_atomic_store(E.hstatus, old | err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// bounded wait until *p >= want; false (and the error recorded) on time-out
+__device__ __forceinline__ bool iem_wait_ge(const unsigned long long *p, unsigned long long want, const IemCommErr &E,
                                             unsigned long long err_bit) {
   const long long t0 = wall_clock64();
   while (iem_sys_load(p) < want) {
     __builtin_amdgcn_s_sleep(4);
-    if (wall_clock64() - t0 > IEM_COMM_TIMEOUT) {
-      __hip_atomic_fetch_or(status, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (wall_clock64() - t0 > E.ticks) {
+      iem_comm_fail(E, err_bit);
       return false;
     }
   }
@@ -660,17 +673,19 @@ struct IemHaloArgs {
   unsigned long long *mine, *left, *right;   // mailboxes (left / right: nullptr at the ends of the chain)
   const long long *src, *dst;                // NH positions of x each: what goes right, where the left's arrive
   long long NH, W, G;
+  unsigned long long *hstatus; long long ticks;
 };
 // one workgroup: (1) my last `reach` owned supports of every sharded slab -> the right neighbour's
 // mailbox, (2) the left neighbour's -> the halo entries of my x (reference stencil:
 // /root/reference/src/transform.jl:535-557, index i-1 at :471-506)
 extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const IemHaloArgs A) {
+  const IemCommErr E = {A.mine + IEM_MB_STATUS, A.hstatus, A.ticks};
   const unsigned long long seq = iem_sys_load(A.mine + IEM_MB_HSEQ) + 1;
   const long long par = (long long)(seq & 1);
   __shared__ int ok_;
   if (A.right != nullptr) {
     if (threadIdx.x == 0)   // the slot of this parity was last used by seq - 2: the right neighbour must have consumed it
-      ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_HACK, seq - 2, A.mine + IEM_MB_STATUS, 1ULL);
+      ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_HACK, seq - 2, E, 1ULL);
     __syncthreads();
     double *data = reinterpret_cast<double *>(A.right + iem_mb_hdata(A.W, A.G)) + par * A.NH;
     for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) iem_sys_stored(data + e, A.x[A.src[e]]);
@@ -679,13 +694,12 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const Ie
   }
   if (A.left != nullptr) {
     if (threadIdx.x == 0) {
-      ok_ = iem_wait_ge(A.mine + IEM_MB_HFLAG + par, seq, A.mine + IEM_MB_STATUS, 2ULL);
+      ok_ = iem_wait_ge(A.mine + IEM_MB_HFLAG + par, seq, E, 2ULL);
       __threadfence_system();
     }
     __syncthreads();
     const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_hdata(A.W, A.G)) + par * A.NH;
-    if (ok_)
-      for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.x[A.dst[e]] = iem_sys_loadd(data + e);
+    for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.x[A.dst[e]] = ok_ ? iem_sys_loadd(data + e) : __builtin_nan("");   // time-out: poisoned, never stale
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) iem_sys_store(A.left + IEM_MB_HACK, seq);
@@ -704,14 +718,16 @@ struct IemFoldArgs {
   unsigned long long *mine, *left, *right;
   const long long *src, *dst;                // as in IemHaloArgs: src = my owned rows the right neighbour copies, dst = my halo copies
   long long NH, W, G, NR;
+  unsigned long long *hstatus; long long ticks;
 };
 extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_fold_kernel(const IemFoldArgs A) {
+  const IemCommErr E = {A.mine + IEM_MB_STATUS, A.hstatus, A.ticks};
   const unsigned long long seq = iem_sys_load(A.mine + IEM_MB_FSEQ) + 1;
   const long long par = (long long)(seq & 1);
   __shared__ int ok_;
   if (A.left != nullptr) {
     if (threadIdx.x == 0)
-      ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_FACK, seq - 2, A.mine + IEM_MB_STATUS, 8ULL);
+      ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_FACK, seq - 2, E, 8ULL);
     __syncthreads();
     double *data = reinterpret_cast<double *>(A.left + iem_mb_fdata(A.W, A.G, A.NH, A.NR)) + par * A.NH;
     for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) {
@@ -723,13 +739,12 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_fold_kernel(con
   }
   if (A.right != nullptr) {
     if (threadIdx.x == 0) {
-      ok_ = iem_wait_ge(A.mine + IEM_MB_FFLAG + par, seq, A.mine + IEM_MB_STATUS, 16ULL);
+      ok_ = iem_wait_ge(A.mine + IEM_MB_FFLAG + par, seq, E, 16ULL);
       __threadfence_system();
     }
     __syncthreads();
     const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_fdata(A.W, A.G, A.NH, A.NR)) + par * A.NH;
-    if (ok_)
-      for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.vec[A.src[e]] += iem_sys_loadd(data + e);
+    for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.vec[A.src[e]] = ok_ ? A.vec[A.src[e]] + iem_sys_loadd(data + e) : __builtin_nan("");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) iem_sys_store(A.right + IEM_MB_FACK, seq);
@@ -743,6 +758,7 @@ struct IemReduceArgs {
   const long long *shared;            // NR - 1 positions of g held by every rank (replicated variables)
   unsigned long long *const *peers;   // W mailboxes, peers[rank] = mine
   long long NR, NH, W, rank, G;
+  unsigned long long *hstatus; long long ticks;
 };
 // G workgroups, each on its own chunk of the NR doubles and with flags of its own (no cross-workgroup
 // step): my chunk -> slot [rank] of EVERY rank's mailbox; wait for the W flags of the chunk in mine; sum
@@ -750,6 +766,7 @@ struct IemReduceArgs {
 // back.  SURVEY 8(e): "one small all-reduce per obj / grad!" — one-shot direct writes, never a ring.
 extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_allreduce_kernel(const IemReduceArgs A) {
   unsigned long long *mine = A.peers[A.rank];
+  const IemCommErr E = {mine + IEM_MB_STATUS, A.hstatus, A.ticks};
   const long long c = blockIdx.x, G = A.G;
   const long long per = (A.NR + G - 1) / G, e0 = c * per, e1 = e0 + per < A.NR ? e0 + per : A.NR;
   const unsigned long long seq = iem_sys_load(mine + IEM_MB_RSEQ + c) + 1;
@@ -766,14 +783,17 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_allreduce_kernel(con
   if (threadIdx.x == 0) ok_ = 1;
   __syncthreads();
   for (long long p = threadIdx.x; p < A.W; p += IEM_BLOCK)
-    if (!iem_wait_ge(mine + iem_mb_rflag(G) + (par * A.W + p) * G + c, seq, mine + IEM_MB_STATUS, 4ULL)) ok_ = 0;
+    if (!iem_wait_ge(mine + iem_mb_rflag(G) + (par * A.W + p) * G + c, seq, E, 4ULL)) ok_ = 0;
   __threadfence_system();
   __syncthreads();
-  if (ok_) {
+  {
     const double *slots = reinterpret_cast<const double *>(mine + iem_mb_rdata(A.W, G, A.NH)) + par * A.W * A.NR;
     for (long long e = e0 + threadIdx.x; e < e1; e += IEM_BLOCK) {
-      double acc = iem_sys_loadd(slots + e);
-      for (long long p = 1; p < A.W; ++p) acc += iem_sys_loadd(slots + p * A.NR + e);
+      double acc = __builtin_nan("");   // a peer's contribution never arrived: the sum is poisoned, not skipped
+      if (ok_) {
+        acc = iem_sys_loadd(slots + e);
+        for (long long p = 1; p < A.W; ++p) acc += iem_sys_loadd(slots + p * A.NR + e);
+      }
       if (e == 0) { if (A.obj) *A.obj = acc; } else A.g[A.shared[e - 1]] = acc;
     }
   }

@@ -76,10 +76,10 @@ class KernelInfo(C.Structure):
 
 # every symbol include/iem.h declares (tests check the export list against the header)
 SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_info", "iem_shard_var_map", "iem_shard_template_info",
-           "iem_shard_template_items", "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_halo_fold", "iem_allreduce_obj_grad", "iem_comm_status",
+           "iem_shard_template_items", "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_halo_exchange_async", "iem_halo_wait", "iem_halo_reads", "iem_halo_fold", "iem_allreduce_obj_grad", "iem_comm_status",
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
-           "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_grad", "iem_cons",
-           "iem_jac_coord", "iem_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
+           "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_obj_begin", "iem_obj_end", "iem_grad", "iem_cons",
+           "iem_jac_coord", "iem_hess_coord", "iem_jac_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
@@ -126,6 +126,9 @@ def lib():
     L.iem_comm_export.argtypes = [vp, vp]
     L.iem_comm_connect.argtypes = [vp, vp]
     L.iem_halo_exchange.argtypes = [vp, vp]
+    L.iem_halo_exchange_async.argtypes = [vp, vp]
+    L.iem_halo_wait.argtypes = [vp]
+    L.iem_halo_reads.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.iem_halo_fold.argtypes = [vp, vp]
     L.iem_allreduce_obj_grad.argtypes = [vp, vp, vp]
     L.iem_comm_status.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -139,6 +142,9 @@ def lib():
     L.iem_set_parameter.argtypes = [vp, i64, i64, vp]
     L.iem_obj.argtypes = [vp, vp, C.POINTER(dbl)]
     L.iem_obj_device.argtypes = [vp, vp, vp]
+    L.iem_obj_begin.argtypes = [vp, vp]
+    L.iem_obj_end.argtypes = [vp, C.POINTER(dbl)]
+    L.iem_jac_hess_coord.argtypes = [vp, vp, vp, dbl, vp, vp]
     L.iem_grad.argtypes = [vp, vp, vp]
     L.iem_cons.argtypes = [vp, vp, vp]
     L.iem_jac_coord.argtypes = [vp, vp, vp]
@@ -172,7 +178,8 @@ def set_option(name: str, value: int):
 
 # generator knobs and their defaults (csrc/iem_codegen.hpp: struct Options)
 OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=0, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
-                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2, autotune=0, autotune_min_blocks=400, pull_scatter=1, det_axis=1, det_scatter=1, det_scatter_max=1 << 28, lazy_loads=2, lazy_min_loads=48, lazy_all_kinds=0, name_tag=0)
+                       min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2, autotune=0, autotune_min_blocks=400, pull_scatter=1, det_axis=1, det_scatter=1, det_scatter_max=1 << 28, lazy_loads=2, lazy_min_loads=48, lazy_all_kinds=0, name_tag=0,
+                       big_batch_slots=48, big_batch_jac=400, big_batch_hess=4000, pair_kernel=1, store_wait=0, comm_timeout_ms=5000)
 
 
 def option_array(opts: dict):

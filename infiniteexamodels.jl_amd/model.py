@@ -35,6 +35,9 @@ class MI355XBackend:
         return f"MI355XBackend(device={self.device}" + (f", shard={self.shard})" if self.shard else ")")
 
 
+KERNEL_KINDS = ("cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod", "pair")   # iem_kernel_info_t.kind
+
+
 def _ptr(t) -> int:
     if t is None:
         return 0
@@ -136,7 +139,7 @@ class ExaModel:
         for k in range(self.meta.n_kernels):
             ki = _lib.KernelInfo()
             _lib.check(self._L.iem_kernel_info(self._h, k, C.byref(ki)))
-            out.append(dict(name=ki.name.decode(), kind=("cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod")[ki.kind],
+            out.append(dict(name=ki.name.decode(), kind=KERNEL_KINDS[ki.kind],
                             grid=tuple(ki.grid), lds_bytes=int(ki.lds_bytes), jit=bool(ki.jit),
                             alg_bytes_read=int(ki.alg_bytes_read), alg_bytes_written=int(ki.alg_bytes_written)))
         return out
@@ -173,6 +176,20 @@ class ExaModel:
         _lib.check(self._L.iem_obj_device(self._h, _ptr(x), _ptr(out)))
         self.counters.neval_obj += 1
         return out
+
+    def obj_begin(self, x) -> None:
+        """First half of ``obj``: enqueue the objective kernel and return (``iem_obj_begin``).  A caller that evaluates
+        obj, grad!, cons!, jac_coord!, hess_coord! at one point calls this first and :meth:`obj_end` after its last
+        launch — the scalar's host round trip overlaps the other four calls."""
+        self._chk(x, self.meta.nvar, "x")
+        self._sync_stream()
+        _lib.check(self._L.iem_obj_begin(self._h, _ptr(x)))
+        self.counters.neval_obj += 1
+
+    def obj_end(self) -> float:
+        out = C.c_double()
+        _lib.check(self._L.iem_obj_end(self._h, C.byref(out)))
+        return float(out.value)
 
     def grad(self, x, g=None):
         """``grad!(m, x, g)``."""
@@ -214,6 +231,19 @@ class ExaModel:
         _lib.check(self._L.iem_hess_coord(self._h, _ptr(x), _ptr(y), float(obj_weight), _ptr(vals)))
         self.counters.neval_hess += 1
         return vals
+
+    def jac_hess_coord(self, x, y, jac=None, hess=None, obj_weight: float = 1.0):
+        """``jac_coord!(m, x, jac)`` and ``hess_coord!(m, x, y, hess; obj_weight)`` in ONE launch
+        (``iem_jac_hess_coord``): identical bytes to the two calls."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(y, self.meta.ncon, "y")
+        jac = jac if jac is not None else self._new(self.meta.nnzj)
+        hess = hess if hess is not None else self._new(self.meta.nnzh)
+        self._chk(jac, self.meta.nnzj, "jac"); self._chk(hess, self.meta.nnzh, "hess")
+        self._sync_stream()
+        _lib.check(self._L.iem_jac_hess_coord(self._h, _ptr(x), _ptr(y), float(obj_weight), _ptr(jac), _ptr(hess)))
+        self.counters.neval_jac += 1
+        self.counters.neval_hess += 1
+        return jac, hess
 
     def jprod(self, x, v, Jv=None):
         """``jprod!(m, x, v, Jv)``: Jacobian–vector product (ncon)."""
@@ -275,7 +305,7 @@ class ExaModel:
     def synchronize(self):
         _lib.check(self._L.iem_synchronize(self._h))
 
-    def raw_pair(self, x, y, jac, hess, obj_weight: float = 1.0):
+    def raw_pair(self, x, y, jac, hess, obj_weight: float = 1.0, fused: bool = False, halo: bool = False):
         """``step()`` closure for hot loops: one ``iem_jac_coord`` + one ``iem_hess_coord`` on fixed buffers with the
         Python-side argument checks and the stream lookup done ONCE here (what a compiled host — the Julia
         ``ccall`` shim — pays per call is the two C calls, not ~10 µs of interpreter work each)."""
@@ -285,11 +315,30 @@ class ExaModel:
         L, h = self._L, self._h
         px, py, pj, ph, w = _ptr(x), _ptr(y), _ptr(jac), _ptr(hess), float(obj_weight)
         jac_coord, hess_coord, check = L.iem_jac_coord, L.iem_hess_coord, _lib.check
+        pair, halo_async = L.iem_jac_hess_coord, L.iem_halo_exchange_async
 
-        def step():
-            rc = jac_coord(h, px, pj) or hess_coord(h, px, py, w, ph)
-            if rc:
-                check(rc)
+        # `fused`: the one-launch form (iem_jac_hess_coord); `halo`: every step first starts the asynchronous halo
+        # exchange of x (what a solver iteration, which moves x, adds around the pair on a sharded handle)
+        if fused and halo:
+            def step():
+                rc = halo_async(h, px) or pair(h, px, py, w, pj, ph)
+                if rc:
+                    check(rc)
+        elif fused:
+            def step():
+                rc = pair(h, px, py, w, pj, ph)
+                if rc:
+                    check(rc)
+        elif halo:
+            def step():
+                rc = halo_async(h, px) or jac_coord(h, px, pj) or hess_coord(h, px, py, w, ph)
+                if rc:
+                    check(rc)
+        else:
+            def step():
+                rc = jac_coord(h, px, pj) or hess_coord(h, px, py, w, ph)
+                if rc:
+                    check(rc)
         return step
 
     # ---- sharding / multi-GPU ------------------------------------------------------
@@ -335,6 +384,28 @@ class ExaModel:
         self._sync_stream()
         _lib.check(self._L.iem_halo_exchange(self._h, _ptr(x)))
         return x
+
+    def halo_exchange_async(self, x):
+        """The same exchange off the critical path (``iem_halo_exchange_async``): it runs on the handle's comm stream;
+        evaluation calls that can touch a halo entry of ``x`` wait for it, the others overlap it.  Nothing else may
+        touch ``x`` until the next evaluation call (or :meth:`halo_wait`)."""
+        self._chk(x, self.meta.nvar, "x")
+        self._sync_stream()
+        _lib.check(self._L.iem_halo_exchange_async(self._h, _ptr(x)))
+        return x
+
+    def halo_wait(self) -> None:
+        self._sync_stream()
+        _lib.check(self._L.iem_halo_wait(self._h))
+
+    def halo_reads(self) -> dict:
+        """Per kernel kind: can its kernels touch a halo entry through ``x`` / through a variable-space ``v``."""
+        out = {}
+        for k, name in enumerate(KERNEL_KINDS):
+            a, b = C.c_int32(), C.c_int32()
+            _lib.check(self._L.iem_halo_reads(self._h, k, C.byref(a), C.byref(b)))
+            out[name] = (bool(a.value), bool(b.value))
+        return out
 
     def halo_fold(self, vec):
         """Transposed halo exchange for a variable-space vector (``jtprod`` of this rank's rows): halo-copy

@@ -291,6 +291,114 @@ def connect_mailboxes(gm, dist=None) -> None:
     dist.barrier()
 
 
+class ShardComm:
+    """The two exchanges a sharded handle needs around its evaluation calls, with the fallback ``north_star`` names:
+
+    * ``kind == "own"`` — the library's mailbox kernels (``iem_halo_exchange[_async]``, ``iem_allreduce_obj_grad``:
+      one-shot pushes over HIP IPC / xGMI), when EVERY rank could export and map them;
+    * ``kind == "rccl"`` — ``torch.distributed`` (backend ``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests): the
+      8·(1 + n_shared)-byte all-reduce of :func:`allreduce_obj_grad_device`, and a point-to-point send / receive of the
+      halo doubles.  Taken when ``iem_comm_export`` / ``iem_comm_connect`` fails on any rank (no fine-grained IPC memory
+      between different GPUs: ``mailbox_kind == 2``), or when ``force_fallback`` is set.
+
+    All ranks agree on the kind (a gathered flag) before anything is exchanged.  ``why`` says what forced the fallback.
+    The fallback only needs ``gm.shard_var_map()`` / ``gm.shard_info()`` and tensors of ``x``'s device, so it runs on CPU
+    tensors under gloo (``tests/test_shard.py``)."""
+
+    def __init__(self, gm, dist=None, force_fallback: bool = False):
+        import torch
+        if dist is None:
+            import torch.distributed as dist
+        self.gm, self.dist, self._torch = gm, dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        err = "forced" if force_fallback else ""
+        mine = b""
+        if not force_fallback:
+            try:
+                mine = gm.comm_export()
+            except Exception as e:     # noqa: BLE001 — becomes the reason of the fallback
+                err = f"export: {e}"
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (mine, err))
+        errs = [h[1] for h in handles if h[1]]
+        if not errs:
+            try:
+                gm.comm_connect(b"".join(h[0] for h in handles))
+            except Exception as e:     # noqa: BLE001
+                err = f"connect: {e}"
+            flags = [None] * self.world
+            dist.all_gather_object(flags, err)
+            errs = [f for f in flags if f]
+        self.kind = "rccl" if errs else "own"
+        self.why = errs[0] if errs else ""
+        if self.kind == "own":
+            return
+        # fallback plan: who sends what to whom (halo copies are the left neighbour's LAST owned supports)
+        vm, vf = gm.shard_var_map()
+        info = gm.shard_info()
+        halo = (vf & 4) != 0
+        self._dst = np.nonzero(halo)[0].astype(np.int64)
+        wanted = [None] * self.world
+        dist.all_gather_object(wanted, vm[halo].astype(np.int64))
+        self._left = self.rank - 1 if self.rank > 0 and self._dst.size else None
+        self._right, self._src = None, np.zeros(0, np.int64)
+        if self.rank + 1 < self.world and wanted[self.rank + 1].size:
+            order = np.argsort(vm, kind="stable")
+            pos = np.searchsorted(vm[order], wanted[self.rank + 1])
+            src = order[np.minimum(pos, vm.size - 1)]
+            if not (np.array_equal(vm[src], wanted[self.rank + 1]) and ((vf[src] & 1) != 0).all()):
+                raise RuntimeError("ShardComm: the right neighbour's halo copies are not all owned by this rank")
+            self._right, self._src = self.rank + 1, src.astype(np.int64)
+        self._shared = np.nonzero((vf & 2) != 0)[0].astype(np.int64)
+        self._n_shared = int(info["n_shared"])
+        self._bufs = {}
+
+    def _dev(self, ref):
+        """Index / staging tensors on the device of ``ref`` (built once per device)."""
+        key = str(ref.device)
+        if key not in self._bufs:
+            t = self._torch
+            mk = lambda a: t.as_tensor(a, device=ref.device)
+            self._bufs[key] = dict(src=mk(self._src), dst=mk(self._dst), shared=mk(self._shared),
+                                   send=t.empty(self._src.size, dtype=t.float64, device=ref.device),
+                                   recv=t.empty(self._dst.size, dtype=t.float64, device=ref.device),
+                                   red=t.empty(1 + self._shared.size, dtype=t.float64, device=ref.device))
+        return self._bufs[key]
+
+    def halo_exchange(self, x, overlap: bool = False):
+        """Halo entries of ``x`` from the left neighbour, mine to the right.  ``overlap`` (own kernels only): the
+        asynchronous form — evaluation calls that do not read a halo entry overlap it (``iem_halo_exchange_async``)."""
+        if self.kind == "own":
+            return self.gm.halo_exchange_async(x) if overlap else self.gm.halo_exchange(x)
+        b, dist, ops = self._dev(x), self.dist, []
+        if self._right is not None:
+            b["send"].copy_(x[b["src"]])
+            ops.append(dist.P2POp(dist.isend, b["send"], self._right))
+        if self._left is not None:
+            ops.append(dist.P2POp(dist.irecv, b["recv"], self._left))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        if self._left is not None:
+            x[b["dst"]] = b["recv"]
+        return x
+
+    def allreduce_obj_grad(self, obj_dev, g):
+        """Sum of the scalar objective (1-element tensor, may be ``None``) and of the replicated entries of ``g`` over
+        the ranks, in place.  Own kernels: rank-order sum, identical bits on every rank; fallback: the collective's."""
+        if self.kind == "own":
+            return self.gm.allreduce_obj_grad(obj_dev, g)
+        ref = g if g is not None else obj_dev
+        b = self._dev(ref)
+        if g is None and self._n_shared:
+            raise ValueError("null gradient but the model has replicated variables")
+        zero = self._torch.zeros(1, dtype=self._torch.float64, device=ref.device)
+        out = allreduce_obj_grad_device(obj_dev if obj_dev is not None else zero, g, b["shared"], b["red"], self.dist)
+        if obj_dev is not None:
+            obj_dev.copy_(out)
+        return obj_dev, g
+
+
 def allreduce_obj_grad_device(obj_dev, grad_dev, shared_idx_dev, buf, dist=None):
     """Device-resident form of :func:`allreduce_obj_grad` (no host round trip, stream-ordered):
     ``obj_dev`` is a 1-element tensor (``ExaModel.obj_device``), ``buf`` a preallocated

@@ -33,7 +33,9 @@ def build_global(name, size):
 def main():
     name, group = sys.argv[1], int(sys.argv[2])
     size = tuple(int(v) for v in sys.argv[3].split("x"))
-    use_graph = len(sys.argv) > 4 and sys.argv[4] == "graph"
+    mode = sys.argv[4] if len(sys.argv) > 4 else "eager"
+    use_graph = mode in ("graph", "async_graph")
+    use_async = mode in ("async", "async_graph")     # iem_halo_exchange_async instead of the stream-ordered exchange
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -66,10 +68,19 @@ def main():
     hp = torch.empty(gm.meta.nvar, dtype=torch.float64, device="cuda")
     jp = torch.empty(gm.meta.ncon, dtype=torch.float64, device="cuda")
 
+    exchange = gm.halo_exchange_async if use_async else gm.halo_exchange
+    reads = gm.halo_reads()
+    if name == "quadrotor" and rank > 0:     # difference rows: cons! reads x_k[a_r - 1], their partials are item data
+        assert reads["cons"][0] and not reads["jac"][0] and not reads["hess"][0] and not reads["obj"][0], reads
+
     def loop():
-        gm.halo_exchange(xd)
-        gm.cons(xd, c); gm.jac_coord(xd, jv); gm.hess_coord(xd, yd, hv, obj_weight=0.7)
-        gm.obj_device(xd, f); gm.grad(xd, g)
+        exchange(xd)
+        if use_async:
+            # solver order: the calls that read no halo entry come first and overlap the exchange; cons! waits for it
+            gm.obj_device(xd, f); gm.grad(xd, g); gm.jac_hess_coord(xd, yd, jv, hv, obj_weight=0.7); gm.cons(xd, c)
+        else:
+            gm.cons(xd, c); gm.jac_coord(xd, jv); gm.hess_coord(xd, yd, hv, obj_weight=0.7)
+            gm.obj_device(xd, f); gm.grad(xd, g)
         fpre.copy_(f); gpre.copy_(g)
         gm.allreduce_obj_grad(f, g)
         # J'v with v = y: each rank's rows, then the transposed halo exchange (what my first difference row owes to
@@ -78,7 +89,7 @@ def main():
         gm.halo_fold(jt)
         gm.allreduce_obj_grad(None, jt)
         # J v and H v with a DISTRIBUTED v: its halo copies arrive like x's; H v folds back like J'v
-        gm.halo_exchange(vd)
+        exchange(vd)
         gm.jprod(xd, vd, jp)
         gm.hprod(xd, yd, vd, hp, obj_weight=0.7)
         gm.halo_fold(hp)

@@ -57,3 +57,15 @@ def test_backend_builds_device_model_and_updates_theta(built):
     om = OracleModel(b.core.to_blob())
     f1 = b.model.obj(x)
     assert f1 != f0 and abs(f1 - om.obj(x.cpu().numpy())) <= 1e-12 * abs(f1)
+
+
+def test_sharded_backend_refuses_the_solver_slot():
+    """A backend holding ONE rank's shard is a build-and-evaluate plug point: optimize() / warm start raise instead of
+    handing the global x0 to the rank's local model (no GPU needed: the refusal comes first)."""
+    from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
+    from infiniteexamodels.jl_amd.model import MI355XBackend
+    be = ExaTranscriptionBackend(solver=lambda *a, **k: None, backend=MI355XBackend(0, shard=(1, 0, 4)))
+    with pytest.raises(NotImplementedError, match="rank 0 of 4"):
+        be.optimize()
+    with pytest.raises(NotImplementedError, match="build-and-evaluate"):
+        be.warmstart_backend_start_values()

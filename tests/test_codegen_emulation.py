@@ -31,6 +31,11 @@ def test_emulated_kernels_match_oracle(name, grid_mode):
     assert not np.isnan(j).any() and not np.isnan(h).any(), "every output slot must be written"
     assert _rel(j, om.jac_coord(x)) <= 1e-14
     assert _rel(h, om.hess_coord(x, y, 0.7)) <= 1e-14
+    if any(k["kind"] == 8 for k in em.kernels):     # the fused jac + hess launch (iem_jac_hess_coord): the same BYTES
+        jp, hp = em.jac_hess_coord(x, y, 0.7, om.nnzj, om.nnzh)
+        assert np.array_equal(jp, j) and np.array_equal(hp, h)
+    else:                                           # only models without Jacobian or without Hessian entries have none
+        assert om.nnzj == 0 or om.nnzh == 0
     # matrix-free products (jprod! / jtprod! / hprod!)
     rng = np.random.default_rng(5)
     v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
@@ -64,6 +69,38 @@ def test_generated_source_is_size_independent(built):
     assert len(large) == 1 and len(small) == 1 and large != small
     with iemlib.options(split_small=0):
         assert {key(100)} == large       # the lane-fused source is the same at any size
+    # the staging batch of jac_coord! / hess_coord! is a function of the grid size (big_batch_jac = 400, big_batch_hess =
+    # 4000 workgroups): two more shapes, each again one code object for all of its sizes — and what build() compiles for
+    # them from a small model with lowered thresholds IS what a model of that size asks for at run time
+    mid = {key(S) for S in (250_000, 600_000)}
+    assert len(mid) == 1 and mid != large
+    with iemlib.options(split_small=0, big_batch_jac=1):
+        assert {key(2000)} == mid
+    with iemlib.options(split_small=0, big_batch_jac=1, big_batch_hess=1):
+        huge = {key(2000)}
+    with iemlib.options(big_batch_hess=500):      # (a 2.2e6-support model, without building one)
+        assert {key(300_000)} == huge and huge != mid
+
+
+@pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "opf_600", "quadrotor_oc3_700"])
+@pytest.mark.parametrize("big", [dict(big_batch_jac=1), dict(big_batch_jac=1, big_batch_hess=1)])
+def test_large_grid_staging_batch_writes_the_same_values(name, big, lane_fused):
+    """The large-grid shapes (48-slot staging batch for jac_coord! only / for both) against the oracle, stand-alone
+    kernels and the fused pair — the batch size moves barriers, never values."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    ref = EmulatedModel(core, blob)
+    with iemlib.options(**big):
+        em = EmulatedModel(core, blob)
+        assert em.source != ref.source
+        j, h = em.jac_coord(x, om.nnzj), em.hess_coord(x, y, 0.7, om.nnzh)
+        assert np.array_equal(j, ref.jac_coord(x, om.nnzj)) and np.array_equal(h, ref.hess_coord(x, y, 0.7, om.nnzh))
+        assert _rel(j, om.jac_coord(x)) <= 1e-14 and _rel(h, om.hess_coord(x, y, 0.7)) <= 1e-14
+        jp, hp = em.jac_hess_coord(x, y, 0.7, om.nnzj, om.nnzh)
+        assert np.array_equal(jp, j) and np.array_equal(hp, h)
 
 
 def test_cross_template_cse(lane_fused):

@@ -25,7 +25,10 @@ def _free_port():
 
 @pytest.mark.parametrize("name,group,size,world,mode", [
     ("quadrotor", 1, "4000", 2, "eager"), ("quadrotor", 1, "4001", 4, "graph"), ("farmer", 1, "3000", 3, "eager"),
-    ("opf", 1, "500", 2, "graph"), ("pandemic", 2, "40x12", 4, "eager"), ("quadrotor_oc3", 1, "2000", 3, "eager")])
+    ("opf", 1, "500", 2, "graph"), ("pandemic", 2, "40x12", 4, "eager"), ("quadrotor_oc3", 1, "2000", 3, "eager"),
+    # the asynchronous exchange (iem_halo_exchange_async): calls that read no halo entry overlap it, the others wait
+    ("quadrotor", 1, "4000", 2, "async"), ("quadrotor", 1, "4001", 3, "async_graph"), ("quadrotor_oc3", 1, "2000", 2, "async"),
+    ("pandemic", 2, "40x12", 2, "async")])
 def test_distributed_x_halo_and_allreduce(name, group, size, world, mode, built):
     port = _free_port()
     procs = []
@@ -62,4 +65,32 @@ def test_bench_line_carries_a_checked_comm_section(built):
     c = j["comm"]
     assert "error" not in c, c
     assert c["halo_exact"] is True and c["allreduce_exact"] is True
-    assert c["halo_exchange_us"] > 0 and c["allreduce_obj_us"] > 0 and c["pair_with_halo"]["value"] > 0
+    assert c["halo_exchange_us"] > 0 and c["allreduce_obj_us"] > 0 and c["pair_behind_blocking_halo"]["ms_per_step"] > 0
+    # the headline step of an N > 1 line CONTAINS the halo exchange: wired in-process after the children came back clean
+    assert j["halo_in_timed_loop"] is True and "behind iem_halo_exchange_async" in j["config"]["step"]
+    assert j["halo"]["status_after_timed_loop"] == 0 and j["halo"]["mailbox_kind"] in (1, 2, 3)
+    assert j["halo"]["reads_halo"] == {"cons": True, "jac": False, "hess": False, "pair": False}   # difference rows are linear
+    assert j["pair_no_halo"]["value"] > 0 and j["fused_pair"]["value"] > 0
+
+
+def test_a_skipped_exchange_surfaces_as_an_error(built):
+    """A rank that does not take part: the peer's kernel times out (bounded), poisons what it should have delivered and
+    the next host synchronisation point returns IEM_E_COMM — never a silent stale halo (iem_device.h)."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "comm_timeout_worker.py")],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    assert "OK timeout surfaced" in outs[0], outs[0][-3000:]

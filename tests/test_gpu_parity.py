@@ -85,6 +85,15 @@ def test_all_entry_points_match_oracle(name, torch_cuda, grid_mode):
         _close(gm.jac_coord(xd, jv).cpu().numpy(), om.jac_coord(x), "jac_coord")
         for w in (1.0, 0.3):
             _close(gm.hess_coord(xd, yd, hv, obj_weight=w).cpu().numpy(), om.hess_coord(x, y, w), "hess_coord")
+        # the fused launch (iem_jac_hess_coord) into poisoned buffers: the BYTES of the two calls (w = 0.3: the last above)
+        jv2 = torch.full((om.nnzj,), float("nan"), device="cuda", dtype=torch.float64)
+        hv2 = torch.full((om.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
+        gm.jac_hess_coord(xd, yd, jv2, hv2, obj_weight=0.3)
+        assert torch.equal(jv2, jv) and torch.equal(hv2, hv), "fused jac + hess launch differs from the two calls"
+        # obj in two halves (iem_obj_begin / iem_obj_end) around other launches: the same bits as obj
+        gm.obj_begin(xd)
+        gm.cons(xd, cv)
+        assert gm.obj_end() == f
         # matrix-free products into poisoned buffers
         rng = np.random.default_rng(seed + 40)
         v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
@@ -487,3 +496,39 @@ def test_misuse_is_an_error_code_not_a_crash(torch_cuda):
         ExaModel(core, device=0, blob=blob, options={"no_such_option": 1})
     _close(gm.jac_coord(xd).cpu().numpy(), om.jac_coord(x), "jac after misuse")
     gm.close()
+
+
+def test_obj_begin_end_protocol(torch_cuda):
+    """One begin outstanding per handle; end without begin is an error; a model without objective returns 0."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core, om, gm = _models("quadrotor_100", torch)
+    xd = torch.tensor(om.x0 + 0.1, device="cuda")
+    with pytest.raises(iemlib.IemError, match="without iem_obj_begin"):
+        gm.obj_end()
+    gm.obj_begin(xd)
+    with pytest.raises(iemlib.IemError, match="has not been collected"):
+        gm.obj_begin(xd)
+    assert gm.obj_end() == gm.obj(xd)
+    gm.close()
+
+
+@pytest.mark.parametrize("opts", [dict(big_batch_jac=1), dict(big_batch_jac=1, big_batch_hess=1), dict(pair_kernel=0)])
+def test_large_grid_shapes_and_pair_fallback_on_gpu(opts, torch_cuda):
+    """The large-grid staging batch (jac only / both) and a handle WITHOUT the fused kernel (iem_jac_hess_coord then makes
+    the two calls) write the bytes of the default handle."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd.model import ExaModel
+    core, om, gm = _models("quadrotor_1000", torch)
+    x, y = cases.eval_point_for("quadrotor_1000", om)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    j0, h0 = gm.jac_coord(xd), gm.hess_coord(xd, yd, obj_weight=0.7)
+    g2 = ExaModel(core, device=0, options=dict(split_small=0, **opts))
+    kinds = [k["kind"] for k in g2.kernels()]
+    assert ("pair" in kinds) == (opts.get("pair_kernel", 1) == 1)
+    assert torch.equal(g2.jac_coord(xd), j0) and torch.equal(g2.hess_coord(xd, yd, obj_weight=0.7), h0)
+    nan = lambda n: torch.full((n,), float("nan"), device="cuda", dtype=torch.float64)
+    j2, h2 = g2.jac_hess_coord(xd, yd, nan(om.nnzj), nan(om.nnzh), obj_weight=0.7)
+    assert torch.equal(j2, j0) and torch.equal(h2, h0)
+    _close(j2.cpu().numpy(), om.jac_coord(x), "jac"); _close(h2.cpu().numpy(), om.hess_coord(x, y, 0.7), "hess")
+    g2.close(); gm.close()

@@ -141,6 +141,13 @@ def test_backend_plug_point_with_a_shard(built):
         assert abs(gm.obj(xd) - so.obj(x)) <= RTOL * max(1.0, abs(so.obj(x)))
         _close(gm.grad(xd).cpu().numpy(), so.grad(x), "grad")
         _close(gm.jac_coord(xd).cpu().numpy(), so.jac_coord(x), "jac")
+    # the sharded plug point is build-and-evaluate only: the single-process solver slot is refused loudly
+    # (a global x0 must never reach a local model)
+    be.solver = lambda *a, **k: None
+    with pytest.raises(NotImplementedError, match="rank 1 of 2"):
+        be.optimize()
+    with pytest.raises(NotImplementedError):
+        be.warmstart_backend_start_values()
     be.empty()
 
 

@@ -114,3 +114,20 @@ def test_obj_grad_allreduce_gloo_world2(name, size, world, built):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert "OK" in outs[0], outs[0]
+
+
+@pytest.mark.parametrize("name,size,world,mode", [("quadrotor", 50, 2, "export"), ("quadrotor", 53, 3, "connect"), ("farmer", 40, 2, "forced"),
+                                                  ("opf", 30, 2, "connect")])
+def test_comm_fallback_gloo(name, size, world, mode, built):
+    """when a rank cannot export / map a mailbox, every rank falls back to torch.distributed for the
+    halo exchange and the one small all-reduce (shard.ShardComm) — world 2 and 3 over gloo, no GPU."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "comm_fallback_worker.py"), name, str(size), mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "OK rccl" in outs[0], outs[0]

@@ -48,7 +48,10 @@ def main():
                 "valu_busy_frac_of_simd_cycles": c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * dur[k] * clk),
                 "fp64_tflops_upper_bound": c["SQ_INSTS_VALU"] * 64 * 2 / dur[k] / 1e12, "fp64_vector_peak_tflops": 78.6,
                 "note": "every vector instruction counted as an FP64 FMA on 64 lanes; quad-cycles x4; 1024 SIMDs; 2.4 GHz assumed"}
-    json.dump({"command": "tools/profile_gpu.sh (rocprofv3 --kernel-trace --stats; each --pmc group in its own pass) on "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    commit = os.environ.get("IEM_COMMIT", "n/a")      # no .git on the GPU box: pass `IEM_COMMIT=$(git rev-parse --short HEAD)` through the runner
+    json.dump({"csrc_fingerprint": bench.csrc_fingerprint(), "commit": commit, "command": "tools/profile_gpu.sh (rocprofv3 --kernel-trace --stats; each --pmc group in its own pass) on "
                           "python3 bench.py --no-cpu-baseline", "kernel_stats": stats, "pmc": pmc}, open(dst, "w"), indent=1)
     print(json.dumps({"kernel_stats": stats, "pmc": {k: {n: v for n, v in c.items() if n in ("hbm_bytes_per_launch", "compute_guard")}
                                                      for k, c in pmc.items()}}, indent=1))
