@@ -23,8 +23,9 @@ pairs per second of that fixed problem, so value(N)/value(1) is the speed-up.
 N > 1, what the timed step is: every solver iteration moves x, so the stencil neighbours x_k[a_r - 1] must cross
 the shard boundary before the rows that read them are evaluated.  The timed step is therefore
 `iem_halo_exchange_async(x); jac_coord!; hess_coord!` — the exchange INSIDE the timed region (key "halo_in_timed_loop").
-The library runs it on its comm stream and orders each evaluation call against it by what the call's kernels load
-(csrc/iem_api.cpp: halo_before / halo_after); the communication-free pair is reported beside it ("pair_no_halo").
+The library launches nothing for it: the exchange rides on the step's first launch as one extra leading workgroup, because
+that kernel's loads cannot touch a halo entry (csrc/iem_api.cpp: halo_plan; a call that can gets the stand-alone exchange
+kernel in front of it); the communication-free pair is reported beside it ("pair_no_halo").
 Before the ranks wire their mailboxes in-process, the same wiring + one checked exchange + one checked all-reduce
 run in CHILD processes (key "comm": peer-mapped memory is the one part that the one-GPU box can only rehearse with all
 ranks on one device — whatever it does on a real xGMI node must end in an entry of the line, never in a lost line).  If
@@ -510,6 +511,10 @@ def main():
                 "hess_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))}
         del xs, ys
 
+    reads_all = None
+    if world > 1 and use_dist and halo_state["in_loop"]:
+        reads_all = [None] * world       # rank 0 has no left neighbour: what the stencil makes a rank wait for shows on rank 1
+        dist.all_gather_object(reads_all, {k: v[0] for k, v in gm.halo_reads().items() if k in ("cons", "jac", "hess", "pair")})
     line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -579,8 +584,9 @@ def main():
         if world > 1:
             line["halo_in_timed_loop"] = bool(halo_state["in_loop"])
             if halo_state["in_loop"]:
-                line["halo"] = {"exchange": "iem_halo_exchange_async (own mailbox kernels, comm stream)", "mailbox_kind": halo_state.get("mailbox_kind"),
-                                "status_after_timed_loop": halo_state.get("status"), "reads_halo": {k: v[0] for k, v in gm.halo_reads().items() if k in ("cons", "jac", "hess", "pair")}}
+                line["halo"] = {"exchange": "iem_halo_exchange_async (deferred; rides on the first launch of the step as one extra workgroup)", "mailbox_kind": halo_state.get("mailbox_kind"),
+                                "status_after_timed_loop": halo_state.get("status"), "reads_halo_rank1": reads_all[1] if reads_all else None,
+                                "meaning": "reads_halo: which calls of rank 1 need the exchange to be complete (their kernels can load a halo entry of x); the others can carry it"}
             elif not args.no_comm and not args.emulate_shard:
                 line["comm_fallback"] = (comm or {}).get("error") or halo_state.get("why") or "not attempted"
             if comm is not None:

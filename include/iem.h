@@ -152,20 +152,25 @@ int iem_shard_blob(const void *blob, size_t nbytes, int group, int rank, int wor
 int iem_comm_export(iem_model *m, void *out_handle /* IEM_COMM_HANDLE_BYTES */);
 int iem_comm_connect(iem_model *m, const void *all_handles /* world x IEM_COMM_HANDLE_BYTES, rank order */);
 int iem_halo_exchange(iem_model *m, double *d_x);
-/* The same exchange OFF the critical path.  It starts on the handle's internal comm stream as soon as the work already
- * enqueued on the handle's stream (whatever produced x) has finished, and the library orders the evaluation calls that
- * follow against it by what their kernels actually load: a call that can touch a halo entry of d_x (cons! of a model with
- * difference rows: x_k[a_r - 1], transform.jl:535-557) waits for the exchange; a call that cannot (obj, grad!, and
- * jac_coord! / hess_coord! whenever the stencil rows are linear — their partials are item data) is launched at once and
- * overlaps it.  The handle's stream re-joins the exchange behind the FIRST evaluation call that follows (or iem_halo_wait,
- * iem_synchronize), so everything enqueued after that call is ordered behind the exchange as usual.  Contract: between this
- * call and that first evaluation call / iem_halo_wait the caller enqueues nothing that reads or writes d_x.  One exchange
- * is outstanding at a time (a second call joins the first).  Graph-capturable (the comm stream forks from and joins the
- * capturing stream).  iem_halo_reads reports what the handle derived: does kernel kind `kind` (iem_kernel_info_t.kind) touch
- * a halo entry through x / through a variable-space v. */
+/* The same exchange OFF the critical path — nothing is launched for it.  The call only DEFERS the exchange; it then rides on
+ * the first evaluation launch that takes the same d_x and whose kernels cannot touch a halo entry of it: ONE EXTRA LEADING
+ * WORKGROUP of that kernel sends my boundary supports to the right neighbour, waits (bounded) for the left neighbour's,
+ * writes them into the halo entries of d_x and acknowledges, while the kernel's other workgroups evaluate — no launch, no
+ * stream, no event of its own, and every kernel launched BEHIND that one sees the halo entries as after iem_halo_exchange.
+ * Which calls can carry it follows from what their generated kernels load (iem_halo_reads): obj, and jac_coord! /
+ * hess_coord! / iem_jac_hess_coord whenever the stencil rows are linear (their partials are item data — the reference's
+ * derivative approximations, transform.jl:511-562); cons! of such a model reads x_k[a_r - 1] (transform.jl:535-557): if it
+ * comes first, it gets the stand-alone exchange kernel in front of it — exactly iem_halo_exchange.  In solver order (obj,
+ * grad!, cons!, jac_coord!, hess_coord! at a new point: ext/InfiniteExaModelsIpopt.jl:48-49) the exchange rides on obj and is
+ * complete before cons! starts.  A call that neither touches nor can carry (grad!, the products) leaves it deferred;
+ * iem_halo_wait, iem_synchronize, iem_halo_fold, iem_comm_status and a further exchange flush it (stand-alone kernel).
+ * Contract: between this call and the evaluation call that carries it (or iem_halo_wait) the caller enqueues nothing that
+ * writes d_x or reads its halo entries.  Graph-capturable (the decision is taken at capture time; a replay repeats it).
+ * iem_halo_reads: for kernel kind `kind` (iem_kernel_info_t.kind): can it touch a halo entry through x / through a
+ * variable-space v, and can it carry a deferred exchange of x. */
 int iem_halo_exchange_async(iem_model *m, double *d_x);
 int iem_halo_wait(iem_model *m);
-int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v);
+int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v, int *out_carrier);
 /* The transposed exchange, for a vector in VARIABLE space produced by a transposed operator on this rank's rows
  * (iem_jtprod): the entries of the halo copies hold what this rank's rows owe to variables the LEFT neighbour owns
  * (the x_k[a_r - 1] column of the first difference row, src/transform.jl:535-557).  They are sent to the left

@@ -173,14 +173,16 @@ struct iem_model {
   // synchronisation points read without a copy (h_obj + 1)
   volatile unsigned long long *h_status = nullptr;
   unsigned long long *d_hstatus = nullptr;
-  // asynchronous halo exchange (iem_halo_exchange_async): the exchange kernel runs on `comm_stream` behind `ev_x`
-  // (= everything enqueued on the handle's stream when it was called); evaluation calls that can touch a halo entry
-  // of the exchanged vector wait for `ev_halo` first, the others are launched and THEN join — they overlap it
-  hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_x = nullptr, ev_halo = nullptr;
-  bool halo_pending = false;
-  const void *halo_vec = nullptr;
-  bool reads_halo_x[iem::KK_PAIR + 1] = {}, reads_halo_v[iem::KK_PAIR + 1] = {};
+  // Asynchronous halo exchange (iem_halo_exchange_async): nothing is launched for it.  The exchange is DEFERRED and rides
+  // on the first evaluation launch that takes the same x and cannot touch a halo entry of it: one extra leading workgroup
+  // of that kernel (iem_halo_wg, through the kernel argument `comm` = d_comm) sends, receives and writes the halo entries
+  // while the kernel's other workgroups evaluate; a launch that CAN touch a halo entry first gets the stand-alone
+  // exchange kernel in front of it.  (A comm stream + events was measured: two cross-stream dependencies cost more —
+  // ~8 us per step — than the 3-4 us stand-alone kernel they were meant to hide; tools/halo_overlap_probe.py.)
+  bool halo_deferred = false;
+  double *halo_vec = nullptr;
+  void *d_comm = nullptr;        // IemHaloArgs in device memory (x unused: the carrier kernel passes its own)
+  bool reads_halo_x[iem::KK_PAIR + 1] = {}, reads_halo_v[iem::KK_PAIR + 1] = {}, carrier[iem::KK_PAIR + 1] = {};
   uint64_t nonce = 0;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -305,9 +307,9 @@ int compile_or_load(iem_model *m) {
 }
 
 // Builds the static part of a kernel's argument block once (iem_create); launching only rewrites
-// the head {x, theta, y, v, out, w, aux}.
+// the head {x, theta, y, v, out, w, aux, comm}.
 void build_argbuf(iem_model *m, const iem::KernelDesc &kd, const void *d_table, std::vector<uint64_t> &buf) {
-  buf.assign(7, 0);
+  buf.assign(8, 0);
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
   if (kd.tables_in_memory) {
     const uint64_t *tb = (const uint64_t *)d_table;
@@ -353,16 +355,18 @@ int prepare_program(iem_model *m, const iem::Program &prog, std::vector<void *> 
   return IEM_OK;
 }
 
+// `carry`: the launch also carries the deferred halo exchange of x — one extra leading workgroup column (iem_halo_wg)
 int launch_one(iem_model *m, const iem::KernelDesc &kd, hipFunction_t fn, std::vector<uint64_t> &buf, const double *x, const double *y,
-               double *out, double w, const double *v, double *aux) {
+               double *out, double w, const double *v, double *aux, bool carry = false) {
   if (kd.n_blocks <= 0) return IEM_OK;   // a support grid none of whose templates has an item
   buf[0] = (uint64_t)(uintptr_t)x; buf[1] = (uint64_t)(uintptr_t)m->d_theta; buf[2] = (uint64_t)(uintptr_t)y;
   buf[3] = (uint64_t)(uintptr_t)v; buf[4] = (uint64_t)(uintptr_t)out;
   std::memcpy(&buf[5], &w, 8);
   buf[6] = (uint64_t)(uintptr_t)aux;
+  buf[7] = carry ? (uint64_t)(uintptr_t)m->d_comm : 0;
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)kd.grid[0], (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
+  HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)kd.grid[0] + (carry ? 1u : 0u), (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
                                 m->stream, nullptr, cfg));
   return IEM_OK;
 }
@@ -382,39 +386,58 @@ int comm_check(iem_model *m) {
                           "a peer did not take part in the exchange; the halo entries / reduced values it should have delivered were set to NaN");
 }
 
-// Ordering of an evaluation call against a pending asynchronous halo exchange (iem_halo_exchange_async): a kind that can
-// touch a halo entry of the exchanged vector waits for it BEFORE its launch; any other kind is launched first and the
-// handle's stream joins the exchange AFTER it — that call overlaps the exchange, everything later is ordered behind it.
-int halo_before(iem_model *m, int kind, const void *x, const void *v) {
-  if (!m->halo_pending) return IEM_OK;
-  const bool need = (x == m->halo_vec && m->reads_halo_x[kind]) || (v && v == m->halo_vec && m->reads_halo_v[kind]);
-  if (!need) return IEM_OK;
-  HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_halo, 0));
-  m->halo_pending = false;
+// Ordering of an evaluation call against a DEFERRED halo exchange (iem_halo_exchange_async).  halo_plan decides for the
+// call about to be launched: 2 = its first kernel carries the exchange (same x, a carrier kind, and no kernel of the kind
+// can touch a halo entry of x); 1 = the stand-alone exchange kernel has been launched in front of it (it can touch one);
+// 0 = nothing (no exchange pending, or this call neither touches nor can carry: the exchange stays deferred).
+// the all-reduce runs on G workgroups, each on its own chunk of the NR doubles (one per 1 024, at most 64)
+int64_t reduce_chunks(int64_t NR) { return std::min<int64_t>(64, std::max<int64_t>(1, (NR + 1023) / 1024)); }
+struct HaloArgsH { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G; unsigned long long *hstatus; long long ticks; };
+HaloArgsH halo_args(iem_model *m, double *d_x) {
+  const iem::ShardInfo &si = m->shard;
+  return HaloArgsH{d_x, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
+                   m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared),
+                   m->d_hstatus, (long long)m->opt.comm_timeout_ms * 100000LL};
+}
+int halo_launch(iem_model *m, double *d_x, hipStream_t stream) {
+  HaloArgsH A = halo_args(m, d_x);
+  size_t sz = sizeof A;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, stream, nullptr, cfg));
   return IEM_OK;
 }
-int halo_after(iem_model *m) {
-  if (!m->halo_pending) return IEM_OK;
-  HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_halo, 0));
-  m->halo_pending = false;
+int halo_flush(iem_model *m) {
+  if (!m->halo_deferred) return IEM_OK;
+  m->halo_deferred = false;
+  return halo_launch(m, m->halo_vec, m->stream);
+}
+int halo_plan(iem_model *m, int kind, const void *x, const void *v, bool *carry) {
+  *carry = false;
+  if (!m->halo_deferred) return IEM_OK;
+  const bool touches = (x == m->halo_vec && m->reads_halo_x[kind]) || (v && v == m->halo_vec && m->reads_halo_v[kind]);
+  if (touches) return halo_flush(m);
+  if (x == m->halo_vec && m->carrier[kind] && m->d_comm) { *carry = true; m->halo_deferred = false; }
   return IEM_OK;
 }
 
 int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux);
 
 int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
-  int rc = halo_before(m, kind, x, v);
-  if (rc == IEM_OK) rc = launch_kind_raw(m, kind, x, y, out, w, v, aux);
-  if (rc == IEM_OK) rc = halo_after(m);
-  return rc;
+  return launch_kind_raw(m, kind, x, y, out, w, v, aux);
 }
 
 int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux) {
+  bool carry = false;
+  int rc0 = halo_plan(m, kind, x, v, &carry);
+  if (rc0) return rc0;
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     if (m->prog.kernels[k].kind == kind) {
-      int rc = launch(m, k, x, y, out, w, v, aux);
+      if (m->prog.kernels[k].n_blocks <= 0) continue;
+      int rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], x, y, out, w, v, aux, carry);
       if (rc) return rc;
+      carry = false;   // the first kernel of the call carries it
     }
+  if (carry) { m->halo_deferred = true; }   // (no kernel of the kind was launched: still pending)
   if (!m->prog.axis[kind].empty()) {   // sums over a non-lane axis: the rows the kernels parked -> one write per entry (iem_axis_sum_kernel)
     int64_t n0 = 1;
     for (auto &a : m->prog.axis[kind]) n0 = std::max(n0, a.n0);
@@ -435,14 +458,18 @@ int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, do
 }
 
 int launch_kind_alt(iem_model *m, int kind, const double *x, const double *y, double *out, double w) {
-  int rc = halo_before(m, kind, x, nullptr);
+  bool carry = false;
+  int rc = halo_plan(m, kind, x, nullptr, &carry);
   if (rc) return rc;
   for (size_t k = 0; k < m->alt.prog.kernels.size(); ++k)
     if (m->alt.prog.kernels[k].kind == kind) {
-      rc = launch_one(m, m->alt.prog.kernels[k], m->alt.fns[k], m->alt.argbuf[k], x, y, out, w, nullptr, nullptr);
+      if (m->alt.prog.kernels[k].n_blocks <= 0) continue;
+      rc = launch_one(m, m->alt.prog.kernels[k], m->alt.fns[k], m->alt.argbuf[k], x, y, out, w, nullptr, nullptr, carry);
       if (rc) return rc;
+      carry = false;
     }
-  return halo_after(m);
+  if (carry) m->halo_deferred = true;
+  return IEM_OK;
 }
 
 // jac_coord! / hess_coord! through the tuner (struct Alt): the first IEM_TUNE_CALLS calls into an output buffer
@@ -966,12 +993,8 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
       m->reads_halo_x[kd.kind] = m->reads_halo_x[kd.kind] || hits(kd.x_ranges);
       m->reads_halo_v[kd.kind] = m->reads_halo_v[kd.kind] || hits(kd.v_ranges);
     }
-    // the exchange kernel is one workgroup that may spin on a peer's flag: its own stream, ahead of the evaluation kernels
-    int lo_pri = 0, hi_pri = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess) { (void)hipGetLastError(); hi_pri = 0; }
-    if (hipStreamCreateWithPriority(&m->comm_stream, hipStreamNonBlocking, hi_pri) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_x, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_halo, hipEventDisableTiming) != hipSuccess) return bail(fail(IEM_E_HIP, "comm stream / events"));
+    if (!m->opt.xcd_remap)
+      for (int k : {(int)iem::KK_CONS, (int)iem::KK_JAC, (int)iem::KK_HESS, (int)iem::KK_JPROD, (int)iem::KK_OBJ, (int)iem::KK_PAIR}) m->carrier[k] = true;
   }
   if ((rc = prepare_program(m, m->prog, m->d_tables, m->argbuf)) != IEM_OK) return bail(rc);
   // second code object for the tuner: only for block-store models with a large jac/hess grid (below ~2e5 supports
@@ -1029,9 +1052,7 @@ int iem_destroy(iem_model *m) {
   if (m->d_halo_dst) hipFree(m->d_halo_dst);
   if (m->d_shared) hipFree(m->d_shared);
   if (m->h_obj) hipHostFree(m->h_obj);
-  if (m->comm_stream) { hipStreamSynchronize(m->comm_stream); hipStreamDestroy(m->comm_stream); }
-  if (m->ev_x) hipEventDestroy(m->ev_x);
-  if (m->ev_halo) hipEventDestroy(m->ev_halo);
+  if (m->d_comm) hipFree(m->d_comm);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
   for (void *t : m->d_tables) if (t) hipFree(t);
   for (void *t : m->alt.d_tables) if (t) hipFree(t);
@@ -1113,7 +1134,7 @@ int iem_set_stream(iem_model *m, void *hip_stream) {
 int iem_synchronize(iem_model *m) {
   if (!m) return fail(IEM_E_ARG, "null handle");
   DevGuard dg_(m->device);
-  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }   // the asynchronous exchange belongs to what the caller waits for
+  { int rc = halo_flush(m); if (rc) return rc; }   // a deferred exchange belongs to what the caller waits for
   HIP_TRY(hipStreamSynchronize(m->stream));
   return comm_check(m);
 }
@@ -1246,9 +1267,9 @@ int iem_jac_hess_coord(iem_model *m, const double *d_x, const double *d_y, doubl
   DevGuard dg_(m->device);
   for (size_t k = 0; k < m->prog.kernels.size(); ++k)
     if (m->prog.kernels[k].kind == iem::KK_PAIR) {
-      int rc = halo_before(m, iem::KK_PAIR, d_x, nullptr);
-      if (rc == IEM_OK) rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], d_x, d_y, d_jac, obj_weight, nullptr, d_hess);
-      if (rc == IEM_OK) rc = halo_after(m);
+      bool carry = false;
+      int rc = halo_plan(m, iem::KK_PAIR, d_x, nullptr, &carry);
+      if (rc == IEM_OK) rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], d_x, d_y, d_jac, obj_weight, nullptr, d_hess, carry);
       return rc;
     }
   int rc = iem_jac_coord(m, d_x, d_jac);
@@ -1343,7 +1364,6 @@ std::vector<int64_t> shard_items(const iem::ShardInfo &si) {
 
 // mailbox words: see iem_device.h
 // the all-reduce runs on G workgroups, each on its own chunk of the NR doubles (one per 1 024, at most 64)
-int64_t reduce_chunks(int64_t NR) { return std::min<int64_t>(64, std::max<int64_t>(1, (NR + 1023) / 1024)); }
 size_t mailbox_words(int64_t W, int64_t NH, int64_t NR) {
   const int64_t G = reduce_chunks(NR);
   return (size_t)(12 + G + 2 * W * G + 2 * NH + 2 * W * NR + 2 * NH);   // header, reduce flags, halo data, reduce data, fold data
@@ -1566,19 +1586,12 @@ int iem_comm_connect(iem_model *m, const void *all_handles) {
     HIP_TRY(hipMalloc((void **)&m->d_shared, sh.size() * 8));
     HIP_TRY(hipMemcpy(m->d_shared, sh.data(), sh.size() * 8, hipMemcpyHostToDevice));
   }
+  {
+    HaloArgsH A = halo_args(m, nullptr);
+    HIP_TRY(hipMalloc(&m->d_comm, sizeof A));
+    HIP_TRY(hipMemcpy(m->d_comm, &A, sizeof A, hipMemcpyHostToDevice));
+  }
   m->connected = true;
-  return IEM_OK;
-}
-
-static int halo_launch(iem_model *m, double *d_x, hipStream_t stream) {
-  const iem::ShardInfo &si = m->shard;
-  struct { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G; unsigned long long *hstatus; long long ticks; } A = {
-      d_x, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
-      m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared),
-      m->d_hstatus, (long long)m->opt.comm_timeout_ms * 100000LL};
-  size_t sz = sizeof A;
-  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_TRY(hipModuleLaunchKernel(m->fn_halo, 1, 1, 1, 256, 1, 1, 0, stream, nullptr, cfg));
   return IEM_OK;
 }
 
@@ -1588,7 +1601,8 @@ int iem_halo_exchange(iem_model *m, double *d_x) {
   const iem::ShardInfo &si = m->shard;
   if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;   // no stencil crosses the shard boundary
   DevGuard dg_(m->device);
-  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }   // one exchange at a time (the mailbox has two parity slots)
+  int rc = halo_flush(m);   // one exchange at a time (the mailbox has two parity slots)
+  if (rc) return rc;
   return halo_launch(m, d_x, m->stream);
 }
 
@@ -1598,14 +1612,9 @@ int iem_halo_exchange_async(iem_model *m, double *d_x) {
   const iem::ShardInfo &si = m->shard;
   if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;
   DevGuard dg_(m->device);
-  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }
-  // behind everything enqueued so far on the handle's stream (the producer of x), concurrent with what follows
-  HIP_TRY(hipEventRecord(m->ev_x, m->stream));
-  HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->ev_x, 0));
-  int rc = halo_launch(m, d_x, m->comm_stream);
+  int rc = halo_flush(m);   // an earlier exchange nobody carried: it goes first, in order
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(m->ev_halo, m->comm_stream));
-  m->halo_pending = true;
+  m->halo_deferred = true;
   m->halo_vec = d_x;
   return IEM_OK;
 }
@@ -1613,13 +1622,14 @@ int iem_halo_exchange_async(iem_model *m, double *d_x) {
 int iem_halo_wait(iem_model *m) {
   if (!m) return fail(IEM_E_ARG, "null handle");
   DevGuard dg_(m->device);
-  return halo_after(m);
+  return halo_flush(m);
 }
 
-int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v) {
+int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v, int *out_carrier) {
   if (!m || kind < 0 || kind > iem::KK_PAIR) return fail(IEM_E_ARG, "bad argument");
   if (out_x) *out_x = m->reads_halo_x[kind] ? 1 : 0;
   if (out_v) *out_v = m->reads_halo_v[kind] ? 1 : 0;
+  if (out_carrier) *out_carrier = (m->carrier[kind] && !m->reads_halo_x[kind]) ? 1 : 0;
   return IEM_OK;
 }
 
@@ -1629,7 +1639,7 @@ int iem_halo_fold(iem_model *m, double *d_vec) {
   const iem::ShardInfo &si = m->shard;
   if (si.halo_doubles == 0 || si.world == 1) return IEM_OK;
   DevGuard dg_(m->device);
-  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }
+  { int rc = halo_flush(m); if (rc) return rc; }
   struct { double *vec; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G, NR; unsigned long long *hstatus; long long ticks; } A = {
       d_vec, m->mailbox, si.rank > 0 ? m->peers[si.rank - 1] : nullptr, si.rank + 1 < si.world ? m->peers[si.rank + 1] : nullptr,
       m->d_halo_src, m->d_halo_dst, (long long)si.halo_doubles, (long long)si.world, (long long)reduce_chunks(1 + m->n_shared),
@@ -1660,7 +1670,7 @@ int iem_comm_status(iem_model *m, int64_t *out_status) {
   if (!m || !out_status) return fail(IEM_E_ARG, "null argument");
   if (!m->mailbox) return fail(IEM_E_ARG, "no mailbox");
   DevGuard dg_(m->device);
-  if (m->halo_pending) { int rc = halo_after(m); if (rc) return rc; }
+  { int rc = halo_flush(m); if (rc) return rc; }
   HIP_TRY(hipStreamSynchronize(m->stream));
   unsigned long long st = 0;
   HIP_TRY(hipMemcpy(&st, m->mailbox, 8, hipMemcpyDeviceToHost));

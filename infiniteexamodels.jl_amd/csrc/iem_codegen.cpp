@@ -1583,7 +1583,7 @@ class KernelBuilder {
       os << "  (void)X; (void)TH; (void)Y; (void)V; (void)FA; (void)IA; (void)A; (void)AUX; (void)lds_blk; (void)lds4; (void)BY_; (void)BZ_; (void)GX_; (void)GY_; (void)GZ_;\n";
       kd.tables_in_memory = false;
     } else {
-    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
+    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n";
     if (kd.tables_in_memory)
       os << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
     else
@@ -1595,6 +1595,14 @@ class KernelBuilder {
     os << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; (void)AUX;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
+    if (carrier()) {
+      // a pending asynchronous halo exchange rides on this launch: one EXTRA leading workgroup (column 0 of the grid;
+      // one per row on 2-D / 3-D grids, only the first works) runs it while the others evaluate — they see workgroup
+      // column blockIdx.x - 1.  A.comm is null on every other launch (and on handles that are not sharded).
+      os << "  const long long cb_ = A.comm != nullptr ? 1 : 0;\n"
+         << "  if (cb_ && blockIdx.x == 0) { if (blockIdx.y == 0 && blockIdx.z == 0) iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
+         << "  const long long BX_ = (long long)blockIdx.x - cb_;  // carrier prologue ends\n";
+    }
     if (opt_.xcd_remap) {
       os << "  const long long GX_ = gridDim.x, GY_ = gridDim.y, GZ_ = gridDim.z;\n"
          << "  const long long L_ = iem_xcd_remap((long long)blockIdx.x + GX_ * ((long long)blockIdx.y + GY_ * (long long)blockIdx.z), GX_ * GY_ * GZ_);\n"
@@ -1618,6 +1626,13 @@ class KernelBuilder {
       kd.lds_bytes = shared_lds_doubles() * 8;
     }
     os << head.str() << tail.str() << "}\n\n";
+    if (!as_body && !opt_.xcd_remap && carrier()) {
+      std::string t = os.str();
+      const std::string from = "blockIdx.x", to = "BX_";
+      for (size_t pos = t.find("// carrier prologue ends"); (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
+      kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
+      return t;
+    }
     if (as_body || opt_.xcd_remap) {
       // the body sees LOGICAL workgroup coordinates: of its own grid, decoded by the wrapper
       // (as_body), and/or remapped so that neighbours share an XCD (xcd_remap)
@@ -1641,6 +1656,11 @@ class KernelBuilder {
   // through the block store overlap their tiles by 16 lanes: the halo items are computed twice so
   // that every 128-byte line of a block is written WHOLE by one workgroup (iem_flush), instead
   // of two workgroups each writing a part of the line at every seam.
+  // kinds whose kernels can carry a pending halo exchange as an extra leading workgroup: the block-store kinds (their
+  // bodies never look at gridDim.x); the objective's and the pair's wrappers add theirs in generate()
+  bool carrier() const {
+    return !opt_.xcd_remap && (kind_ == KK_CONS || kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_JPROD);
+  }
   int qstep() const {
     const bool blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD) && opt_.store_mode == 2;
     return (blk && opt_.overlap && opt_.block >= 256) ? opt_.block - 16 : opt_.block;
@@ -2332,7 +2352,7 @@ Program generate(const Model &m, const Options &opt_in) {
     // the workgroup->body table has one entry per workgroup: in device memory always, so that the
     // argument struct (hence the source) does not depend on the launch size
     F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > tbl;
-    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
+    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n";
     if (F.tables_in_memory)
       src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
     else
@@ -2351,8 +2371,12 @@ Program generate(const Model &m, const Options &opt_in) {
     };
     if (is_obj) {
       // every lane adds the terms of its tiles b, b + gridDim.x, ... in that order; the body index only grows
+      // (a pending halo exchange rides on this launch as one extra leading workgroup; the walkers are the others)
+      src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;\n"
+          << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
+          << "  const long long bx_ = (long long)blockIdx.x - cb_, gx_ = (long long)gridDim.x - cb_;\n";
       src << "  double acc = 0.0;\n  int j_ = 0;\n"
-          << "  for (long long b = blockIdx.x; b < A.ip[" << nt_slot << "]; b += gridDim.x) {\n";
+          << "  for (long long b = bx_; b < A.ip[" << nt_slot << "]; b += gx_) {\n";
       if (ks.size() > 1)
         src << "    while (j_ + 1 < " << ks.size() << " && b >= A.ip[" << dec << " + 4 * (j_ + 1)]) ++j_;\n";
       src << "    const long long gx = A.ip[" << dec << " + 4 * j_ + 1], gy = A.ip[" << dec << " + 4 * j_ + 2], gz = A.ip[" << dec << " + 4 * j_ + 3];\n"
@@ -2362,11 +2386,11 @@ Program generate(const Model &m, const Options &opt_in) {
         // while the first is summed; a tile index past the end decodes to a workgroup column outside the
         // grid, where every lane's guard is false and the body adds 0
         src << call(0, "    ")
-            << "    { const long long b2 = b + gridDim.x; const bool in2 = b2 < A.ip[" << nt_slot << "];\n"
+            << "    { const long long b2 = b + gx_; const bool in2 = b2 < A.ip[" << nt_slot << "];\n"
             << "      const long long lb2 = b2 - A.ip[" << dec << " + 4 * j_];\n"
             << "      acc += " << descs[ks[0]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[0] << ", A.dp + " << odp[0] << ", A.fa + " << ofa[0]
             << ", A.ia + " << oia[0] << ", lds_blk, lds4, in2 ? lb2 % gx : gx, in2 ? (lb2 / gx) % gy : 0, in2 ? lb2 / (gx * gy) : 0, gx, gy, gz);\n"
-            << "      b += gridDim.x; }\n";
+            << "      b += gx_; }\n";
       } else if (ks.size() == 1) src << call(0, "    ");
       else {
         src << "    switch (j_) {\n";
@@ -2374,11 +2398,16 @@ Program generate(const Model &m, const Options &opt_in) {
         src << "    }\n";
       }
       src << "  }\n"
-          << "  iem_block_partial(acc, A.out, blockIdx.x, lds4, gridDim.x, A.aux);\n";
+          << "  iem_block_partial(acc, A.out, bx_, lds4, gx_, A.aux);\n";
       src << "}\n\n";
       P.kernels.push_back(F);
       continue;
     }
+    if (!si && !opt.xcd_remap && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
+      src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
+          << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
+          << "  const long long b = (long long)blockIdx.x - cb_;\n";
+    else
     src << "  const long long b = blockIdx.x;\n";
     if (si) src << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; long long wg_ = 0;\n";
     if (ks.size() > 4) {
@@ -2476,7 +2505,7 @@ Program generate(const Model &m, const Options &opt_in) {
         const size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
         const size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
         F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > tbl;
-        src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux;\n";
+        src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n";
         if (F.tables_in_memory)
           src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
         else
@@ -2485,7 +2514,10 @@ Program generate(const Model &m, const Options &opt_in) {
             << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
         if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
         else src << "  double* lds_blk = nullptr;\n";
-        src << "  double* lds4 = nullptr;\n  const long long b = blockIdx.x;\n";
+        src << "  double* lds4 = nullptr;\n"
+            << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
+            << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
+            << "  const long long b = (long long)blockIdx.x - cb_;\n";
         auto call = [&](size_t jj, const std::string &ind) {
           const KernelDesc &d = pd[ord[jj]];
           std::ostringstream c;

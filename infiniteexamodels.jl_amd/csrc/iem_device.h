@@ -677,18 +677,23 @@ struct IemHaloArgs {
 };
 // one workgroup: (1) my last `reach` owned supports of every sharded slab -> the right neighbour's
 // mailbox, (2) the left neighbour's -> the halo entries of my x (reference stencil:
-// /root/reference/src/transform.jl:535-557, index i-1 at :471-506)
-extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const IemHaloArgs A) {
+// /root/reference/src/transform.jl:535-557, index i-1 at :471-506).
+// Runs either as the stand-alone iem_halo_kernel (stream-ordered: iem_halo_exchange) or as the LEADING workgroup of an
+// evaluation kernel that cannot touch a halo entry itself (iem_halo_exchange_async: the exchange rides on the first
+// such launch — no launch, no stream and no event of its own — and overlaps that kernel's other workgroups; kernels
+// launched behind it see the halo entries in x).  Any workgroup size.
+__device__ __forceinline__ void iem_halo_wg(const IemHaloArgs &A, double *__restrict__ x) {
   const IemCommErr E = {A.mine + IEM_MB_STATUS, A.hstatus, A.ticks};
   const unsigned long long seq = iem_sys_load(A.mine + IEM_MB_HSEQ) + 1;
   const long long par = (long long)(seq & 1);
+  const long long nt = (long long)blockDim.x;
   __shared__ int ok_;
   if (A.right != nullptr) {
     if (threadIdx.x == 0)   // the slot of this parity was last used by seq - 2: the right neighbour must have consumed it
       ok_ = seq <= 2 || iem_wait_ge(A.mine + IEM_MB_HACK, seq - 2, E, 1ULL);
     __syncthreads();
     double *data = reinterpret_cast<double *>(A.right + iem_mb_hdata(A.W, A.G)) + par * A.NH;
-    for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) iem_sys_stored(data + e, A.x[A.src[e]]);
+    for (long long e = threadIdx.x; e < A.NH; e += nt) iem_sys_stored(data + e, x[A.src[e]]);
     iem_publish_fence();
     if (threadIdx.x == 0) iem_sys_store(A.right + IEM_MB_HFLAG + par, seq);
   }
@@ -699,7 +704,7 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const Ie
     }
     __syncthreads();
     const double *data = reinterpret_cast<const double *>(A.mine + iem_mb_hdata(A.W, A.G)) + par * A.NH;
-    for (long long e = threadIdx.x; e < A.NH; e += IEM_BLOCK) A.x[A.dst[e]] = ok_ ? iem_sys_loadd(data + e) : __builtin_nan("");   // time-out: poisoned, never stale
+    for (long long e = threadIdx.x; e < A.NH; e += nt) x[A.dst[e]] = ok_ ? iem_sys_loadd(data + e) : __builtin_nan("");   // time-out: poisoned, never stale
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) iem_sys_store(A.left + IEM_MB_HACK, seq);
@@ -707,6 +712,7 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const Ie
   __syncthreads();
   if (threadIdx.x == 0) iem_sys_store(A.mine + IEM_MB_HSEQ, seq);
 }
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_halo_kernel(const IemHaloArgs A) { iem_halo_wg(A, A.x); }
 
 // The transposed exchange, for vectors in VARIABLE space that a transposed operator produced (J'v): the entries of
 // my halo copies hold what my rows owe to the variables the LEFT neighbour owns.  (1) they go into the left

@@ -128,7 +128,7 @@ def lib():
     L.iem_halo_exchange.argtypes = [vp, vp]
     L.iem_halo_exchange_async.argtypes = [vp, vp]
     L.iem_halo_wait.argtypes = [vp]
-    L.iem_halo_reads.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.iem_halo_reads.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.iem_halo_fold.argtypes = [vp, vp]
     L.iem_allreduce_obj_grad.argtypes = [vp, vp, vp]
     L.iem_comm_status.argtypes = [vp, C.POINTER(C.c_int64)]

@@ -386,9 +386,10 @@ class ExaModel:
         return x
 
     def halo_exchange_async(self, x):
-        """The same exchange off the critical path (``iem_halo_exchange_async``): it runs on the handle's comm stream;
-        evaluation calls that can touch a halo entry of ``x`` wait for it, the others overlap it.  Nothing else may
-        touch ``x`` until the next evaluation call (or :meth:`halo_wait`)."""
+        """The same exchange off the critical path (``iem_halo_exchange_async``): nothing is launched — the exchange rides
+        on the first evaluation launch that takes ``x`` and cannot touch a halo entry of it (one extra leading workgroup
+        of that kernel); a call that can touch one gets the stand-alone exchange in front of it.  Nothing else may write
+        ``x`` or read its halo entries until that call (or :meth:`halo_wait`)."""
         self._chk(x, self.meta.nvar, "x")
         self._sync_stream()
         _lib.check(self._L.iem_halo_exchange_async(self._h, _ptr(x)))
@@ -399,12 +400,12 @@ class ExaModel:
         _lib.check(self._L.iem_halo_wait(self._h))
 
     def halo_reads(self) -> dict:
-        """Per kernel kind: can its kernels touch a halo entry through ``x`` / through a variable-space ``v``."""
+        """Per kernel kind ``(touches a halo entry through x, through a variable-space v, can carry a deferred exchange)``."""
         out = {}
         for k, name in enumerate(KERNEL_KINDS):
-            a, b = C.c_int32(), C.c_int32()
-            _lib.check(self._L.iem_halo_reads(self._h, k, C.byref(a), C.byref(b)))
-            out[name] = (bool(a.value), bool(b.value))
+            a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+            _lib.check(self._L.iem_halo_reads(self._h, k, C.byref(a), C.byref(b), C.byref(c)))
+            out[name] = (bool(a.value), bool(b.value), bool(c.value))
         return out
 
     def halo_fold(self, vec):

@@ -23,6 +23,12 @@
 struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };
 static thread_local emu_dim3 threadIdx, blockIdx, gridDim;
 
+// the deferred halo exchange that rides on an evaluation launch as an extra leading workgroup (iem_device.h: iem_halo_wg):
+// here it only counts its lanes, so that tests/emu.py can launch a kernel WITH the extra workgroup and check that every
+// other workgroup still evaluates its own tile
+struct IemHaloArgs { long long calls; };
+inline void iem_halo_wg(const IemHaloArgs &A, double *) { ++const_cast<IemHaloArgs &>(A).calls; }
+
 inline long long iem_xcd_remap(long long b, long long nb) {
   const long long p = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
   return x * p + (x < r ? x : r) + i;

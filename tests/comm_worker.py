@@ -72,11 +72,13 @@ def main():
     reads = gm.halo_reads()
     if name == "quadrotor" and rank > 0:     # difference rows: cons! reads x_k[a_r - 1], their partials are item data
         assert reads["cons"][0] and not reads["jac"][0] and not reads["hess"][0] and not reads["obj"][0], reads
+        assert reads["obj"][2] and reads["jac"][2] and reads["pair"][2] and not reads["cons"][2] and not reads["grad"][2], reads   # who can carry
 
     def loop():
         exchange(xd)
         if use_async:
-            # solver order: the calls that read no halo entry come first and overlap the exchange; cons! waits for it
+            # solver order: obj carries the deferred exchange (one extra workgroup), grad! neither touches nor carries,
+            # the fused pair and cons! find the halo entries in x
             gm.obj_device(xd, f); gm.grad(xd, g); gm.jac_hess_coord(xd, yd, jv, hv, obj_weight=0.7); gm.cons(xd, c)
         else:
             gm.cons(xd, c); gm.jac_coord(xd, jv); gm.hess_coord(xd, yd, hv, obj_weight=0.7)

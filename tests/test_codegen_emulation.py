@@ -343,3 +343,32 @@ def test_a_few_items_against_many_are_deferred(lane_fused):
         em0 = EmulatedModel(core, blob)
     assert em0.source.count("iem_grad_atomic(OUT") > 0
     assert _rel(em0.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+
+
+@pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "opf_600", "quadrotor_oc3_700", "kinetic_20", "irregular"])
+def test_a_carried_halo_exchange_leaves_every_tile_in_place(name, grid_mode):
+    """iem_halo_exchange_async: the deferred exchange rides on an evaluation launch as ONE EXTRA LEADING workgroup (column
+    0 of the grid; one per row on 2-D grids, only the first works).  Launched that way (the exchange itself stubbed: it
+    counts its lanes), every kernel kind that can carry must write exactly what it writes alone — cons!, jac_coord!,
+    hess_coord!, jprod!, the fused pair and obj (whose tile walkers and partial count must not see the extra workgroup)."""
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    v = np.random.default_rng(5).standard_normal(om.nvar)
+    ref = EmulatedModel(core, blob)
+    em = EmulatedModel(core, blob)
+    em.carry = True
+    block = em.kernels[0]["block"]
+    n = 0
+    for got, want in ((em.cons(x), ref.cons(x)), (em.jac_coord(x, om.nnzj), ref.jac_coord(x, om.nnzj)),
+                      (em.hess_coord(x, y, 0.7, om.nnzh), ref.hess_coord(x, y, 0.7, om.nnzh)), (em.jprod(x, v), ref.jprod(x, v))):
+        assert np.array_equal(got, want)
+    n += sum(1 for k in em.kernels if k["kind"] in (0, 1, 2, 5))
+    assert em.obj(x) == ref.obj(x)
+    n += sum(1 for k in em.kernels if k["kind"] == 3)
+    if any(k["kind"] == 8 for k in em.kernels):
+        jp, hp = em.jac_hess_coord(x, y, 0.7, om.nnzj, om.nnzh)
+        assert np.array_equal(jp, ref.jac_coord(x, om.nnzj)) and np.array_equal(hp, ref.hess_coord(x, y, 0.7, om.nnzh))
+        n += 1
+    assert em.carried == n * block, "exactly one workgroup per carrying launch ran the exchange"

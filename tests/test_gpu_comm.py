@@ -69,7 +69,7 @@ def test_bench_line_carries_a_checked_comm_section(built):
     # the headline step of an N > 1 line CONTAINS the halo exchange: wired in-process after the children came back clean
     assert j["halo_in_timed_loop"] is True and "behind iem_halo_exchange_async" in j["config"]["step"]
     assert j["halo"]["status_after_timed_loop"] == 0 and j["halo"]["mailbox_kind"] in (1, 2, 3)
-    assert j["halo"]["reads_halo"] == {"cons": True, "jac": False, "hess": False, "pair": False}   # difference rows are linear
+    assert j["halo"]["reads_halo_rank1"] == {"cons": True, "jac": False, "hess": False, "pair": False}   # difference rows are linear
     assert j["pair_no_halo"]["value"] > 0 and j["fused_pair"]["value"] > 0
 
 
