@@ -6,8 +6,9 @@ same run.
 
   python bench.py --gpus N --steps K --warmup W [--supports S] [--scaling strong|weak]
 
-A "step" is one jac_coord! + one hess_coord! over the resident model (inputs already
-in HBM).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the time
+A "step" is one jac_coord! + one hess_coord! over the resident model (inputs already in HBM) — by default through
+iem_jac_hess_coord, the C-ABI's one-launch form of the pair (identical bytes; `--separate` times the two calls, and the
+form that is not the timed one is always reported beside it: "separate_calls" / "fused_pair").  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the time
 axis is sharded into contiguous support blocks (halo of one support for the
 finite-difference rows); jac_coord!/hess_coord! need no collective, so ranks only meet
 at the barriers that bracket the timed region.
@@ -242,7 +243,7 @@ def comm_isolated(args, dist, rank, world, local_rank, barrier):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--comm-child", "--gpus", str(world), "--dist-backend", "gloo", "--supports", str(args.supports),
            "--scaling", args.scaling, "--steps", str(min(args.steps, 200)), "--warmup", "3", "--store-mode", str(args.store_mode),
-           "--hess-layout", args.hess_layout, "--no-cold"] + (["--same-device"] if args.same_device else []) + (["--fused"] if args.fused else []) + [a for kv in args.opt for a in ("--opt", kv)]
+           "--hess-layout", args.hess_layout, "--no-cold"] + (["--same-device"] if args.same_device else []) + (["--separate"] if args.separate else []) + [a for kv in args.opt for a in ("--opt", kv)]
     out, rc = "", -1
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -287,13 +288,16 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the jac+hess pair from a captured HIP graph instead of eager launches")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the (untimed) check of the halo exchange / objective all-reduce")
     ap.add_argument("--comm-child", action="store_true", help=argparse.SUPPRESS)   # internal: run ONLY the comm section (see comm_isolated)
-    ap.add_argument("--fused", action="store_true", help="the timed step is iem_jac_hess_coord (one launch) instead of the two calls; the other form is reported beside it")
+    ap.add_argument("--separate", action="store_true", help="the timed step is iem_jac_coord + iem_hess_coord (two launches) instead of "
+                    "iem_jac_hess_coord (one launch, the default); the other form is always reported beside it")
+    ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)   # (the default; kept so older command lines still parse)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-input measurement (K rotating x / y sets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU, no evaluation, NOT a measurement: spawn / rendezvous / reduce only (CPU test of the N>1 launch path)")
     args = ap.parse_args()
+    args.fused = not args.separate
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -489,6 +493,18 @@ def main():
     torch.cuda.synchronize()
     pair_ms = np.array([a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])])
 
+    has_pair = any(k["kind"] == "pair" for k in gm.kernels())
+    # average duration of the fused kernel: an event pair around every launch, launches back to back (what rocprofv3
+    # --kernel-trace --stats reports as the kernel's average)
+    pair_kernel_ms = None
+    if has_pair:
+        pe = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(100)]
+        for _ in range(5):
+            gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0)
+        for a, b in pe:
+            a.record(); gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0); b.record()
+        torch.cuda.synchronize()
+        pair_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in pe]))
     # the same pair with COLD inputs: K distinct (x, y) sets, > 256 MiB in total, cycled per call — per-kernel events
     cold = None
     if world == 1 and not args.no_cold and not args.graph:
@@ -509,6 +525,12 @@ def main():
         cold = {"sets": K, "input_bytes_total": int(8 * K * (gm.meta.nvar + gm.meta.ncon)),
                 "jac_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
                 "hess_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))}
+        if has_pair:
+            for i in range(nc):
+                evs[i][0].record(); gm.jac_hess_coord(xs[i % K], ys[i % K], jac, hess, obj_weight=1.0)
+                evs[i][1].record()
+            torch.cuda.synchronize()
+            cold["pair_kernel_ms"] = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
         del xs, ys
 
     reads_all = None
@@ -522,14 +544,20 @@ def main():
         # roofline of the dominant kernel, timed live with HIP events on the launch stream
         ms_jac, ms_hess = gm.time_kernels(xd, yd, jac, hess, iters=100)
         ks = {k["kind"]: k for k in gm.kernels() if k["kind"] in ("jac", "hess") and k["grid"][0] > 1}
-        dom = "hess" if ms_hess >= ms_jac else "jac"
-        kd = dict(ks[dom])
-        if gm._tuned.get(dom, -1) == 1:     # the tuner chose the handle's second code object for this buffer: its kernels carry a tag
-            kd["name"] += "_b48"
-        alg = kd["alg_bytes_read"] + kd["alg_bytes_written"]
-        ms_dom = ms_hess if dom == "hess" else ms_jac
-        achieved = alg / (ms_dom * 1e-3) / 1e9
         pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())
+        if args.fused and has_pair:
+            # the timed step is ONE kernel (both calls' workgroups behind one dispatcher): it is the dominant kernel
+            dom = "pair"
+            kd = dict([k for k in gm.kernels() if k["kind"] == "pair"][0])
+            alg, ms_dom = pair_alg, pair_kernel_ms     # (x7..x9, u1..u3 and h are loaded by both kinds' workgroups: counted per kind, as for the two calls)
+        else:
+            dom = "hess" if ms_hess >= ms_jac else "jac"
+            kd = dict(ks[dom])
+            if gm._tuned.get(dom, -1) == 1:     # the tuner chose the handle's second code object for this buffer: its kernels carry a tag
+                kd["name"] += "_b48"
+            alg = kd["alg_bytes_read"] + kd["alg_bytes_written"]
+            ms_dom = ms_hess if dom == "hess" else ms_jac
+        achieved = alg / (ms_dom * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (they need rocprofv3
         # passes of their own): read from the committed profile of the same command and size (tools/profile_gpu.sh →
         # profiles/), which records the fingerprint of the csrc tree it was taken from — `traffic_stale` says whether
@@ -554,8 +582,11 @@ def main():
                 "alg_bytes": alg, "kernel_ms": ms_dom,
                 "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
                 "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if pair_kernel_ms is not None:
+            roof["pair_kernel_ms"] = pair_kernel_ms
+            roof["pair_kernel_frac"] = pair_alg / (pair_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if cold:
-            cms = cold["hess_ms"] if dom == "hess" else cold["jac_ms"]
+            cms = cold.get("pair_kernel_ms") if dom == "pair" else cold["hess_ms"] if dom == "hess" else cold["jac_ms"]
             roof["frac_cold_inputs"] = alg / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["pair_frac_cold_inputs"] = pair_alg / ((cold["jac_ms"] + cold["hess_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["cold_inputs"] = cold

@@ -772,6 +772,7 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "big_batch_slots") == 0) { o.big_batch_slots = (int)value; return IEM_OK; }
   if (std::strcmp(name, "big_batch_jac") == 0) { o.big_batch_jac = value; return IEM_OK; }
   if (std::strcmp(name, "big_batch_hess") == 0) { o.big_batch_hess = value; return IEM_OK; }
+  if (std::strcmp(name, "big_xcd") == 0) { o.big_xcd = (int)value; return IEM_OK; }
   if (std::strcmp(name, "pair_kernel") == 0) { o.pair_kernel = (int)value; return IEM_OK; }
   if (std::strcmp(name, "store_wait") == 0) { o.store_wait = (int)value; return IEM_OK; }
   if (std::strcmp(name, "comm_timeout_ms") == 0) {
@@ -993,8 +994,7 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
       m->reads_halo_x[kd.kind] = m->reads_halo_x[kd.kind] || hits(kd.x_ranges);
       m->reads_halo_v[kd.kind] = m->reads_halo_v[kd.kind] || hits(kd.v_ranges);
     }
-    if (!m->opt.xcd_remap)
-      for (int k : {(int)iem::KK_CONS, (int)iem::KK_JAC, (int)iem::KK_HESS, (int)iem::KK_JPROD, (int)iem::KK_OBJ, (int)iem::KK_PAIR}) m->carrier[k] = true;
+    for (int k : {(int)iem::KK_CONS, (int)iem::KK_JAC, (int)iem::KK_HESS, (int)iem::KK_JPROD, (int)iem::KK_OBJ, (int)iem::KK_PAIR}) m->carrier[k] = true;
   }
   if ((rc = prepare_program(m, m->prog, m->d_tables, m->argbuf)) != IEM_OK) return bail(rc);
   // second code object for the tuner: only for block-store models with a large jac/hess grid (below ~2e5 supports

@@ -1601,12 +1601,15 @@ class KernelBuilder {
       // column blockIdx.x - 1.  A.comm is null on every other launch (and on handles that are not sharded).
       os << "  const long long cb_ = A.comm != nullptr ? 1 : 0;\n"
          << "  if (cb_ && blockIdx.x == 0) { if (blockIdx.y == 0 && blockIdx.z == 0) iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
-         << "  const long long BX_ = (long long)blockIdx.x - cb_;  // carrier prologue ends\n";
+         << "  const long long BX_ = (long long)blockIdx.x - cb_;\n";
     }
     if (opt_.xcd_remap) {
-      os << "  const long long GX_ = gridDim.x, GY_ = gridDim.y, GZ_ = gridDim.z;\n"
-         << "  const long long L_ = iem_xcd_remap((long long)blockIdx.x + GX_ * ((long long)blockIdx.y + GY_ * (long long)blockIdx.z), GX_ * GY_ * GZ_);\n"
-         << "  const long long BX_ = L_ % GX_, BY_ = (L_ / GX_) % GY_, BZ_ = L_ / (GX_ * GY_); (void)BY_; (void)BZ_; (void)GZ_;\n";
+      // (with a carried halo exchange the evaluating workgroups are columns 1 .. of the launch: workgroups that share
+      // b & 7 still share an XCD on a 1-D grid — the labels rotate by one)
+      const std::string bx = carrier() ? "BX_" : "(long long)blockIdx.x", gx = carrier() ? "((long long)gridDim.x - cb_)" : "(long long)gridDim.x";
+      os << "  const long long GX_ = " << gx << ", GY_ = gridDim.y, GZ_ = gridDim.z;\n"
+         << "  const long long L_ = iem_xcd_remap(" << bx << " + GX_ * ((long long)blockIdx.y + GY_ * (long long)blockIdx.z), GX_ * GY_ * GZ_);\n"
+         << "  const long long RX_ = L_ % GX_, BY_ = (L_ / GX_) % GY_, BZ_ = L_ / (GX_ * GY_); (void)BY_; (void)BZ_; (void)GZ_;\n";
     }
     }
     if (use_lds) {
@@ -1629,7 +1632,7 @@ class KernelBuilder {
     if (!as_body && !opt_.xcd_remap && carrier()) {
       std::string t = os.str();
       const std::string from = "blockIdx.x", to = "BX_";
-      for (size_t pos = t.find("// carrier prologue ends"); (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
+      for (size_t pos = t.find("const long long BX_ = (long long)blockIdx.x - cb_;\n") + 52; (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
       kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
       return t;
     }
@@ -1641,7 +1644,7 @@ class KernelBuilder {
       auto subst = [&](const std::string &from, const std::string &to) {
         for (size_t pos = keep; (pos = t.find(from, pos)) != std::string::npos; pos += to.size()) t.replace(pos, from.size(), to);
       };
-      subst("blockIdx.x", "BX_"); subst("blockIdx.y", "BY_"); subst("blockIdx.z", "BZ_");
+      subst("blockIdx.x", as_body ? "BX_" : "RX_"); subst("blockIdx.y", "BY_"); subst("blockIdx.z", "BZ_");
       subst("gridDim.x", "GX_"); subst("gridDim.y", "GY_"); subst("gridDim.z", "GZ_");
       kd.ip = ipv_; kd.dp = dpv_; kd.fa = fav_; kd.ia = iav_;
       return t;
@@ -1659,7 +1662,7 @@ class KernelBuilder {
   // kinds whose kernels can carry a pending halo exchange as an extra leading workgroup: the block-store kinds (their
   // bodies never look at gridDim.x); the objective's and the pair's wrappers add theirs in generate()
   bool carrier() const {
-    return !opt_.xcd_remap && (kind_ == KK_CONS || kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_JPROD);
+    return kind_ == KK_CONS || kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_JPROD;
   }
   int qstep() const {
     const bool blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD) && opt_.store_mode == 2;
@@ -1902,7 +1905,10 @@ static Options kind_options(const Options &opt, const Group &g, int kind) {
   if (thr <= 0) return ko;
   KernelDesc probe;
   launch_grid(g, (opt.overlap && opt.block >= 256) ? opt.block - 16 : opt.block, probe);
-  if (probe.n_blocks >= thr) ko.lds_slots = opt.big_batch_slots;
+  if (probe.n_blocks >= thr) {
+    ko.lds_slots = opt.big_batch_slots;
+    if (opt.big_xcd) ko.xcd_remap = 1;
+  }
   return ko;
 }
 
@@ -2403,12 +2409,14 @@ Program generate(const Model &m, const Options &opt_in) {
       P.kernels.push_back(F);
       continue;
     }
-    if (!si && !opt.xcd_remap && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
+    if (!si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
           << "  const long long b = (long long)blockIdx.x - cb_;\n";
     else
     src << "  const long long b = blockIdx.x;\n";
+    bool any_remap = false;   // (many bodies = templates side by side on small grids: one flag for all of them)
+    for (size_t k : ks) any_remap = any_remap || kopts[k].xcd_remap;
     if (si) src << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; long long wg_ = 0;\n";
     if (ks.size() > 4) {
       // many bodies (one per template on a small grid): binary search of the workgroup id in the
@@ -2422,7 +2430,7 @@ Program generate(const Model &m, const Options &opt_in) {
           << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n";
       src
           << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
-          << "  const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)"
+          << "  const long long lb = " << (any_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)"
                                                           : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]") << ";\n";
       if (si) src << "  wg_ = A.ip[" << sh_off << " + lo_] + lb;\n";
       src << "  switch (lo_) {\n";
@@ -2434,7 +2442,7 @@ Program generate(const Model &m, const Options &opt_in) {
       src << "  " << (j ? "else " : "");
       if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
       src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-          << "    const long long lb = " << (opt.xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n";
+          << "    const long long lb = " << (kopts[ks[j]].xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n";
       if (si) src << "    wg_ = A.ip[" << (sh_off + j) << "] + lb;\n";
       src << call(j, "    ") << "  }\n";
     }
@@ -2455,6 +2463,7 @@ Program generate(const Model &m, const Options &opt_in) {
     if (have[0] && have[1]) {
       std::vector<std::unique_ptr<KernelBuilder>> pb;
       std::vector<KernelDesc> pd;
+      std::vector<bool> pxcd;
       int64_t nnz_again = 0;
       std::vector<HessClass> classes_again;
       for (size_t k : ks) {   // in the order of the first pass: the merged Hessian layout's offsets are running counters
@@ -2467,6 +2476,7 @@ Program generate(const Model &m, const Options &opt_in) {
         if (kd.kind == KK_HESS && opt.hess_merge) kb->merge_hess(nnz_again, classes_again);
         pb.push_back(std::move(kb));
         pd.push_back(kd);
+        pxcd.push_back(kopts[k].xcd_remap != 0);
       }
       std::vector<size_t> ord(pd.size());
       for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
@@ -2525,12 +2535,15 @@ Program generate(const Model &m, const Options &opt_in) {
             << ", A.fa + " << ofa[jj] << ", A.ia + " << oia[jj] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n";
           return c.str();
         };
+        bool pair_remap = false;
+        for (bool f : pxcd) pair_remap = pair_remap || f;
         if (ord.size() > 4) {
           if (table) src << "  const int lo_ = (int)A.ip[" << tbl << " + b];\n";
           else src << "  int lo_ = 0, hi_ = " << ord.size() << ";\n"
                    << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n";
           src << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
-              << "  const long long lb = b - A.ip[" << dec << " + 4 * lo_];\n  switch (lo_) {\n";
+              << "  const long long lb = " << (pair_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)" : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]")
+              << ";\n  switch (lo_) {\n";
           for (size_t jj = 0; jj < ord.size(); ++jj) src << "    case " << jj << ":\n" << call(jj, "      ") << "      break;\n";
           src << "  }\n";
         } else
@@ -2539,7 +2552,8 @@ Program generate(const Model &m, const Options &opt_in) {
             src << "  " << (jj ? "else " : "");
             if (jj + 1 < ord.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
             src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-                << "    const long long lb = b - A.ip[" << e << "];\n" << call(jj, "    ") << "  }\n";
+                << "    const long long lb = " << (pxcd[ord[jj]] ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
+                << call(jj, "    ") << "  }\n";
           }
         src << "}\n\n";
         P.kernels.push_back(F);

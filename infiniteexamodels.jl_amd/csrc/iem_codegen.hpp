@@ -79,12 +79,16 @@ struct Options {
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)
   int obj_unroll = 1;  // 2: the objective's tile walk takes two tiles per trip (single-body kernels)
   int det_shared = 1;  // 1: scatter entries shared by many items are reduced deterministically (iem_shared_*), 0: one f64 atomic per wave
-  // Large grids stage a LARGER batch per barrier pair (one 96-KB workgroup per CU instead of three 48-KB ones: a third of
-  // the concurrently open store streams).  Chosen from the GRID SIZE, per kind, never from a timer: jac_coord! with its
-  // 18 narrow streams from `big_batch_jac` workgroups on (placement-insensitive there), hess_coord! from
-  // `big_batch_hess` on (its 7 wide streams only gain above the Infinity Cache).  0: never.
+  // LARGE grids — outputs far beyond the 256-MiB Infinity Cache, everything goes to DRAM — get another kernel shape, chosen
+  // from the GRID SIZE per kind (never from a timer): jac_coord! / hess_coord! kernels of at least `big_batch_jac` /
+  // `big_batch_hess` workgroups (4000: about 2e6 quadrotor supports; 0: never) stage `big_batch_slots` values per barrier
+  // pair — one 96-KB workgroup per CU instead of three 48-KB ones, a third of the concurrently open store streams — and
+  // (`big_xcd`) walk their tiles XCD-aware: consecutive tiles on ONE XCD, so that neighbouring chunks of a store stream leave
+  // through one L2.  In-process A/Bs (profiles/r03_ab_large_grid_shape.txt): 2e6 supports jac -10 % / hess -3 %, 4e6 jac
+  // -5..-8 % / hess -5..-7 %; below ~1e6 neither knob wins reliably (the buffers' placement moves the same kernel by more).
   int big_batch_slots = 48;
-  int64_t big_batch_jac = 400, big_batch_hess = 4000;
+  int64_t big_batch_jac = 4000, big_batch_hess = 4000;
+  int big_xcd = 1;
   int pair_kernel = 1;     // 1: also emit the fused jac_coord! + hess_coord! launch (KK_PAIR, iem_jac_hess_coord)
   int store_wait = 0;      // experiment: s_waitcnt vmcnt(0) behind every flushed batch (paces a wave's outstanding stores)
   // runtime only (the generator ignores them)

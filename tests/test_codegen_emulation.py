@@ -69,24 +69,22 @@ def test_generated_source_is_size_independent(built):
     assert len(large) == 1 and len(small) == 1 and large != small
     with iemlib.options(split_small=0):
         assert {key(100)} == large       # the lane-fused source is the same at any size
-    # the staging batch of jac_coord! / hess_coord! is a function of the grid size (big_batch_jac = 400, big_batch_hess =
-    # 4000 workgroups): two more shapes, each again one code object for all of its sizes — and what build() compiles for
-    # them from a small model with lowered thresholds IS what a model of that size asks for at run time
-    mid = {key(S) for S in (250_000, 600_000)}
-    assert len(mid) == 1 and mid != large
-    with iemlib.options(split_small=0, big_batch_jac=1):
-        assert {key(2000)} == mid
+    # LARGE grids (>= 4000 workgroups, about 2e6 supports) get another kernel shape (48-slot staging batch, XCD-aware tile
+    # walk): again one code object for all of its sizes — and what build() compiles for it from a small model with lowered
+    # thresholds IS what a model of that size asks for at run time
     with iemlib.options(split_small=0, big_batch_jac=1, big_batch_hess=1):
         huge = {key(2000)}
-    with iemlib.options(big_batch_hess=500):      # (a 2.2e6-support model, without building one)
-        assert {key(300_000)} == huge and huge != mid
+    with iemlib.options(big_batch_jac=500, big_batch_hess=500):      # (a 2.2e6-support model, without building one)
+        assert {key(300_000)} == huge and huge != large
+    with iemlib.options(big_batch_jac=0, big_batch_hess=0):
+        assert {key(300_000)} == large
 
 
 @pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "opf_600", "quadrotor_oc3_700"])
-@pytest.mark.parametrize("big", [dict(big_batch_jac=1), dict(big_batch_jac=1, big_batch_hess=1)])
+@pytest.mark.parametrize("big", [dict(big_batch_jac=1, big_batch_hess=0), dict(big_batch_jac=1, big_batch_hess=1), dict(big_batch_jac=1, big_batch_hess=1, big_xcd=0)])
 def test_large_grid_staging_batch_writes_the_same_values(name, big, lane_fused):
-    """The large-grid shapes (48-slot staging batch for jac_coord! only / for both) against the oracle, stand-alone
-    kernels and the fused pair — the batch size moves barriers, never values."""
+    """The large-grid shape (48-slot staging batch + XCD-aware tile walk; for jac_coord! only, for both, without the remap)
+    against the oracle, stand-alone kernels and the fused pair — it moves barriers and tiles, never values."""
     from infiniteexamodels.jl_amd import lib as iemlib
     core = cases.build_core(name)
     blob = core.to_blob()

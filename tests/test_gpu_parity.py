@@ -513,9 +513,11 @@ def test_obj_begin_end_protocol(torch_cuda):
     gm.close()
 
 
-@pytest.mark.parametrize("opts", [dict(big_batch_jac=1), dict(big_batch_jac=1, big_batch_hess=1), dict(pair_kernel=0)])
+@pytest.mark.parametrize("opts", [dict(big_batch_jac=1, big_batch_hess=0), dict(big_batch_jac=1, big_batch_hess=1), dict(big_batch_jac=1, big_batch_hess=1, big_xcd=0),
+                                  dict(xcd_remap=1), dict(pair_kernel=0)])
 def test_large_grid_shapes_and_pair_fallback_on_gpu(opts, torch_cuda):
-    """The large-grid staging batch (jac only / both) and a handle WITHOUT the fused kernel (iem_jac_hess_coord then makes
+    """The large-grid kernel shape (staging batch for jac only / both, with and without the XCD-aware walk), the XCD remap
+    everywhere, and a handle WITHOUT the fused kernel (iem_jac_hess_coord then makes
     the two calls) write the bytes of the default handle."""
     torch = torch_cuda
     from infiniteexamodels.jl_amd.model import ExaModel

@@ -195,17 +195,16 @@ def test_shard_kernels_are_rank_world_and_size_independent(built):
     with iemlib.options(split_small=0):
         first = {iemlib.emit_source(iemlib.shard_blob(g_small, 1, 0, 2)[0])[1], iemlib.emit_source(g_small)[1]}
         later = {iemlib.emit_source(iemlib.shard_blob(g_small, 1, 1, 2)[0])[1]}
-    # (the staging batch of jac_coord! is a function of the grid size — 400 workgroups up, test_codegen_emulation —, a
-    # deliberate third shape; switched off here: this test is about what rank and world size must NOT change)
-    with iemlib.options(big_batch_jac=0):
-        for r, w in ((0, 8), (0, 3)):
-            first.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
-        for r, w in ((1, 8), (3, 8), (7, 8), (1, 2), (2, 3)):
-            later.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
+    for r, w in ((0, 8), (0, 3)):
+        first.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
+    for r, w in ((1, 8), (3, 8), (7, 8), (1, 2), (2, 3)):
+        later.add(iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1])
     assert len(first) == 1 and len(later) == 1 and first != later
-    # ... and with it on, shards on either side of the threshold are each one of the two code objects of their regime
-    big_first = {iemlib.emit_source(iemlib.shard_blob(g_big, 1, 0, w)[0])[1] for w in (2, 3)}
-    big_later = {iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1] for r, w in ((1, 2), (2, 3))}
+    # the large-grid kernel shape (a function of the grid size: >= 4000 workgroups; lowered here) is again one code object
+    # for every first shard and one for every later shard
+    with iemlib.options(big_batch_jac=300, big_batch_hess=300):
+        big_first = {iemlib.emit_source(iemlib.shard_blob(g_big, 1, 0, w)[0])[1] for w in (2, 3)}
+        big_later = {iemlib.emit_source(iemlib.shard_blob(g_big, 1, r, w)[0])[1] for r, w in ((1, 2), (2, 3))}
     assert len(big_first) == 1 and len(big_later) == 1 and big_first != first and big_later != later
 
 

@@ -54,5 +54,14 @@ for rnd in range(3):
                     step()
                 e1.record(); torch.cuda.synchronize()
                 cell += f" pair {e0.elapsed_time(e1) / 100:.4f}"
+                if os.environ.get("IEM_AB_FUSED"):     # ... and the one-launch form (iem_jac_hess_coord)
+                    fstep = m.raw_pair(xd, yd, jb, hb, obj_weight=1.0, fused=True)
+                    for _ in range(10):
+                        fstep()
+                    torch.cuda.synchronize(); e0.record()
+                    for _ in range(100):
+                        fstep()
+                    e1.record(); torch.cuda.synchronize()
+                    cell += f" fused {e0.elapsed_time(e1) / 100:.4f}"
             row.append(cell)
         print(f"round {rnd} {v:28s} jac/hess ms into 3 buffer pairs: " + "  ".join(row), flush=True)
