@@ -341,6 +341,31 @@ class ExaModel:
                     check(rc)
         return step
 
+    def raw_loop(self, x, y, g, c, jac, hess, obj_weight: float = 1.0, fused: bool = True, defer_obj: bool = True):
+        """``step() -> f`` closure: the five evaluations a solver makes at one point — obj, grad!, cons!, jac_coord!,
+        hess_coord! (``ext/InfiniteExaModelsIpopt.jl:48-49``) — on fixed buffers, argument checks and stream lookup done
+        once.  ``defer_obj``: the objective is launched FIRST (``iem_obj_begin``) and its value collected LAST
+        (``iem_obj_end``), so the scalar's host round trip overlaps the other four calls instead of stalling the host in
+        front of them; ``fused``: jac_coord! + hess_coord! through the one-launch form."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(y, self.meta.ncon, "y"); self._chk(g, self.meta.nvar, "g")
+        self._chk(c, self.meta.ncon, "c"); self._chk(jac, self.meta.nnzj, "vals"); self._chk(hess, self.meta.nnzh, "vals")
+        self._sync_stream()
+        L, h, check = self._L, self._h, _lib.check
+        px, py, pg, pc, pj, ph, w = _ptr(x), _ptr(y), _ptr(g), _ptr(c), _ptr(jac), _ptr(hess), float(obj_weight)
+        out = C.c_double()
+        ref = C.byref(out)
+        obj, begin, end, grad, cons = L.iem_obj, L.iem_obj_begin, L.iem_obj_end, L.iem_grad, L.iem_cons
+        jacf, hessf, pair = L.iem_jac_coord, L.iem_hess_coord, L.iem_jac_hess_coord
+
+        def step():
+            rc = (begin(h, px) if defer_obj else obj(h, px, ref)) or grad(h, px, pg) or cons(h, px, pc) or \
+                (pair(h, px, py, w, pj, ph) if fused else (jacf(h, px, pj) or hessf(h, px, py, w, ph))) or \
+                (end(h, ref) if defer_obj else 0)
+            if rc:
+                check(rc)
+            return out.value
+        return step
+
     # ---- sharding / multi-GPU ------------------------------------------------------
     def shard_info(self) -> dict:
         t = _lib.ShardT()

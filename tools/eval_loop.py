@@ -34,10 +34,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="generator knob name=value (repeatable)")
     ap.add_argument("--products", action="store_true", help="also time jprod!/jtprod!/hprod! (event-timed, outside the loop figures)")
     args = ap.parse_args()
-    from infiniteexamodels.jl_amd import lib as iemlib
-    for kv in args.opt:
-        k, v = kv.split("=")
-        iemlib.set_option(k, int(v))
+    args.options = {k: int(v) for k, v in (kv.split("=") for kv in args.opt)}     # per handle (iem_create_opts)
     print(json.dumps(measure(args)))
 
 
@@ -69,7 +66,7 @@ def measure(args):
         im = workloads.quadrotor(args.supports)
         desc = f"quadrotor, {args.supports} supports"
     core = transcribe.exa_core(im)
-    gm = ExaModel(core, device=0)
+    gm = ExaModel(core, device=0, options=getattr(args, "options", None))
     t_build = time.perf_counter() - t0
     rng = np.random.default_rng(0)
     x0 = gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)
@@ -110,6 +107,37 @@ def measure(args):
             f()
     torch.cuda.synchronize()
     loop_ms = (time.perf_counter() - t0) / args.iters * 1e3
+    # the solver-facing forms of the same loop through prebound C calls (what a compiled host — the Julia ccall shim —
+    # pays): (a) the five calls in order, obj returning its scalar before anything else is launched; (b) obj DEFERRED:
+    # iem_obj_begin first, iem_obj_end after the last launch; (c) deferred + the one-launch jac/hess pair
+    forms = {}
+    for name, kw in (("five_calls", dict(fused=False, defer_obj=False)), ("obj_deferred", dict(fused=False, defer_obj=True)),
+                     ("obj_deferred_fused_pair", dict(fused=True, defer_obj=True))):
+        step = gm.raw_loop(x, y, g, c, jv, hv, obj_weight=1.0, **kw)
+        for _ in range(10):
+            fval = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            step()
+        torch.cuda.synchronize()
+        forms[name] = (time.perf_counter() - t0) / args.iters * 1e3
+    assert fval == gm.obj(x)
+    # what obj costs IN the loop: the deferred loop against the same loop without any objective call
+    L_, h_ = gm._L, gm._h
+    px, py, pg, pc, pj, ph = (t.data_ptr() for t in (x, y, g, c, jv, hv))
+    def no_obj():
+        L_.iem_grad(h_, px, pg); L_.iem_cons(h_, px, pc); L_.iem_jac_coord(h_, px, pj); L_.iem_hess_coord(h_, px, py, 1.0, ph)
+    for _ in range(10):
+        no_obj()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        no_obj()
+    torch.cuda.synchronize()
+    forms["four_calls_without_obj"] = (time.perf_counter() - t0) / args.iters * 1e3
+    forms["obj_in_loop_us"] = {"blocking": (forms["five_calls"] - forms["four_calls_without_obj"]) * 1e3,
+                               "deferred": (forms["obj_deferred"] - forms["four_calls_without_obj"]) * 1e3}
     # the same loop captured in a HIP graph (obj kept on the device)
     fdev = torch.zeros(1, dtype=torch.float64, device="cuda")
 
@@ -140,7 +168,7 @@ def measure(args):
     out = {
         "workload": desc, "nvar": gm.meta.nvar, "ncon": gm.meta.ncon, "nnzj": gm.meta.nnzj, "nnzh": gm.meta.nnzh,
         "n_kernels": gm.meta.n_kernels, "build_s": t_build, "loop_ms": loop_ms, "loops_per_s": 1e3 / loop_ms,
-        "graph_loop_ms": graph_ms, "graph_loops_per_s": 1e3 / graph_ms,
+        "graph_loop_ms": graph_ms, "graph_loops_per_s": 1e3 / graph_ms, "loop_forms_ms": forms,
         "ms": ms, "alg_bytes": bytes_,
         "GBps": {k: (bytes_[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else None) for k in ms},
     }
