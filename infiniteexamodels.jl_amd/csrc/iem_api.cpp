@@ -30,6 +30,9 @@
 static const char *kDeviceHeader =
 #include "iem_device_h.inc"
     ;
+static const char *kKktSource =
+#include "iem_kkt_device_h.inc"
+    ;
 
 namespace {
 
@@ -123,7 +126,7 @@ struct iem_model {
   hipStream_t stream = nullptr;
   hipModule_t mod = nullptr;
   std::vector<hipFunction_t> fns;
-  hipFunction_t fn_struct = nullptr, fn_csr = nullptr, fn_csr32 = nullptr, fn_axis = nullptr;
+  hipFunction_t fn_struct = nullptr, fn_csr = nullptr, fn_csr32 = nullptr, fn_axis = nullptr, fn_spmv = nullptr, fn_spmv_long = nullptr;
   long long *d_axis[iem::KK_COUNT] = {};
   long long *d_gather[iem::KK_COUNT] = {};   // per scatter kind: dest | seg | perm of its plan-driven gather (iem_gather_sum_kernel)
   hipFunction_t fn_gather = nullptr;   // per scatter kind: table of its axis sums (iem_axis_sum_kernel)
@@ -184,6 +187,9 @@ struct iem_model {
   void *d_comm = nullptr;        // IemHaloArgs in device memory (x unused: the carrier kernel passes its own)
   bool reads_halo_x[iem::KK_PAIR + 1] = {}, reads_halo_v[iem::KK_PAIR + 1] = {}, carrier[iem::KK_PAIR + 1] = {};
   uint64_t nonce = 0;
+  // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
+  struct KktMod { hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr; };
+  std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
   std::vector<void *> d_tables;    // per kernel: device copy of {ip, dp, fa, ia} when they do not fit the argument block
@@ -268,6 +274,25 @@ int jit_compile(iem_model *m, const std::string &src, const std::string &dir, co
   return IEM_OK;
 }
 
+// code object of a complete HIP source (code-object cache next to the library -> hiprtc on a miss)
+int load_source(iem_model *m, const std::string &src, hipModule_t *mod) {
+  const uint64_t key = iem::fnv1a64(src);
+  const std::string dir = cache_dir();
+  const std::string path = dir + "/iem_" + key_hex(key) + ".hsaco";
+  std::vector<char> code;
+  bool loaded = false;
+  if (read_file(path, code)) {
+    loaded = hipModuleLoadData(mod, code.data()) == hipSuccess;
+    if (!loaded) { *mod = nullptr; (void)hipGetLastError(); }
+  }
+  if (!loaded) {
+    int rc = jit_compile(m, src, dir, path, code);
+    if (rc) return rc;
+    HIP_TRY(hipModuleLoadData(mod, code.data()));
+  }
+  return IEM_OK;
+}
+
 // code object of `prog` (cache -> hiprtc on a miss) and its kernel functions
 int load_program(iem_model *m, const iem::Program &prog, const iem::Options &opt, hipModule_t *mod, std::vector<hipFunction_t> *fns) {
   const std::string src = full_source(prog, opt);
@@ -298,6 +323,8 @@ int compile_or_load(iem_model *m) {
   HIP_TRY(hipModuleGetFunction(&m->fn_struct, m->mod, "iem_structure_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr, m->mod, "iem_csr_gather_sum"));
   HIP_TRY(hipModuleGetFunction(&m->fn_csr32, m->mod, "iem_csr_gather_sum32"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_spmv, m->mod, "iem_csr_spmv_kernel"));
+  HIP_TRY(hipModuleGetFunction(&m->fn_spmv_long, m->mod, "iem_csr_spmv_long_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_axis, m->mod, "iem_axis_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_gather, m->mod, "iem_gather_sum_kernel"));
   HIP_TRY(hipModuleGetFunction(&m->fn_halo, m->mod, "iem_halo_kernel"));
@@ -1053,6 +1080,7 @@ int iem_destroy(iem_model *m) {
   if (m->d_shared) hipFree(m->d_shared);
   if (m->h_obj) hipHostFree(m->h_obj);
   if (m->d_comm) hipFree(m->d_comm);
+  for (auto &kv : m->kkt_mods) if (kv.second.mod) hipModuleUnload(kv.second.mod);
   for (auto &kv : m->d_arrays) hipFree(kv.second);
   for (void *t : m->d_tables) if (t) hipFree(t);
   for (void *t : m->alt.d_tables) if (t) hipFree(t);
@@ -1323,6 +1351,22 @@ int iem_csr_values32(iem_model *m, int64_t n_csr, const uint32_t *d_seg, const u
   long long n = n_csr;
   void *args[] = {(void *)&d_seg, (void *)&d_perm, (void *)&d_coo, (void *)&d_csr, (void *)&n};
   HIP_TRY(hipModuleLaunchKernel(m->fn_csr32, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
+  return IEM_OK;
+}
+
+int iem_csr_spmv(iem_model *m, int64_t n, const int32_t *d_rowptr, const int32_t *d_colind, const double *d_vals, const double *d_x, double *d_y,
+                 int64_t n_long, const int64_t *d_long_rows) {
+  if (!m || n < 0 || n_long < 0 || (n && (!d_rowptr || !d_colind || !d_vals || !d_x || !d_y)) || (n_long && !d_long_rows)) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
+  if (n == 0) return IEM_OK;
+  long long nn = n;
+  int skip = n_long > 0 ? IEM_SPMV_LONG_ROW : 0;
+  void *args[] = {(void *)&d_rowptr, (void *)&d_colind, (void *)&d_vals, (void *)&d_x, (void *)&d_y, (void *)&nn, (void *)&skip};
+  HIP_TRY(hipModuleLaunchKernel(m->fn_spmv, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
+  if (n_long > 0) {
+    void *largs[] = {(void *)&d_rowptr, (void *)&d_colind, (void *)&d_vals, (void *)&d_x, (void *)&d_y, (void *)&d_long_rows};
+    HIP_TRY(hipModuleLaunchKernel(m->fn_spmv_long, (unsigned)n_long, 1, 1, 256, 1, 1, 0, m->stream, largs, nullptr));
+  }
   return IEM_OK;
 }
 
@@ -1675,6 +1719,114 @@ int iem_comm_status(iem_model *m, int64_t *out_status) {
   unsigned long long st = 0;
   HIP_TRY(hipMemcpy(&st, m->mailbox, 8, hipMemcpyDeviceToHost));
   *out_status = (int64_t)st;
+  return IEM_OK;
+}
+
+/* ---- chain KKT solver ------------------------------------------------------------------------------ */
+namespace {
+std::string kkt_source(int nb, int ne) {
+  std::string s = "// iem-flags: -O3 -ffp-contract=off -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+  s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n";
+  s += kKktSource;
+  return s;
+}
+int kkt_module(iem_model *m, int nb, int ne, iem_model::KktMod **out) {
+  if (nb < 4 || nb > 96 || nb % 4 || ne < 0 || ne > 64 || ne % 4 || 16LL * nb * (nb + 1) + 16LL * nb * (ne + 1) + 4096 > 160 * 1024)
+    return fail(IEM_E_ARG, "chain KKT: block size must be a multiple of 4 in 4..96, border size a multiple of 4 in 0..64, two tiles of each within 160 KB of LDS");
+  auto it = m->kkt_mods.find({nb, ne});
+  if (it == m->kkt_mods.end()) {
+    iem_model::KktMod km;
+    int rc = load_source(m, kkt_source(nb, ne), &km.mod);
+    if (rc) return rc;
+    HIP_TRY(hipModuleGetFunction(&km.elim, km.mod, "kkt_eliminate"));
+    HIP_TRY(hipModuleGetFunction(&km.upd, km.mod, "kkt_update"));
+    HIP_TRY(hipModuleGetFunction(&km.fwd, km.mod, "kkt_forward"));
+    HIP_TRY(hipModuleGetFunction(&km.bwd, km.mod, "kkt_backward"));
+    it = m->kkt_mods.emplace(std::make_pair(nb, ne), km).first;
+  }
+  *out = &it->second;
+  return IEM_OK;
+}
+struct KktArgsH { double *D, *B, *X, *Y, *E, *Z, *Gp; long long *info; long long S, s; int final_block; double tiny; };
+struct KktSolveArgsH { const double *D, *X, *Y, *Z; double *r, *rBp; const double *xB; long long S, s; int final_block; };
+int kkt_launch_raw(iem_model *m, hipFunction_t fn, void *args, size_t sz, long long grid, unsigned block) {
+  if (grid <= 0) return IEM_OK;
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, 0, m->stream, nullptr, cfg));
+  return IEM_OK;
+}
+int kkt_launch(iem_model *m, hipFunction_t fn, KktArgsH a, long long grid, unsigned block) { return kkt_launch_raw(m, fn, &a, sizeof a, grid, block); }
+int kkt_launch_solve(iem_model *m, hipFunction_t fn, KktSolveArgsH a, long long grid, unsigned block) { return kkt_launch_raw(m, fn, &a, sizeof a, grid, block); }
+}  // namespace
+
+int iem_kkt_source(int nb, int ne, char **out_src, uint64_t *out_key) {
+  const std::string s = kkt_source(nb, ne);
+  if (out_src) { *out_src = (char *)std::malloc(s.size() + 1); std::memcpy(*out_src, s.c_str(), s.size() + 1); }
+  if (out_key) *out_key = iem::fnv1a64(s);
+  return IEM_OK;
+}
+
+int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, double *d_D, double *d_B, double *d_X, double *d_Y, double *d_E,
+                         double *d_Z, double *d_Gp, int64_t *d_info, double tiny) {
+  const bool chained = d_B != nullptr;   // d_B == NULL: the blocks do not couple to each other (reach 0), only to the border
+  if (!m || S < 1 || !d_D || (chained && (!d_X || !d_Y)) || !d_info || (ne > 0 && (!d_E || !d_Z || !d_Gp))) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
+  iem_model::KktMod *km = nullptr;
+  int rc = kkt_module(m, nb, ne, &km);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_info, 0, 24, m->stream));
+  const unsigned wg = (nb / 4) * (nb / 4) <= 128 ? 128u : 256u;   // KKT_T of csrc/iem_kkt_device.h
+  KktArgsH A{d_D, d_B, d_X, d_Y, d_E, d_Z, d_Gp, (long long *)d_info, (long long)S, 1, 0, tiny};
+  if (!chained) {   // one launch: every block against the border
+    A.final_block = 2;
+    return kkt_launch(m, km->elim, A, S, wg);
+  }
+  for (long long s = 1; s < S; s *= 2) {   // level: eliminate the odd multiples of s, fold them into the even ones
+    A.s = s;
+    const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
+    if ((rc = kkt_launch(m, km->elim, A, n_elim, wg)) != IEM_OK) return rc;
+    if ((rc = kkt_launch(m, km->upd, A, n_surv, wg)) != IEM_OK) return rc;
+  }
+  A.final_block = 1;
+  return kkt_launch(m, km->elim, A, 1, wg);
+}
+
+int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, const double *d_Dinv, const double *d_X, const double *d_Y, const double *d_Z,
+                        double *d_r, double *d_rBp, const double *d_xB, int phase) {
+  const bool chained = d_X != nullptr;   // as in iem_kkt_chain_factor
+  if (!m || S < 1 || !d_Dinv || (chained && !d_Y) || !d_r || (ne > 0 && (!d_Z || (phase == 0 && !d_rBp) || (phase == 1 && !d_xB)))) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
+  iem_model::KktMod *km = nullptr;
+  int rc = kkt_module(m, nb, ne, &km);
+  if (rc) return rc;
+  KktSolveArgsH A{d_Dinv, d_X, d_Y, d_Z, d_r, d_rBp, d_xB, (long long)S, 1, 0};
+  if (!chained) {            // independent blocks: the border terms of all blocks (forward), every block's own solve (backward)
+    if (phase != 0 && phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
+    A.final_block = 2;
+    if (phase == 0) return ne > 0 ? kkt_launch_solve(m, km->fwd, A, S, 64) : IEM_OK;
+    return kkt_launch_solve(m, km->bwd, A, S, 64);
+  }
+  if (phase == 0) {          // forward: levels up, then the last block's border contribution
+    for (long long s = 1; s < S; s *= 2) {
+      A.s = s;
+      const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
+      if ((rc = kkt_launch_solve(m, km->fwd, A, n_surv + (ne > 0 ? n_elim : 0), 64)) != IEM_OK) return rc;
+    }
+    A.final_block = 1;
+    return ne > 0 ? kkt_launch_solve(m, km->fwd, A, 1, 64) : IEM_OK;
+  }
+  if (phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
+  A.final_block = 1;
+  if ((rc = kkt_launch_solve(m, km->bwd, A, 1, 64)) != IEM_OK) return rc;
+  A.final_block = 0;
+  long long top = 1;
+  while (top * 2 < S) top *= 2;
+  for (long long s = top; s >= 1; s /= 2) {
+    if (s >= S) continue;
+    A.s = s;
+    const long long n_elim = (S - s + 2 * s - 1) / (2 * s);
+    if ((rc = kkt_launch_solve(m, km->bwd, A, n_elim, 64)) != IEM_OK) return rc;
+  }
   return IEM_OK;
 }
 

@@ -545,6 +545,37 @@ extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_gather_sum32(con
   csr[i] = acc;
 }
 
+// y = A x for a CSR matrix with 32-bit indices (the assembled KKT matrix: residuals of the chain solver's iterative
+// refinement, kkt_chain.py).  Rows are short (4-5 entries on average): one thread per row — except the few LONG rows (the
+// column of a first-stage variable in J' has an entry per scenario: 1e5 of them), which `skip_longer` leaves to
+// iem_csr_spmv_long_kernel: one workgroup per listed row, fixed summation order (strided partials, LDS tree).
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_spmv_kernel(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                                           const double *__restrict__ vals, const double *__restrict__ x,
+                                                                           double *__restrict__ y, long long n, int skip_longer) {
+  const long long i = (long long)blockIdx.x * IEM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int lo = rowptr[i], hi = rowptr[i + 1];
+  if (skip_longer > 0 && hi - lo > skip_longer) return;
+  double acc = 0.0;
+  for (int k = lo; k < hi; ++k) acc += vals[k] * x[colind[k]];
+  y[i] = acc;
+}
+extern "C" __global__ __launch_bounds__(IEM_BLOCK) void iem_csr_spmv_long_kernel(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                                                const double *__restrict__ vals, const double *__restrict__ x,
+                                                                                double *__restrict__ y, const long long *__restrict__ rows) {
+  __shared__ double part_[IEM_BLOCK];
+  const long long i = rows[blockIdx.x];
+  double acc = 0.0;
+  for (int k = rowptr[i] + (int)threadIdx.x; k < rowptr[i + 1]; k += IEM_BLOCK) acc += vals[k] * x[colind[k]];
+  part_[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = IEM_BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part_[threadIdx.x] += part_[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) y[i] = part_[0];
+}
+
 // ---- sums over a non-lane axis of a scatter kind (Program::AxisSum) ----------------------------------
 // The kind's kernels parked one addend per item at aux[off + row*n0 + lane]; entry e (blockIdx.y) writes
 // out[c + k0*lane] = the sum of the lane's column.  A workgroup takes 64 lanes x 4 row groups: thread (l, g) adds

@@ -80,7 +80,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_obj_begin", "iem_obj_end", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jac_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_csr_spmv", "iem_kkt_chain_factor", "iem_kkt_chain_solve", "iem_kkt_source", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
 
@@ -156,6 +156,10 @@ def lib():
         getattr(L, f).argtypes = [vp, vp, vp, i32]
     L.iem_csr_values.argtypes = [vp, i64, vp, vp, vp, vp]
     L.iem_csr_values32.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.iem_csr_spmv.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp]
+    L.iem_kkt_chain_factor.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl]
+    L.iem_kkt_chain_solve.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.iem_kkt_source.argtypes = [i32, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     L.iem_emit_source.restype = i32
     L.iem_free.argtypes = [vp]
@@ -228,6 +232,38 @@ def emit_source(blob: bytes):
     finally:
         L.iem_free(p)
     return src, int(key.value)
+
+
+def kkt_source(nb: int, ne: int):
+    """HIP source of the chain KKT solver's kernels for block size ``nb`` / border size ``ne`` and its cache key."""
+    L = lib()
+    p, key = C.c_void_p(), C.c_uint64()
+    check(L.iem_kkt_source(int(nb), int(ne), C.byref(p), C.byref(key)))
+    try:
+        src = C.string_at(p).decode()
+    finally:
+        L.iem_free(p)
+    return src, int(key.value)
+
+
+def precompile_source(src: str, key: int, arch: str = "gfx950", defer: list = None) -> str:
+    """Offline-compile a complete HIP source (first line ``// iem-flags: ...``) into the in-tree code-object cache."""
+    os.makedirs(KERNEL_DIR, exist_ok=True)
+    out = os.path.join(KERNEL_DIR, f"iem_{key:016x}.hsaco")
+    if os.path.exists(out):
+        return out
+    hip = os.path.join(KERNEL_DIR, f"iem_{key:016x}.hip")
+    with open(hip, "w") as f:
+        f.write(src)
+    flags = src.split("\n", 1)[0][len("// iem-flags:"):].split()
+    cmd = [os.path.join(ROCM, "bin", "hipcc"), "--genco", f"--offload-arch={arch}", *flags, "-o", out + ".tmp", hip]
+    if defer is not None:
+        if not any(c[1] == out for c in defer):
+            defer.append((cmd, out))
+        return out
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
 
 
 def emit_launch_plan(blob: bytes) -> str:

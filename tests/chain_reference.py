@@ -1,0 +1,92 @@
+"""numpy restatement of the chain KKT solver's block cyclic reduction (csrc/iem_kkt_device.h: kkt_eliminate / kkt_update /
+kkt_forward / kkt_backward, level by level) — TEST INFRASTRUCTURE: checks kkt_chain.ChainLayout's grouping and scatter plan
+on CPU, and is what the GPU kernels are compared with block for block."""
+import numpy as np
+
+
+def fill_blocks(layout, rows, cols, vals):
+    oD, oB, oE, oG, total = layout.offsets()
+    flat = np.zeros(total)
+    flat[layout.pad_positions()] = 1.0
+    src, dest = layout.scatter_plan(rows, cols)
+    assert np.unique(dest).size == dest.size, "every kept KKT entry has a dense position of its own"
+    flat[dest] = vals[src]
+    S, nb, ne = layout.S, layout.nb, layout.ne
+    return (flat[oD:oB].reshape(S, nb, nb).copy(), flat[oB:oE].reshape(S, nb, nb).copy(),
+            flat[oE:oG].reshape(S, nb, ne).copy(), flat[oG:total].reshape(ne, ne).copy())
+
+
+def factor(D, B, E):
+    """In place on copies: returns (Dinv, X, Y, Z, Gp, negative pivots)."""
+    S, nb, _ = D.shape
+    ne = E.shape[2]
+    D, B, E = D.copy(), B.copy(), E.copy()
+    X, Y, Z, Gp = np.zeros_like(B), np.zeros_like(B), np.zeros_like(E), np.zeros((S, ne, ne))
+    neg = 0
+
+    def eliminate(i, s, final):
+        nonlocal neg
+        # pivots of the un-pivoted elimination = those of LDL': count the negative ones
+        M = D[i].copy()
+        for k in range(nb):
+            neg += M[k, k] < 0
+            M[k + 1:, k + 1:] -= np.outer(M[k + 1:, k], M[k, k + 1:]) / M[k, k]
+        Di = np.linalg.inv(D[i])
+        D[i] = Di
+        if not final:
+            X[i] = Di @ B[i]
+            if i + s < S:
+                Y[i] = Di @ B[i + s].T
+        if ne:
+            Z[i] = Di @ E[i]
+            Gp[i] = E[i].T @ Z[i]
+
+    s = 1
+    while s < S:
+        for i in range(s, S, 2 * s):
+            eliminate(i, s, False)
+        newB = {}
+        for j in range(0, S, 2 * s):
+            p, q = j - s, j + s
+            if j > 0:
+                D[j] -= B[j] @ Y[p]
+                E[j] -= B[j] @ Z[p]
+                newB[j] = -B[j] @ X[p]
+            if q < S:
+                D[j] -= B[q].T @ X[q]
+                E[j] -= B[q].T @ Z[q]
+        for j, v in newB.items():
+            B[j] = v
+        s *= 2
+    eliminate(0, s, True)
+    return D, X, Y, Z, Gp, int(neg)
+
+
+def solve(Dinv, X, Y, Z, G, Gp, r, rB):
+    S, nb, _ = Dinv.shape
+    ne = Z.shape[2]
+    r = r.copy()
+    rBp = np.zeros((S, ne))
+    levels = []
+    s = 1
+    while s < S:
+        levels.append(s)
+        for j in range(0, S, 2 * s):
+            p, q = j - s, j + s
+            if j > 0:
+                r[j] -= Y[p].T @ r[p]
+            if q < S:
+                r[j] -= X[q].T @ r[q]
+        for i in range(s, S, 2 * s):
+            rBp[i] = Z[i].T @ r[i]
+        s *= 2
+    rBp[0] = Z[0].T @ r[0]
+    xB = np.linalg.solve(G - Gp.sum(0), rB - rBp.sum(0)) if ne else np.zeros(0)
+    r[0] = Dinv[0] @ r[0] - Z[0] @ xB
+    for s in reversed(levels):
+        for i in range(s, S, 2 * s):
+            v = Dinv[i] @ r[i] - X[i] @ r[i - s] - Z[i] @ xB
+            if i + s < S:
+                v -= Y[i] @ r[i + s]
+            r[i] = v
+    return r, xB

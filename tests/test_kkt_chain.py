@@ -1,0 +1,125 @@
+"""Chain KKT solver.  CPU: the grouping of the unknowns into chain blocks + border derived from the slab
+table and the Jacobian structure (kkt_chain.ChainLayout), its scatter plan, and the block cyclic reduction itself (numpy
+restatement, tests/chain_reference.py) against scipy on the oracle's KKT matrix.  GPU: the hand-written kernels
+(csrc/iem_kkt_device.h through iem_kkt_chain_factor / _solve) against the same."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from scipy.sparse.linalg import spsolve
+
+import cases
+import chain_reference as ref
+from pyoracle import OracleModel
+from test_kkt import host_kkt
+
+MODELS = ["quadrotor_100", "quadrotor_5", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "test_problem_1", "kinetic_20", "irregular"]
+
+
+def _system(name, seed=5):
+    core = cases.build_core(name)
+    om = OracleModel(core.to_blob())
+    x, y = cases.eval_point_for(name, om, seed)
+    rng = np.random.default_rng(3)
+    sigma = 0.5 + rng.random(om.nvar)
+    K = host_kkt(om, x, y, sigma, 1e-2, 1e-6).tocsr()
+    K.sum_duplicates(); K.sort_indices()
+    return core, om, K, rng.standard_normal(om.nvar + om.ncon)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_layout_and_block_cyclic_reduction_on_cpu(name, built):
+    from infiniteexamodels.jl_amd.kkt_chain import ChainLayout
+    core, om, K, rhs = _system(name)
+    jr, jc = om.jac_structure()
+    L = ChainLayout(core.slabs, om.nvar, om.ncon, jr, jc)
+    n = om.nvar + om.ncon
+    assert L.counts.sum() + L.n_border == n and L.counts.max() <= L.nb and L.nb % 4 == 0 and L.ne % 4 == 0
+    # every unknown has one slot; variables precede rows inside a block
+    slot = np.where(L.blk >= 0, L.blk * L.nb + L.loc, -1 - L.loc)
+    assert np.unique(slot).size == n
+    rows = np.repeat(np.arange(n), np.diff(K.indptr))
+    D, B, E, G = ref.fill_blocks(L, rows, K.indices, K.data)
+    Dinv, X, Y, Z, Gp, neg = ref.factor(D, B, E)
+    on, pos, border = L.positions()
+
+    def solve(b):
+        r = np.zeros(L.S * L.nb); r[pos] = b[on]
+        rB = np.zeros(L.ne); rB[:L.n_border] = b[border]
+        xs, xB = ref.solve(Dinv, X, Y, Z, G, Gp, r.reshape(L.S, L.nb), rB)
+        out = np.empty(n); out[on] = xs.reshape(-1)[pos]; out[border] = xB[:L.n_border]
+        return out
+    sol = solve(rhs)
+    assert np.abs(K @ sol - rhs).max() <= 1e-3 * max(1.0, np.abs(rhs).max())     # pivot blocks carry the -delta_c rows: ~1e-4 before ...
+    sol = sol + solve(rhs - K @ sol)                                               # ... one step of iterative refinement (ChainKKT.solve's default)
+    want = spsolve(K.tocsc(), rhs)
+    assert np.abs(K @ sol - rhs).max() <= 1e-8 * max(1.0, np.abs(rhs).max())
+    np.testing.assert_allclose(sol, want, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(want).max()))
+    # inertia: the negative pivots (blocks + border) are the negative eigenvalues of K — ncon of them when the
+    # regularised Hessian block is positive definite, more when it is not (random multipliers: the quadrotor's is not),
+    # which is exactly what an interior-point method asks the factorisation for
+    Gs = G - Gp.sum(0)
+    assert neg + int((np.linalg.eigvalsh(Gs) < 0).sum()) == int((np.linalg.eigvalsh(K.toarray()) < 0).sum()) >= om.ncon
+
+
+def test_layout_picks_the_stencil_axis_and_refuses_oversized_blocks(built):
+    from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
+    from infiniteexamodels.jl_amd.kkt_chain import ChainLayout
+    core = cases.build_core("pandemic_20x3")                 # groups: t (stencil) and xi — the chain must run along t
+    om = OracleModel(core.to_blob())
+    L = ChainLayout(core.slabs, om.nvar, om.ncon, *om.jac_structure())
+    assert L.group == 1 and L.reach == 1 and L.S == 30 and L.n_border == 0      # 20 + 10 extra supports
+    q = cases.build_core("quadrotor_oc3_40")                 # OrthogonalCollocation(3): an element's rows reach two supports back
+    oq = OracleModel(q.to_blob())
+    Lq = ChainLayout(q.slabs, oq.nvar, oq.ncon, *oq.jac_structure())
+    assert Lq.reach == 2 and Lq.supports_per_block == 2
+    f = cases.build_core("farmer_5")                         # no stencil: independent scenario blocks + first-stage border
+    of = OracleModel(f.to_blob())
+    Lf = ChainLayout(f.slabs, of.nvar, of.ncon, *of.jac_structure())
+    assert Lf.reach == 0 and Lf.S == 5 and Lf.n_border == 4   # x[1:3] and the row sum(x) <= 500
+    big = transcribe.exa_core(workloads.pandemic(10, 40))     # 40 scenarios x 17 unknowns per time support: too wide for dense blocks
+    ob = OracleModel(big.to_blob())
+    with pytest.raises(iemlib.IemError, match="exceed the dense-block solver's limits"):
+        ChainLayout(big.slabs, ob.nvar, ob.ncon, *ob.jac_structure())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS + ["quadrotor_1000", "opf_600", "farmer_1000"])
+def test_chain_kkt_on_gpu(name, built):
+    import torch
+    from infiniteexamodels.jl_amd.kkt import KKTSystem
+    from infiniteexamodels.jl_amd.kkt_chain import ChainKKT
+    from infiniteexamodels.jl_amd.model import ExaModel
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    gm = ExaModel(core, device=0, blob=blob)
+    kkt = KKTSystem(gm)
+    ck = ChainKKT(kkt)
+    rng = np.random.default_rng(3)
+    n = om.nvar + om.ncon
+    for seed in (5, 9):
+        x, y = cases.eval_point_for(name, om, seed)
+        sigma = 0.5 + rng.random(om.nvar)
+        xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+        kkt.assemble(gm.hess_coord(xd, yd, obj_weight=1.0), gm.jac_coord(xd), torch.tensor(sigma, device="cuda"), 1e-2, 1e-6)
+        Kh = host_kkt(om, x, y, sigma, 1e-2, 1e-6)
+        ck.load().factor()
+        pos, neg, doubtful = ck.inertia()
+        # the factors themselves, block for block, and the pivot signs, against the numpy restatement
+        L = ck.layout
+        Kc = Kh.tocsr(); Kc.sum_duplicates(); Kc.sort_indices()
+        D, B, E, G = ref.fill_blocks(L, np.repeat(np.arange(n), np.diff(Kc.indptr)), Kc.indices, Kc.data)
+        Dinv, X, Y, Z, Gp, neg_ref = ref.factor(D, B, E)
+        neg_ref += int((np.linalg.eigvalsh(G - Gp.sum(0)) < 0).sum())
+        assert (pos, neg, doubtful) == (n - neg_ref, neg_ref, 0) and neg >= om.ncon
+        got = ck.D.view(L.S, L.nb, L.nb).cpu().numpy()
+        assert np.abs(got - Dinv).max() <= 1e-6 * max(1.0, np.abs(Dinv).max())      # (Gauss-Jordan here, pivoted LU there; blocks with -delta_c pivots reach 1e6)
+        rhs = rng.standard_normal(n)
+        sol = ck.solve(torch.tensor(rhs, device="cuda"), refine=1).cpu().numpy()
+        want = spsolve(Kh.tocsc(), rhs)
+        resid = np.abs(Kh @ sol - rhs)
+        # 1e-9 of the right-hand side, or — where the solution itself is 1e5..1e6 (farmer: multipliers over delta_c) — a
+        # componentwise backward error at rounding level
+        assert resid.max() <= 1e-9 * max(1.0, np.abs(rhs).max()) or (resid / (abs(Kh) @ np.abs(sol) + np.abs(rhs))).max() <= 1e-12, name
+        np.testing.assert_allclose(sol, want, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(want).max()))
+    kkt.close(); gm.close()
