@@ -123,3 +123,29 @@ def test_chain_kkt_on_gpu(name, built):
         assert resid.max() <= 1e-9 * max(1.0, np.abs(rhs).max()) or (resid / (abs(Kh) @ np.abs(sol) + np.abs(rhs))).max() <= 1e-12, name
         np.testing.assert_allclose(sol, want, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(want).max()))
     kkt.close(); gm.close()
+
+
+@pytest.mark.gpu
+def test_device_resident_newton_iterations_reach_a_kkt_point(built):
+    """f3 + f4 together: Lagrange-Newton iterations whose every step — the five evaluation calls, the KKT assembly, the chain
+    factorisation and solve — runs on the device (tools/newton_kkt_demo.py), on the quadrotor tracking problem.  The KKT
+    residual must fall below 1e-8 in a handful of iterations, the factorisation must report the right inertia at the
+    solution, and the point must be the one scipy finds through the same device model."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from newton_kkt_demo import newton
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    from infiniteexamodels.jl_amd.model import ExaModel
+    gm = ExaModel(transcribe.exa_core(workloads.quadrotor(400)), device=0)
+    x, y, hist = newton(gm, iters=25)
+    assert hist[-1]["kkt_residual"] <= 1e-8, hist
+    assert len(hist) <= 20
+    pos, neg, doubtful = hist[-2]["inertia"]
+    assert (pos, neg, doubtful) == (gm.meta.nvar, gm.meta.ncon, 0)      # a minimiser: the reduced Hessian is positive definite
+    # feasibility and stationarity re-checked through the oracle on the host
+    om = OracleModel(gm.core.to_blob())
+    xh, yh = x.cpu().numpy(), y.cpu().numpy()
+    assert np.abs(om.cons(xh) - om.lcon).max() <= 1e-8
+    assert np.abs(om.grad(xh) + om.jtprod(xh, yh)).max() <= 1e-7
+    gm.close()
