@@ -92,6 +92,27 @@ function NLPModels.hess_coord!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVect
                 m.handle, dptr(x), dptr(y), obj_weight, dptr(v)))
     return v
 end
+# jac_coord! + hess_coord! in ONE launch (include/iem.h: iem_jac_hess_coord) for a solver that evaluates both at an accepted
+# point (MadNLP); identical bytes to the two calls above
+function jac_hess_coord!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Float64}, jac::ROCVector{Float64},
+                         hess::ROCVector{Float64}; obj_weight = 1.0)
+    check(ccall((:iem_jac_hess_coord, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Float64}),
+                m.handle, dptr(x), dptr(y), obj_weight, dptr(jac), dptr(hess)))
+    return jac, hess
+end
+# obj in two halves: obj_begin! first, obj_end after the last launch of the evaluation point — the scalar's host round trip
+# overlaps grad!, cons!, jac_coord!, hess_coord! (ext/InfiniteExaModelsIpopt.jl:48-49 evaluates all five at one point)
+obj_begin!(m::MI355XModel, x::ROCVector{Float64}) =
+    (check(ccall((:iem_obj_begin, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.handle, dptr(x))); m)
+function obj_end(m::MI355XModel)
+    out = Ref{Float64}()
+    check(ccall((:iem_obj_end, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.handle, out))
+    return out[]
+end
+# sharded handles: the halo exchange off the critical path (it rides on the next evaluation launch that takes x and cannot
+# touch a halo entry; include/iem.h: iem_halo_exchange_async)
+halo_exchange_async!(m::MI355XModel, x::ROCVector{Float64}) =
+    (check(ccall((:iem_halo_exchange_async, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}), m.handle, dptr(x))); x)
 # optional set-up step, once the solver has allocated its COO value buffers: which of the handle's two code objects
 # writes THESE buffers faster (include/iem.h: iem_tune); a no-op for handles with one code object
 function tune!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Float64}, jac::ROCVector{Float64},
