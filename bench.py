@@ -350,7 +350,7 @@ def main():
             iemlib.build_library()
         barrier()
     # generator options of THIS run's handles (iem_create_opts): nothing process-global
-    hopts = {"store_mode": args.store_mode, "nt_stores": args.nt, "fp_contract": args.fma}
+    hopts = {"store_mode": args.store_mode, "nt_stores": args.nt, "fp_contract": args.fma, "comm_timeout_ms": 1000}
     for kv in args.opt:
         k, v = kv.split("=")
         hopts[k] = int(v)
@@ -425,8 +425,23 @@ def main():
             with torch.cuda.graph(graph):
                 eager()
             step = graph.replay
+        barrier()      # ranks build their shards at different speeds: start the first exchanges together
         for _ in range(warmup):
             step()
+        if halo_state["in_loop"]:
+            # the warm-up steps carried real exchanges over this machine's links: if ANY rank saw a mailbox wait time out
+            # (bounded: comm_timeout_ms = 1 s on these handles), every rank times the communication-free step instead and
+            # the line says so — a broken link must cost seconds, not steps x time-out
+            st = gm.comm_status()
+            flag = torch.tensor([float(st)], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() != 0:
+                halo_state.update(in_loop=False, why=f"a mailbox wait timed out during the warm-up (status {int(flag.item())})")
+                step = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=False)
+                try:
+                    gm.synchronize()      # reports and clears the recorded time-out
+                except Exception:         # noqa: BLE001
+                    pass
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
