@@ -67,6 +67,18 @@ int main(int argc, char **argv) {
   long long sr = 0, sc = 0;
   for (int64_t i = 0; i < meta.nnzj; ++i) { sr += rows[i]; sc += cols[i]; }
   printf("jac_structure %lld %lld %lld\n", (long long)meta.nnzj, sr, sc);
+  /* the solver-facing forms of the same evaluations: objective launched first and collected last (iem_obj_begin / _end),
+   * jac_coord! + hess_coord! in one launch (iem_jac_hess_coord) — identical results, into fresh buffers */
+  double *jv2, *hv2, f2 = 0.0;
+  HIP(hipMalloc((void **)&jv2, (size_t)meta.nnzj * 8 + 8)); HIP(hipMalloc((void **)&hv2, (size_t)meta.nnzh * 8 + 8));
+  IEM(iem_obj_begin(m, x));
+  IEM(iem_grad(m, x, g));
+  IEM(iem_cons(m, x, c));
+  IEM(iem_jac_hess_coord(m, x, y, 1.0, jv2, hv2));
+  IEM(iem_obj_end(m, &f2));
+  IEM(iem_synchronize(m));
+  printf("obj2 1 %.17g %.17g\n", f2, f2 * f2);
+  if (report("jac2", jv2, meta.nnzj) || report("hess2", hv2, meta.nnzh)) return 1;
   IEM(iem_destroy(m));
   return 0;
 }

@@ -49,3 +49,5 @@ def test_c_demo_matches_oracle(name, built, tmp_path):
         assert abs(q - (v * v).sum()) <= 1e-10 * max(1.0, float((v * v).sum())), k
     jr, jc = om.jac_structure(base=1)
     assert [int(v) for v in got["jac_structure"]] == [om.nnzj, int(jr.sum()), int(jc.sum())]
+    # the deferred objective and the one-launch jac + hess pair give the very same numbers as the five plain calls
+    assert got["obj2"] == got["obj"] and got["jac2"] == got["jac"] and got["hess2"] == got["hess"]
