@@ -191,6 +191,11 @@ def test_quadrotor_1e5_properties(torch_cuda):
     # linearity in (obj_weight, y): H(2w, 2y) == 2 H(w, y) exactly (power-of-two scaling)
     h2 = gm.hess_coord(xd, 2 * yd, obj_weight=2.0).cpu().numpy()
     assert np.array_equal(h2, 2 * h1)
+    # the one-launch pair at this size: the bytes of the two calls, into poisoned buffers
+    jp = torch.full((gm.meta.nnzj,), float("nan"), device="cuda", dtype=torch.float64)
+    hp = torch.full((gm.meta.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
+    gm.jac_hess_coord(xd, yd, jp, hp, obj_weight=1.0)
+    assert np.array_equal(jp.cpu().numpy(), j1) and np.array_equal(hp.cpu().numpy(), h1)
     # structure equals the oracle's, position by position
     r, c = gm.jac_structure()
     ro, co = om.jac_structure()
@@ -234,7 +239,17 @@ def test_quadrotor_1e6_headline_size(torch_cuda):
     r, c = gm.jac_structure_device()
     ro, co = om.jac_structure()
     assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(c.cpu().numpy(), co)
-    gm.close()
+    # the bench's default step at this size (iem_jac_hess_coord) writes the same bytes; so does the LARGE-GRID kernel shape
+    # (what a model of >= 2e6 supports gets: 48-slot staging batch + XCD-aware tile walk), forced here by its thresholds
+    jp = torch.full((gm.meta.nnzj,), float("nan"), device="cuda", dtype=torch.float64)
+    hp = torch.full((gm.meta.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
+    gm.jac_hess_coord(xd, yd, jp, hp, obj_weight=1.0)
+    assert np.array_equal(jp.cpu().numpy(), j) and np.array_equal(hp.cpu().numpy(), h)
+    del jp, hp
+    big = ExaModel(core, device=0, options=dict(big_batch_jac=1000, big_batch_hess=1000))
+    assert {k["kind"]: k["lds_bytes"] for k in big.kernels() if k["kind"] in ("jac", "hess")} == {"jac": 98304, "hess": 98304}
+    assert np.array_equal(big.jac_coord(xd).cpu().numpy(), j) and np.array_equal(big.hess_coord(xd, yd, obj_weight=1.0).cpu().numpy(), h)
+    big.close(); gm.close()
 
 
 def test_eval_loop_is_graph_capturable(torch_cuda, grid_mode):
