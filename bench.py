@@ -294,6 +294,9 @@ def main():
                     "iem_jac_hess_coord (one launch, the default); the other form is always reported beside it")
     ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)   # (the default; kept so older command lines still parse)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-input measurement (K rotating x / y sets)")
+    ap.add_argument("--rotate-inputs", type=int, default=0, metavar="K",
+                    help="cold-input measurement (roofline.frac_cold_inputs): K distinct (x, y) sets cycled per call; 0 = as many as "
+                         "it takes to exceed the 256-MiB Infinity Cache, at least 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -526,7 +529,7 @@ def main():
     cold = None
     if world == 1 and not args.no_cold and not args.graph:
         K = max(4, int(np.ceil(300e6 / (8.0 * (gm.meta.nvar + gm.meta.ncon)))))
-        K = min(K, 64)
+        K = max(2, args.rotate_inputs) if args.rotate_inputs else min(K, 64)
         xs = [xd] + [xd + 1e-3 * (i + 1) for i in range(K - 1)]
         ys = [yd] + [yd * (1.0 + 1e-3 * (i + 1)) for i in range(K - 1)]
         nc = 20 * K if gm.meta.nvar < 5_000_000 else 4 * K

@@ -413,10 +413,6 @@ int comm_check(iem_model *m) {
                           "a peer did not take part in the exchange; the halo entries / reduced values it should have delivered were set to NaN");
 }
 
-// Ordering of an evaluation call against a DEFERRED halo exchange (iem_halo_exchange_async).  halo_plan decides for the
-// call about to be launched: 2 = its first kernel carries the exchange (same x, a carrier kind, and no kernel of the kind
-// can touch a halo entry of x); 1 = the stand-alone exchange kernel has been launched in front of it (it can touch one);
-// 0 = nothing (no exchange pending, or this call neither touches nor can carry: the exchange stays deferred).
 // the all-reduce runs on G workgroups, each on its own chunk of the NR doubles (one per 1 024, at most 64)
 int64_t reduce_chunks(int64_t NR) { return std::min<int64_t>(64, std::max<int64_t>(1, (NR + 1023) / 1024)); }
 struct HaloArgsH { double *x; unsigned long long *mine, *left, *right; const long long *src, *dst; long long NH, W, G; unsigned long long *hstatus; long long ticks; };
@@ -438,6 +434,10 @@ int halo_flush(iem_model *m) {
   m->halo_deferred = false;
   return halo_launch(m, m->halo_vec, m->stream);
 }
+// Ordering of an evaluation call against a DEFERRED halo exchange (iem_halo_exchange_async), decided for the call about to
+// be launched: a kind that can touch a halo entry of the exchanged vector (through x, or through a variable-space v) gets
+// the stand-alone exchange kernel in front of it; otherwise, if it takes the same x and is a carrier kind, its first kernel
+// CARRIES the exchange (*carry: one extra leading workgroup); otherwise nothing happens and the exchange stays deferred.
 int halo_plan(iem_model *m, int kind, const void *x, const void *v, bool *carry) {
   *carry = false;
   if (!m->halo_deferred) return IEM_OK;
