@@ -549,3 +549,23 @@ def test_large_grid_shapes_and_pair_fallback_on_gpu(opts, torch_cuda):
     assert torch.equal(j2, j0) and torch.equal(h2, h0)
     _close(j2.cpu().numpy(), om.jac_coord(x), "jac"); _close(h2.cpu().numpy(), om.hess_coord(x, y, 0.7), "hess")
     g2.close(); gm.close()
+
+
+@pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "farmer_1000", "opf_600"])
+def test_raw_loop_forms_agree(name, torch_cuda):
+    """ExaModel.raw_loop — the five evaluations of one solver point through prebound C calls: plain order, objective
+    deferred (iem_obj_begin first / iem_obj_end last), and deferred + one-launch pair — same value, same bytes."""
+    torch = torch_cuda
+    core, om, gm = _models(name, torch)
+    x, y = cases.eval_point_for(name, om)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    ref = (gm.obj(xd), gm.grad(xd).clone(), gm.cons(xd).clone(), gm.jac_coord(xd).clone(), gm.hess_coord(xd, yd, obj_weight=0.7).clone())
+    for kw in (dict(fused=False, defer_obj=False), dict(fused=False, defer_obj=True), dict(fused=True, defer_obj=True)):
+        nan = lambda n: torch.full((n,), float("nan"), device="cuda", dtype=torch.float64)
+        g, c, j, h = nan(om.nvar), nan(om.ncon), nan(om.nnzj), nan(om.nnzh)
+        step = gm.raw_loop(xd, yd, g, c, j, h, obj_weight=0.7, **kw)
+        for _ in range(3):
+            f = step()
+        torch.cuda.synchronize()
+        assert f == ref[0] and torch.equal(g, ref[1]) and torch.equal(c, ref[2]) and torch.equal(j, ref[3]) and torch.equal(h, ref[4]), kw
+    gm.close()
