@@ -1,0 +1,23 @@
+#!/bin/bash
+# End-of-round evidence from ONE tree (run through gpurun; IEM_COMMIT=$(git rev-parse --short HEAD) in the environment):
+# the rocprof recipe of the default bench (kernel stats + PMC passes -> gpurun_out/prof), kernel stats of a 1/8 shard,
+# ten consecutive default bench processes, the N = 2 rehearsal.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03_final; mkdir -p $O
+cd $R
+bash tools/profile_gpu.sh > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
+echo "profile ok"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard_stats -- python3 $R/bench.py --emulate-shard 3/8 --steps 200 --warmup 20 --no-cpu-baseline --no-cold > $O/shard_bench.json 2> $O/shard_bench.err ) || exit 1
+echo "shard stats ok"
+for i in 1 2 3 4 5 6 7 8 9 10; do
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-cold > $O/run_$i.json 2> $O/run_$i.err || exit 1
+  python3 - $O/run_$i.json $i <<'PY' >> $O/bench_runs.txt
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j["roofline"]
+print(f"run {sys.argv[2]:>2}: value {j['value']:.1f} pairs/s  ms/step {j['ms_per_step']:.4f}  pair kernel {r['pair_kernel_ms']:.4f} ms ({r['pair_kernel_frac']:.3f})  jac {r['jac_ms']:.4f}  hess {r['hess_ms']:.4f}  pair_frac {r['pair_frac']:.3f}  two calls {j['separate_calls']['value']:.1f} pairs/s")
+PY
+done
+cat $O/bench_runs.txt
+timeout -k 10 600 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+echo "default bench ok"
