@@ -321,11 +321,12 @@ void iem_free(void *p);
  *                  scenarios) are parked per item and reduced in row order by a follow-up kernel; 0: f64 atomics
  *   "lazy_loads"   2 (default): product / scatter kernels with >= "lazy_min_loads" (48) loads emit a load where its value
  *                  is first used instead of at the head of the kernel (register pressure); 1: only rows of v / y; 0: never
- *   "big_batch_jac", "big_batch_hess", "big_batch_slots", "big_xcd"   the LARGE-GRID kernel shape: jac_coord! / hess_coord!
- *                  kernels of a grid with at least this many workgroups (defaults 4000 / 4000 — about 2e6 quadrotor supports,
- *                  outputs far beyond the Infinity Cache; 0: never) stage "big_batch_slots" (48) values per barrier pair
- *                  instead of "lds_slots" — one 96-KB workgroup per CU instead of three — and ("big_xcd" = 1) walk their
- *                  tiles XCD-aware.  A function of kind and grid size only, never of a timer
+ *   "big_batch_jac", "big_batch_hess", "big_tile", "big_batch_slots", "big_xcd"   the LARGE-GRID shape of jac_coord! /
+ *                  hess_coord!: when a kind has a support grid of at least this many workgroups (defaults 4000 / 4000 — about
+ *                  2e6 quadrotor supports, outputs far beyond the Infinity Cache; 0: never), all kernels of that kind run
+ *                  "big_tile"-lane workgroups (1024; 0 = the model's own; the other kinds keep theirs), stage
+ *                  "big_batch_slots" (48) values per barrier pair — one 96-KB workgroup per CU — and ("big_xcd" = 1) walk their
+ *                  tiles XCD-aware.  A function of kind and grid sizes only, never of a timer
  *   "pair_kernel"  1 (default): the handle also carries the fused jac + hess launch behind iem_jac_hess_coord
  *   "comm_timeout_ms"  bound of every mailbox wait of this handle's exchange kernels (default 5000)
  *   "autotune"     0 (default) / 1 (opt-in): handles whose jac/hess grid has >= "autotune_min_blocks" (400) workgroups

@@ -76,7 +76,26 @@ std::string full_source(const iem::Program &p, const iem::Options &o) {
   s += std::string("#define IEM_WIDE_STORES ") + (o.wide_stores ? "1" : "0") + "\n";
   if (o.flush32 != 2) s += "#define IEM_FLUSH32 " + std::to_string(o.flush32) + "\n";
   if (o.ablate) s += "#define IEM_ABLATE " + std::to_string(o.ablate & 1) + "  // timing experiment, results are wrong\n";
-  s += kDeviceHeader;
+  // A program whose kernels all use one workgroup size sees the device header as it is.  Otherwise (jac_coord! /
+  // hess_coord! of a large grid run wider tiles than the rest) the header's tile-dependent region is repeated per size,
+  // each copy in a namespace iem_t<size> — the generator wraps the kernels of that size in the same namespace.
+  std::vector<int> tiles;
+  for (const iem::KernelDesc &kd : p.kernels)
+    if (std::find(tiles.begin(), tiles.end(), kd.block) == tiles.end()) tiles.push_back(kd.block);
+  std::sort(tiles.begin(), tiles.end());
+  if (tiles.size() <= 1) {
+    s += kDeviceHeader;
+  } else {
+    const std::string hdr(kDeviceHeader);
+    const size_t a = hdr.find("// IEM-TILE-REGION-BEGIN"), b = hdr.find("// IEM-TILE-REGION-END");
+    if (a == std::string::npos || b == std::string::npos || b < a) throw std::runtime_error("internal: device header without tile-region markers");
+    s += hdr.substr(0, a);
+    for (int t : tiles)
+      s += "#undef IEM_TILE\n#define IEM_TILE " + std::to_string(t) + "\nnamespace iem_t" + std::to_string(t) + " {\n" + hdr.substr(a, b - a) + "}  // namespace iem_t" +
+           std::to_string(t) + "\n";
+    s += "#undef IEM_TILE\n#define IEM_TILE " + std::to_string(p.block) + "\n";
+    s += hdr.substr(b);
+  }
   s += "\n";
   s += p.source;
   return s;
@@ -800,6 +819,11 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "big_batch_jac") == 0) { o.big_batch_jac = value; return IEM_OK; }
   if (std::strcmp(name, "big_batch_hess") == 0) { o.big_batch_hess = value; return IEM_OK; }
   if (std::strcmp(name, "big_xcd") == 0) { o.big_xcd = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "big_tile") == 0) {
+    if (value != 0 && (value < 64 || value > 1024 || value % 64)) return fail(IEM_E_ARG, "big_tile must be 0 (keep the model's tile) or a multiple of 64 in 64..1024");
+    o.big_tile = (int)value;
+    return IEM_OK;
+  }
   if (std::strcmp(name, "pair_kernel") == 0) { o.pair_kernel = (int)value; return IEM_OK; }
   if (std::strcmp(name, "store_wait") == 0) { o.store_wait = (int)value; return IEM_OK; }
   if (std::strcmp(name, "comm_timeout_ms") == 0) {

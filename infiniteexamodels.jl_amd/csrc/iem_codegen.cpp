@@ -1894,20 +1894,26 @@ static void launch_grid(const Group &g, int64_t qs, KernelDesc &kd) {
   kd.n_blocks = kd.grid[0] * kd.grid[1] * kd.grid[2];
 }
 
-// The options one kernel is generated with: the handle's, except that jac_coord! / hess_coord! of a LARGE grid stage
-// Options::big_batch_slots values per barrier pair — one 96-KB workgroup per CU instead of three 48-KB ones.  The choice
-// is a function of the kind and the grid size alone (Options::big_batch_jac / big_batch_hess workgroups), so that a
-// handle's code never depends on a timer or on the process it runs in.
-static Options kind_options(const Options &opt, const Group &g, int kind) {
+// The options the kernels of one KIND are generated with: the handle's, except that jac_coord! / hess_coord! get the
+// LARGE-GRID shape (Options::big_*) when any support grid of the model gives that kind at least big_batch_jac / _hess
+// workgroups at the model's own tile.  A function of the kind and the grid sizes alone — never of a timer or of the process
+// — and one decision per kind: the kernels (bodies) of a kind share launches, hence a workgroup size.
+static Options kind_options(const Options &opt, const std::vector<Group> &groups, int kind) {
   Options ko = opt;
   if ((kind != KK_JAC && kind != KK_HESS) || opt.store_mode != 2 || opt.no_fuse || opt.big_batch_slots <= opt.lds_slots) return ko;
   const int64_t thr = kind == KK_JAC ? opt.big_batch_jac : opt.big_batch_hess;
   if (thr <= 0) return ko;
-  KernelDesc probe;
-  launch_grid(g, (opt.overlap && opt.block >= 256) ? opt.block - 16 : opt.block, probe);
-  if (probe.n_blocks >= thr) {
+  int64_t biggest = 0;
+  for (const Group &g : groups) {
+    if (g.grid_id <= 0) continue;
+    KernelDesc probe;
+    launch_grid(g, (opt.overlap && opt.block >= 256) ? opt.block - 16 : opt.block, probe);
+    biggest = std::max(biggest, probe.n_blocks);
+  }
+  if (biggest >= thr) {
     ko.lds_slots = opt.big_batch_slots;
     if (opt.big_xcd) ko.xcd_remap = 1;
+    if (opt.big_tile > 0) ko.block = opt.big_tile;
   }
   return ko;
 }
@@ -1963,14 +1969,14 @@ Program generate(const Model &m, const Options &opt_in) {
     for (int kind = 0; kind < KK_COUNT; ++kind) {
       if (split && is_scatter(kind) != (pass == 1)) continue;   // pass 1: the scatter kinds on the fused groups
       std::string name = std::string("iem_") + kname[kind] + "_g" + std::to_string(gi) + name_tag;
-      const Options ko = kind_options(opt, g, kind);
+      const Options ko = kind_options(opt, pass ? groups_fused : groups, kind);
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, ko, name);
       if (!kb->build(nullptr)) continue;
       if (kind == KK_HESS && opt.hess_merge) kb->merge_hess(P.nnzh_merged, P.hess_classes);
       KernelDesc kd;
       kd.name = name;
       kd.kind = kind;
-      kd.block = opt.block;
+      kd.block = ko.block;
       kd.lds_slots = ko.lds_slots;
       launch_grid(g, kb->qstep(), kd);
       if (kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD) {
@@ -2287,19 +2293,32 @@ Program generate(const Model &m, const Options &opt_in) {
   // shared LDS, largest grid first so that its workgroups start first).
   // The objective always takes this form, with a wrapper of its own: at most `obj_wgs` workgroups
   // WALK the tiles of every body, so there is one partial (and one ticket) per workgroup.
+  // Kernels of more than one workgroup size in one program (the large-grid shape of jac_coord! / hess_coord!): every kernel
+  // then sits in the namespace iem_t<size> that holds the tile-dependent device primitives compiled for its size, with
+  // IEM_TILE redefined in front of it (csrc/iem_api.cpp: full_source).  A program of one size is emitted as it always was.
+  bool mixed = false;
+  for (const KernelDesc &d : descs) mixed = mixed || d.block != opt.block;
+  auto ns_begin = [&](int tile) {
+    if (mixed) src << "#undef IEM_TILE\n#define IEM_TILE " << tile << "\nnamespace iem_t" << tile << " {\n";
+  };
+  auto ns_end = [&](int tile) {
+    if (mixed) src << "}  // namespace iem_t" << tile << "\n#undef IEM_TILE\n#define IEM_TILE " << opt.block << "\n\n";
+  };
   for (int kind = 0; kind < KK_COUNT; ++kind) {
     std::vector<size_t> ks;
     for (size_t k = 0; k < descs.size(); ++k) if (descs[k].kind == kind) ks.push_back(k);
     if (ks.empty()) continue;
     const bool is_obj = kind == KK_OBJ;
+    const int ktile = descs[ks[0]].block;   // one workgroup size per kind (kind_options)
     if (!is_obj && (ks.size() == 1 || !opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2))) {   // fuse_groups = 2: experiments (one launch of per-template bodies)
-      for (size_t k : ks) { src << builders[k]->emit(descs[k]); P.kernels.push_back(descs[k]); }
+      for (size_t k : ks) { ns_begin(ktile); src << builders[k]->emit(descs[k]); ns_end(ktile); P.kernels.push_back(descs[k]); }
       continue;
     }
+    ns_begin(ktile);
     std::stable_sort(ks.begin(), ks.end(), [&](size_t a, size_t b) { return descs[a].n_blocks > descs[b].n_blocks; });
     KernelDesc F;
     F.name = std::string("iem_") + kname[kind] + "_all" + name_tag;
-    F.kind = kind; F.block = opt.block;
+    F.kind = kind; F.block = ktile;
     F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
     std::vector<size_t> oip, odp, ofa, oia;   // table offsets of each body
     for (size_t k : ks) {
@@ -2406,6 +2425,7 @@ Program generate(const Model &m, const Options &opt_in) {
       src << "  }\n"
           << "  iem_block_partial(acc, A.out, bx_, lds4, gx_, A.aux);\n";
       src << "}\n\n";
+      ns_end(ktile);
       P.kernels.push_back(F);
       continue;
     }
@@ -2448,6 +2468,7 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     if (si) src << KernelBuilder::shared_epilogue(*si, "A.ip + " + std::to_string(sh_tbl), "wg_", "lds_blk", sh_lds);
     src << "}\n\n";
+    ns_end(ktile);
     P.kernels.push_back(F);
   }
   // jac_coord! + hess_coord! in ONE launch (KK_PAIR; iem_jac_hess_coord).  The two calls are independent given x (and y):
@@ -2460,7 +2481,11 @@ Program generate(const Model &m, const Options &opt_in) {
     bool have[2] = {false, false};
     for (size_t k = 0; k < descs.size(); ++k)
       if (descs[k].kind == KK_JAC || descs[k].kind == KK_HESS) { ks.push_back(k); have[descs[k].kind == KK_HESS] = true; }
-    if (have[0] && have[1]) {
+    int ptile = 0;
+    bool one_tile = true;
+    for (size_t k : ks) { if (!ptile) ptile = descs[k].block; one_tile = one_tile && descs[k].block == ptile; }
+    if (have[0] && have[1] && one_tile) {   // (kinds of different workgroup sizes cannot share a launch: the two calls stay)
+      ns_begin(ptile);
       std::vector<std::unique_ptr<KernelBuilder>> pb;
       std::vector<KernelDesc> pd;
       std::vector<bool> pxcd;
@@ -2483,7 +2508,7 @@ Program generate(const Model &m, const Options &opt_in) {
       std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return pd[a].n_blocks > pd[b].n_blocks; });
       KernelDesc F;
       F.name = std::string("iem_pair_all") + name_tag;
-      F.kind = KK_PAIR; F.block = opt.block;
+      F.kind = KK_PAIR; F.block = ptile;
       F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
       std::vector<size_t> oip, odp, ofa, oia;
       for (size_t j : ord) {
@@ -2558,6 +2583,7 @@ Program generate(const Model &m, const Options &opt_in) {
         src << "}\n\n";
         P.kernels.push_back(F);
       }
+      ns_end(ptile);
     }
   }
   P.source = src.str();

@@ -79,16 +79,19 @@ struct Options {
   int autotune_min_blocks = 400;   // ... grids of at least this many workgroups (about 2e5 supports)
   int obj_unroll = 1;  // 2: the objective's tile walk takes two tiles per trip (single-body kernels)
   int det_shared = 1;  // 1: scatter entries shared by many items are reduced deterministically (iem_shared_*), 0: one f64 atomic per wave
-  // LARGE grids — outputs far beyond the 256-MiB Infinity Cache, everything goes to DRAM — get another kernel shape, chosen
-  // from the GRID SIZE per kind (never from a timer): jac_coord! / hess_coord! kernels of at least `big_batch_jac` /
-  // `big_batch_hess` workgroups (4000: about 2e6 quadrotor supports; 0: never) stage `big_batch_slots` values per barrier
-  // pair — one 96-KB workgroup per CU instead of three 48-KB ones, a third of the concurrently open store streams — and
-  // (`big_xcd`) walk their tiles XCD-aware: consecutive tiles on ONE XCD, so that neighbouring chunks of a store stream leave
-  // through one L2.  In-process A/Bs (profiles/r03_ab_large_grid_shape.txt): 2e6 supports jac -10 % / hess -3 %, 4e6 jac
-  // -5..-8 % / hess -5..-7 %; below ~1e6 neither knob wins reliably (the buffers' placement moves the same kernel by more).
+  // LARGE grids — outputs far beyond the 256-MiB Infinity Cache, everything goes to DRAM — get another kernel shape for
+  // jac_coord! / hess_coord!, chosen from the GRID SIZE per kind (never from a timer): when a kind has a grid of at least
+  // `big_batch_jac` / `big_batch_hess` workgroups (counted at the model's own tile; 4000 = about 2e6 quadrotor supports; 0:
+  // never), ALL kernels of that kind run `big_tile`-lane workgroups (1024: twice the contiguous chunk per store stream;
+  // every other kind keeps the model's tile — cons! is 27 % slower at 1024 lanes), stage `big_batch_slots` (quoted for
+  // 256 lanes: 12 values per lane at 1024, one 96-KB workgroup per CU) and (`big_xcd`) walk their tiles XCD-aware:
+  // consecutive tiles on ONE XCD, so that neighbouring chunks of a stream leave through one L2.  In-process A/Bs on two
+  // boxes (profiles/r03_ab_kernel_shapes.txt): 2e6 supports fused pair -3..-5 %, 4e6 -5..-8 % (0.69 -> 0.76..0.79 of
+  // peak), 8e6 -4..-8 %; below ~1e6 no shape wins reliably (the buffers' placement moves the same kernel by more).
   int big_batch_slots = 48;
   int64_t big_batch_jac = 4000, big_batch_hess = 4000;
   int big_xcd = 1;
+  int big_tile = 1024;     // 0: keep the model's tile (the 512-lane, 48-slot form of the first measurements)
   int pair_kernel = 1;     // 1: also emit the fused jac_coord! + hess_coord! launch (KK_PAIR, iem_jac_hess_coord)
   int store_wait = 0;      // experiment: s_waitcnt vmcnt(0) behind every flushed batch (paces a wave's outstanding stores)
   // runtime only (the generator ignores them)

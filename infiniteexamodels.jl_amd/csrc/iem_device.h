@@ -130,6 +130,10 @@ __device__ __forceinline__ void iem_store_rows(double *__restrict__ out, long lo
   iem_wave_lds_sync();
 }
 
+// IEM-TILE-REGION-BEGIN — everything from here to the matching END marker depends on IEM_TILE.  A program whose kernels
+// use more than one workgroup size (jac_coord! / hess_coord! of a LARGE grid run 1 024-lane tiles, everything else 512) gets
+// this region once per size, each copy in a namespace iem_t<size> of its own together with the kernels of that size
+// (csrc/iem_api.cpp: full_source).
 // Block-cooperative, 128-byte-ALIGNED form (store_mode 2).
 //
 // The COO offsets are ExaModels' running counters (o1 = 9, 209, ...), so a wave's own
@@ -477,6 +481,7 @@ __device__ __forceinline__ void iem_grad_wave_uniform(double *__restrict__ g, lo
 __device__ __forceinline__ void iem_grad_atomic(double *__restrict__ g, long long idx, double v, bool valid) {
   if (valid) atomicAdd(&g[idx], v);
 }
+// IEM-TILE-REGION-END
 
 // ---- jac_structure! / hess_structure! on the device -----------------------------------------
 // One launch per template: thread e handles COO element e of the template's block

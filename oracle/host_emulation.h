@@ -44,6 +44,8 @@ template <int NS>
 inline void iem_store_rows(double *out, long long pos0, bool valid, const double (&v)[NS], double *) {
   iem_store_rows_direct<NS>(out, pos0, valid, v);
 }
+// IEM-TILE-REGION-BEGIN (as in csrc/iem_device.h: tests/emu.py repeats this region per workgroup size, each copy in a
+// namespace iem_t<size>, for programs whose kernels use more than one)
 inline int iem_clamp256(long long v) { return v < 0 ? 0 : (v > IEM_TILE ? IEM_TILE : (int)v); }
 template <int NS>
 inline void iem_store_block(double *out, long long P0, int v0, int v1, const double (&v)[NS], double *) {
@@ -163,5 +165,6 @@ inline void iem_zero_fill(double *p, long long n, long long b, long long nb) {
   const long long lo = b * chunk, hi = lo + chunk < n ? lo + chunk : n;
   for (long long i = lo + threadIdx.x; i < hi; i += IEM_TILE) p[i] = 0.0;
 }
+// IEM-TILE-REGION-END
 inline void iem_grad_wave_uniform(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }
 inline void iem_grad_atomic(double *g, long long idx, double v, bool valid) { if (valid) g[idx] += v; }

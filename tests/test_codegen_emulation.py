@@ -81,10 +81,13 @@ def test_generated_source_is_size_independent(built):
 
 
 @pytest.mark.parametrize("name", ["quadrotor_1000", "pandemic_300x7", "opf_600", "quadrotor_oc3_700"])
-@pytest.mark.parametrize("big", [dict(big_batch_jac=1, big_batch_hess=0), dict(big_batch_jac=1, big_batch_hess=1), dict(big_batch_jac=1, big_batch_hess=1, big_xcd=0)])
+@pytest.mark.parametrize("big", [dict(big_batch_jac=1, big_batch_hess=0), dict(big_batch_jac=1, big_batch_hess=1), dict(big_batch_jac=1, big_batch_hess=1, big_xcd=0),
+                                 dict(big_batch_jac=1, big_batch_hess=1, big_tile=0), dict(big_batch_jac=1, big_batch_hess=1, big_tile=256)])
 def test_large_grid_staging_batch_writes_the_same_values(name, big, lane_fused):
-    """The large-grid shape (48-slot staging batch + XCD-aware tile walk; for jac_coord! only, for both, without the remap)
-    against the oracle, stand-alone kernels and the fused pair — it moves barriers and tiles, never values."""
+    """The large-grid shape of jac_coord! / hess_coord! (1 024-lane tiles in a program whose other kinds keep 512 — two copies
+    of the tile-dependent primitives in namespaces —, 48-slot staging batch, XCD-aware tile walk; for jac_coord! only, for both,
+    without the remap, at the model's own tile, at a smaller one) against the oracle, stand-alone kernels and the fused pair
+    — it moves barriers and tiles, never values."""
     from infiniteexamodels.jl_amd import lib as iemlib
     core = cases.build_core(name)
     blob = core.to_blob()
@@ -97,8 +100,15 @@ def test_large_grid_staging_batch_writes_the_same_values(name, big, lane_fused):
         j, h = em.jac_coord(x, om.nnzj), em.hess_coord(x, y, 0.7, om.nnzh)
         assert np.array_equal(j, ref.jac_coord(x, om.nnzj)) and np.array_equal(h, ref.hess_coord(x, y, 0.7, om.nnzh))
         assert _rel(j, om.jac_coord(x)) <= 1e-14 and _rel(h, om.hess_coord(x, y, 0.7)) <= 1e-14
-        jp, hp = em.jac_hess_coord(x, y, 0.7, om.nnzj, om.nnzh)
-        assert np.array_equal(jp, j) and np.array_equal(hp, h)
+        tiles = {k["kind"]: k["block"] for k in em.kernels}
+        assert tiles[1] == (big.get("big_tile", 1024) or tiles[0]) and tiles[0] == ref.kernels[0]["block"]     # jac at the big tile, cons! at the model's
+        if tiles[1] == tiles[2]:        # both kinds at one workgroup size: they also share the fused launch
+            jp, hp = em.jac_hess_coord(x, y, 0.7, om.nnzj, om.nnzh)
+            assert np.array_equal(jp, j) and np.array_equal(hp, h)
+        else:
+            assert not any(k["kind"] == 8 for k in em.kernels)
+        # the other kinds of the same (mixed-size) program are untouched
+        assert np.array_equal(em.cons(x), ref.cons(x)) and em.obj(x) == ref.obj(x) and np.array_equal(em.grad(x), ref.grad(x))
 
 
 def test_cross_template_cse(lane_fused):
