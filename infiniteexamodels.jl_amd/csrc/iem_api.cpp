@@ -807,6 +807,8 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "flush32") == 0) { o.flush32 = (int)value; return IEM_OK; }
   if (std::strcmp(name, "autotune") == 0) { o.autotune = (int)value; return IEM_OK; }
   if (std::strcmp(name, "pull_scatter") == 0) { o.pull_scatter = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fold_colloc") == 0) { if (value < 0 || value > 2) return IEM_E_ARG; o.fold_colloc = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "fold_max_n") == 0) { if (value < 2 || value > 16) return IEM_E_ARG; o.fold_max_n = (int)value; return IEM_OK; }
   if (std::strcmp(name, "det_axis") == 0) { o.det_axis = (int)value; return IEM_OK; }
   if (std::strcmp(name, "det_scatter") == 0) { o.det_scatter = (int)value; return IEM_OK; }
   if (std::strcmp(name, "det_scatter_max") == 0) { o.det_scatter_max = value; return IEM_OK; }

@@ -70,6 +70,13 @@ struct Group {
   // lanes along dim 0 only — used when dim 0 is too short to fill a wave (e.g. the 2 x (S-1)
   // item box of an OrthogonalCollocation(3) derivative)
   bool flat = false;
+  // FOLDED templates (orthogonal collocation): the 1-D grid also carries templates whose items form node x element boxes
+  // (w x ne, w <= fold_n) or element lists.  Every lane derives  q1 = floor((q0 - fold_off) / fold_n)  (the element) and
+  // q2 = (q0 - fold_off) mod fold_n  (the node within it); a folded template's item (j, e) is evaluated by lane
+  // fold_off + j + fold_n * e ("natural", w = fold_n) or by the lane that owns the entry it adds into (a "pinned" clone:
+  // lanes with q2 == K evaluate item (J, q1 + de)).  A scheduling decision only, like every grid id.
+  int64_t fold_n = 0, fold_off = 0;
+  std::set<int> folded;
 };
 
 std::string hexf(double v) {
@@ -144,6 +151,11 @@ struct Output {
   std::vector<int> slot_ti, slot_tj;  // ... and the template-local index-expression ids
   bool scalar = false;
   int64_t qlo[3] = {0, 0, 0}, qhi[3] = {1, 1, 1};  // valid q range of the template in the launch domain
+  // folded templates (Group::fold_n): 0 not folded, 1 natural, 2 pinned — then only the lanes of [qlo0, qhi0) with
+  // q2 == pin_K are items (J, q1 + de)
+  int fold = 0;
+  int64_t pin_J = 0, pin_K = -1, pin_de = 0;
+  std::vector<int> grad_tidx;   // scatter kinds: template index-expression id behind each destination
 };
 
 class KernelBuilder {
@@ -287,7 +299,34 @@ class KernelBuilder {
     int64_t sh[3] = {0, 0, 0};  // k_d = q_d + sh_d
     int guard = 0;
     int64_t qlo[3] = {0, 0, 0}, qhi[3] = {1, 1, 1};
+    int fold = 0;                    // 1 natural, 2 pinned (Group::fold_n)
+    int64_t J = 0, K = 0, de = 0;    // pinned: lanes with q2 == K evaluate item (J, q1 + de)
   };
+  struct Pin { int64_t J, K, de; };
+  bool is_folded(int ti) const { return g_.fold_n > 0 && g_.folded.count(ti) != 0; }
+  // node x element box of a folded template: w nodes (1 for an element list), ne elements
+  static void fold_box(const Template &t, int64_t &w, int64_t &ne) {
+    if (t.nd >= 2) { w = t.dims[0]; ne = t.dims[1]; } else { w = 1; ne = t.dims[0]; }
+  }
+  static void fold_steps(const Template &t, const FieldDesc &f, int64_t &sj, int64_t &se) {
+    if (t.nd >= 2) { sj = f.step[0]; se = f.step[1]; } else { sj = 0; se = f.step[0]; }
+  }
+  // value  base + sj*j + se*e  of a folded template's item as a function of the lane.  An element stride that is a
+  // multiple of fold_n is rewritten on q0 (n*q1 = q0 - off - q2): node-indexed slabs are then read and written at
+  // c + k*q0, the SAME index value the templates of the grid itself use — loads merge, scatter slots meet in registers.
+  AffQ fold_aff(const TGeo &G, int64_t base, int64_t sj, int64_t se) const {
+    const int64_t n = g_.fold_n, off = g_.fold_off;
+    AffQ a;
+    if (G.fold == 1) {
+      if (se % n == 0) { const int64_t b = se / n; a.c = base - b * off; a.k[0] = b; a.k[2] = sj - b; }
+      else { a.c = base; a.k[1] = se; a.k[2] = sj; }
+    } else {
+      const int64_t c = base + sj * G.J + se * G.de;
+      if (se % n == 0) { const int64_t b = se / n; a.c = c - b * (off + G.K); a.k[0] = b; }
+      else { a.c = c; a.k[1] = se; }
+    }
+    return a;
+  }
 
   // guard id: canonical text → id
   int guard_id(const std::string &txt) {
@@ -298,13 +337,30 @@ class KernelBuilder {
 
   // shift0: lane q of dim 0 evaluates the item that normally sits on lane q - shift0 (a "pulled" clone of the
   // template, build(): scatter slots that land on a neighbour lane's entry are computed BY that neighbour)
-  TGeo geo(int ti, bool scalar, int64_t shift0 = 0) {
+  TGeo geo(int ti, bool scalar, int64_t shift0 = 0, const Pin *pin = nullptr) {
     const Template &t = m_.tpl[ti];
     TGeo G;
     G.scalar = scalar;
     std::ostringstream os;
     if (scalar) {
-      os << "(q0 == 0 && q1 == 0 && q2 == 0)";
+      os << (g_.fold_n > 0 ? "(q0 == 0)" : "(q0 == 0 && q1 == 0 && q2 == 0)");
+    } else if (is_folded(ti)) {
+      const int64_t n = g_.fold_n, off = g_.fold_off;
+      int64_t w, ne;
+      fold_box(t, w, ne);
+      os << "inb";
+      if (pin) {
+        G.fold = 2; G.J = pin->J; G.K = pin->K; G.de = pin->de;
+        const int64_t q1lo = -pin->de, q1hi = ne - pin->de;   // q1 + de in [0, ne)
+        os << " && q2 == " << pin->K << "LL && q1 >= " << coefstr(q1lo) << " && q1 < " << ip(q1hi);
+        G.qlo[0] = off + pin->K + n * q1lo; G.qhi[0] = off + pin->K + n * (q1hi - 1) + 1;
+      } else {
+        if (w != n) throw std::runtime_error("internal: natural geometry of a partial folded template");
+        G.fold = 1;
+        G.qlo[0] = off; G.qhi[0] = off + n * ne;
+        if (G.qlo[0] > 0) os << " && q0 >= " << coefstr(G.qlo[0]);
+        if (G.qhi[0] < g_.ext[0]) os << " && q0 < " << ip(G.qhi[0]);
+      }
     } else {
       os << "inb";
       for (int d = 0; d < g_.nd; ++d) {
@@ -320,6 +376,11 @@ class KernelBuilder {
   }
 
   AffQ field_aff(const Template &t, const FieldDesc &f, const TGeo &G) const {
+    if (G.fold) {
+      int64_t sj, se;
+      fold_steps(t, f, sj, se);
+      return fold_aff(G, f.base, sj, se);
+    }
     AffQ a;
     a.c = f.base;
     for (int d = 0; d < t.nd; ++d) {
@@ -353,6 +414,13 @@ class KernelBuilder {
   }
 
   AffQ klin_aff(const Template &t, const TGeo &G, int64_t scale, int64_t off) const {
+    if (G.fold) {   // item ordinal j + w*e
+      int64_t w, ne;
+      fold_box(t, w, ne);
+      AffQ a = fold_aff(G, off, t.nd >= 2 ? scale : 0, t.nd >= 2 ? scale * w : scale);
+      a.space = 3;
+      return a;
+    }
     AffQ a;
     a.space = 3;
     a.c = off;
@@ -640,13 +708,15 @@ class KernelBuilder {
     for (int ti : g_.tpls) order.emplace_back(ti, false);
     for (int ti : g_.scalars) order.emplace_back(ti, true);
     std::sort(order.begin(), order.end());
-    auto make_output = [&](int ti, bool scalar, int64_t shift0) -> Output {
+    auto make_output = [&](int ti, bool scalar, int64_t shift0, const Pin *pin) -> Output {
       const Template &t = m_.tpl[ti];
-      TGeo G = geo(ti, scalar, shift0);
+      TGeo G = geo(ti, scalar, shift0, pin);
       TplGen tg(*this, ti, G);
       Output o;
       o.kind = kind_; o.tpl = ti; o.guard = G.guard; o.pos_idx = -1;
       o.scalar = scalar;
+      o.fold = G.fold;
+      if (G.fold == 2) { o.pin_J = G.J; o.pin_K = G.K; o.pin_de = G.de; }
       for (int d = 0; d < 3; ++d) { o.qlo[d] = G.qlo[d]; o.qhi[d] = G.qhi[d]; }
       switch (kind_) {
         case KK_CONS: {
@@ -675,6 +745,7 @@ class KernelBuilder {
             for (int s = 0; s < t.o1step; ++s) {
               int id = tg.pos0(t.slot1_idx[s]);
               o.grad_idx.push_back(id);
+              o.grad_tidx.push_back(t.slot1_idx[s]);
               o.grad_mode.push_back(2);
               alg_w_ += t.n_items;
             }
@@ -705,6 +776,7 @@ class KernelBuilder {
           o.vals = tg.slots1;
           for (int s = 0; s < t.o1step; ++s) {
             o.grad_idx.push_back(tg.pos0(t.slot1_idx[s]));
+            o.grad_tidx.push_back(t.slot1_idx[s]);
             o.grad_mode.push_back(2);
             alg_w_ += t.n_items;
           }
@@ -721,29 +793,31 @@ class KernelBuilder {
           }
           tg.hr0(t.root, 0, adj, C(0.0));
           std::map<int, int> dest;   // destination IdxVal id (0-based position) -> accumulated DAG value
+          std::map<int, int> dest_tidx;
           std::vector<int> dest_order;
-          auto contribute = [&](int pos_id, int val) {
+          auto contribute = [&](int pos_id, int val, int tidx) {
             auto it = dest.find(pos_id);
-            if (it == dest.end()) { dest.emplace(pos_id, val); dest_order.push_back(pos_id); }
+            if (it == dest.end()) { dest.emplace(pos_id, val); dest_tidx.emplace(pos_id, tidx); dest_order.push_back(pos_id); }
             else it->second = add(it->second, val);
           };
           for (int s = 0; s < t.o2step; ++s) {
             int h = tg.slots2[s] < 0 ? C(0.0) : tg.slots2[s];
             int ia = tg.idx1(t.slot2_i[s]), ib = tg.idx1(t.slot2_j[s]);
             int pa = tg.pos0(t.slot2_i[s]), pb = tg.pos0(t.slot2_j[s]);
-            contribute(pa, mul(h, load(4, 0, pb, G.guard)));
+            contribute(pa, mul(h, load(4, 0, pb, G.guard)), t.slot2_i[s]);
             if (ia != ib) {
               int c2 = mul(h, load(4, 0, pa, G.guard));
               const IdxVal &A = idx_[ia], &Bv = idx_[ib];
               bool never = A.ind.empty() && Bv.ind.empty() && A.aff.k[0] == Bv.aff.k[0] && A.aff.k[1] == Bv.aff.k[1] &&
                            A.aff.k[2] == Bv.aff.k[2] && A.aff.c != Bv.aff.c;
               if (!never) c2 = mk(VSEL, sel_id(ia, ib), C(0.0), c2, -1, 0);
-              contribute(pb, c2);
+              contribute(pb, c2, t.slot2_j[s]);
             }
           }
           for (int pid : dest_order) {
             o.vals.push_back(dest[pid]);
             o.grad_idx.push_back(pid);
+            o.grad_tidx.push_back(dest_tidx[pid]);
             o.grad_mode.push_back(2);
             alg_w_ += t.n_items;
           }
@@ -775,13 +849,109 @@ class KernelBuilder {
     };
     for (auto &pr : order) {
       if (!relevant(m_.tpl[pr.first])) continue;
-      outs_.push_back(make_output(pr.first, pr.second, 0));
+      const Template &t = m_.tpl[pr.first];
+      int64_t w = 0, ne = 0;
+      if (!pr.second && is_folded(pr.first)) fold_box(t, w, ne);
+      if (w > 0 && w != g_.fold_n) {
+        // a partial folded template (fewer nodes per element than the fold) has no natural geometry: node J of every
+        // element starts on the lanes with q2 == J, pull_folded moves each slot to the lane that owns its entry
+        for (int64_t J = 0; J < w; ++J) { Pin pin{J, J, 0}; outs_.push_back(make_output(pr.first, false, 0, &pin)); }
+        continue;
+      }
+      outs_.push_back(make_output(pr.first, pr.second, 0, nullptr));
     }
     if (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD) {
       if (opt_.pull_scatter) pull_neighbours(make_output);
+      if (g_.fold_n > 0) pull_folded(make_output);
       merge_scatter();
     }
     return !outs_.empty();
+  }
+
+  // Scatter kinds, folded templates (orthogonal collocation).  Row (j, e) of a derivative adds into the entries of ALL
+  // nodes of its element and of the element's lower boundary — which is the LAST node of the element before, and which
+  // the rows of the grid itself (the dynamics at that support) write too.  Every slot of a folded template whose
+  // destination is affine in (j, e) with an element stride of fold_n entries is therefore computed by the lane that OWNS
+  // the entry: for node J of every element a clone of the template pinned to the lanes with q2 == K evaluates item
+  // (J, q1 + de), its destination is the same index value the owner's own slots have, merge_scatter sums them in registers
+  // and the entry leaves through one exclusive store.  fold_n (+1) clones per slot, each a handful of multiplies — the
+  // derivative approximation is linear, its partials are item data (src/transform.jl:511-562 of the reference).
+  template <class MakeOutput>
+  void pull_folded(MakeOutput &make_output) {
+    const int64_t n = g_.fold_n, off = g_.fold_off;
+    auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; };
+    // pure lane-affine destinations of the grid's own templates — and of the natural folded ones (a row's own node: a
+    // state no row of the grid itself touches still has ONE owner per entry): (space, k0) -> constants
+    std::map<std::pair<int, int64_t>, std::vector<int64_t>> canon;
+    for (const Output &o : outs_) {
+      if (o.scalar || o.fold == 2) continue;
+      for (size_t s = 0; s < o.grad_idx.size(); ++s) {
+        const IdxVal &iv = idx_[o.grad_idx[s]];
+        if (iv.ind.empty() && iv.aff.k[0] != 0 && iv.aff.k[1] == 0 && iv.aff.k[2] == 0) canon[{iv.aff.space, iv.aff.k[0]}].push_back(iv.aff.c);
+      }
+    }
+    std::map<std::array<int64_t, 4>, std::vector<int>> moved;   // (template, J, K, de) -> slots
+    const size_t n_outs = outs_.size();
+    for (size_t oi = 0; oi < n_outs; ++oi) {
+      Output &o = outs_[oi];
+      if (!o.fold || o.scalar) continue;
+      const Template &t = m_.tpl[o.tpl];
+      int64_t w, ne;
+      fold_box(t, w, ne);
+      for (size_t s = 0; s < o.grad_idx.size(); ++s) {
+        if (o.grad_mode[s] < 0) continue;
+        // raw destination (0-based): c + a*j + b*e
+        const IdxExpr &ix = t.idx[o.grad_tidx[s]];
+        int64_t c = ix.c0 - 1, a = 0, b = 0;
+        bool affine = true;
+        for (int j = 0; j < ix.nterms; ++j) {
+          const FieldDesc &f = t.ifields[ix.field[j]];
+          if (f.mode != IEM_F_AFFINE) { affine = false; break; }
+          int64_t sj, se;
+          fold_steps(t, f, sj, se);
+          c += ix.coef[j] * f.base; a += ix.coef[j] * sj; b += ix.coef[j] * se;
+        }
+        if (!affine || b == 0 || b % n != 0) continue;
+        const int64_t bp = b / n;
+        const int space = idx_[o.grad_idx[s]].aff.space;
+        // the owner map  entry = c* + bp*q0: the grid's own slot of that stride nearest to this one, else the slot's own lanes
+        int64_t cstar = c - bp * off;
+        bool found = false;
+        auto it = canon.find({space, bp});
+        if (it != canon.end())
+          for (int64_t cg : it->second) {
+            if ((c - cg) % bp != 0) continue;
+            const int64_t m0 = (c - cg) / bp - off;
+            if (m0 < -n || m0 > 2 * n) continue;
+            if (!found || std::llabs(m0) < std::llabs((c - cstar) / bp - off)) { cstar = cg; found = true; }
+          }
+        if (a % bp != 0 || (c - cstar) % bp != 0) continue;
+        const int64_t Jlo = o.fold == 2 ? o.pin_J : 0, Jhi = o.fold == 2 ? o.pin_J + 1 : w;
+        std::vector<std::array<int64_t, 3>> plan;   // (J, K, de) per node
+        bool stay = true, ok = true;
+        for (int64_t J = Jlo; J < Jhi && ok; ++J) {
+          const int64_t mJ = (c + a * J - cstar) / bp - off;   // owner lane - off - n*e
+          const int64_t K = mJ - n * fdiv(mJ, n), de = -fdiv(mJ, n);
+          const int64_t qlo = off + K + n * (-de), qhi = off + K + n * (ne - de - 1) + 1;
+          if (qlo < 0 || qhi > g_.ext[0]) ok = false;
+          const bool home = o.fold == 2 ? (K == o.pin_K && de == o.pin_de) : (K == J && de == 0);
+          if (!home) stay = false;
+          plan.push_back({J, K, de});
+        }
+        if (!ok || stay) continue;
+        o.grad_mode[s] = -1;
+        for (auto &pl : plan) moved[{(int64_t)o.tpl, pl[0], pl[1], pl[2]}].push_back((int)s);
+      }
+    }
+    for (auto &mv : moved) {
+      Pin pin{mv.first[1], mv.first[2], mv.first[3]};
+      Output clone = make_output((int)mv.first[0], false, 0, &pin);
+      std::vector<char> keep(clone.vals.size(), 0);
+      for (int s : mv.second) keep[s] = 1;
+      for (size_t s = 0; s < clone.vals.size(); ++s)
+        if (!keep[s]) clone.grad_mode[s] = -1;
+      outs_.push_back(std::move(clone));
+    }
   }
 
   // Scatter kinds, stencil neighbours.  A backward difference row at lane i adds into x[i] AND into x[i-1] — the
@@ -801,7 +971,7 @@ class KernelBuilder {
     auto box_items = [](const Output &o) { int64_t n = 1; for (int d = 0; d < 3; ++d) n *= std::max<int64_t>(o.qhi[d] - o.qlo[d], 0); return n; };
     for (size_t oi = 0; oi < outs_.size(); ++oi) {
       const Output &o = outs_[oi];
-      if (o.scalar) continue;
+      if (o.scalar || o.fold) continue;   // (folded templates: pull_folded)
       for (size_t s = 0; s < o.grad_idx.size(); ++s) {
         const IdxVal &iv = idx_[o.grad_idx[s]];
         if (!iv.ind.empty() || iv.aff.k[0] == 0) continue;
@@ -842,7 +1012,7 @@ class KernelBuilder {
     }
     for (auto &mv : moved) {
       const int oi = mv.first.first;
-      Output clone = make_output(outs_[oi].tpl, false, mv.first.second);
+      Output clone = make_output(outs_[oi].tpl, false, mv.first.second, nullptr);
       if (clone.vals.size() != outs_[oi].vals.size()) throw std::runtime_error("internal: pulled clone differs in shape");
       std::vector<char> keep(clone.vals.size(), 0);
       for (int s : mv.second) { keep[s] = 1; outs_[oi].grad_mode[s] = -1; }
@@ -874,6 +1044,7 @@ class KernelBuilder {
       };
       int host = -1;   // the part whose box contains every other part's
       for (size_t c = 0; c < parts.size() && host < 0; ++c) {
+        if (outs_[parts[c].first].fold == 2) continue;   // a pinned clone stores on one lane in fold_n: never the carrier of others
         bool all = true;
         for (auto &p : parts) if (!inside(outs_[p.first], outs_[parts[c].first])) all = false;
         if (all) host = (int)c;
@@ -910,7 +1081,7 @@ class KernelBuilder {
           int v = mk(VGUARD, o.guard, o.vals[p.second], -1, -1, 0);
           acc = acc < 0 ? v : add(acc, v);
         }
-        u.vals = {acc}; u.grad_idx = {kv.first}; u.grad_mode = {2};
+        u.vals = {acc}; u.grad_idx = {kv.first}; u.grad_tidx = {-1}; u.grad_mode = {2};
         for (auto &p : parts) outs_[p.first].grad_mode[p.second] = -1;
         outs_.push_back(std::move(u));
         continue;
@@ -959,7 +1130,7 @@ class KernelBuilder {
         if (!iv.ind.empty() || outs_[oi].grad_mode[s] < 0) continue;
         for (size_t hj = 0; hj < outs_.size(); ++hj) {
           Output &h = outs_[hj];
-          if (h.scalar) continue;
+          if (h.scalar || h.fold == 2) continue;
           bool has0 = true;
           for (int d = 0; d < 3; ++d) if (h.qlo[d] > 0 || h.qhi[d] < 1) has0 = false;
           if (!has0) continue;
@@ -967,6 +1138,7 @@ class KernelBuilder {
           for (size_t hs = 0; hs < h.grad_idx.size() && !done_; ++hs) {
             const IdxVal &hv = idx_[h.grad_idx[hs]];
             if (h.grad_mode[hs] < 0 || !hv.ind.empty() || hv.aff.c != iv.aff.c) continue;
+            if (g_.fold_n > 0 && (hv.aff.k[1] != 0 || hv.aff.k[2] != 0)) continue;   // (derived coordinates are not 0 on lane 0)
             h.vals[hs] = add(h.vals[hs], mk(VGUARD, outs_[oi].guard, outs_[oi].vals[s], -1, -1, 0));
             outs_[oi].grad_mode[s] = -1;
             done_ = true;
@@ -1426,6 +1598,7 @@ class KernelBuilder {
             else if (mode == 5) {   // parked for the plan-driven gather: one slot of the aux buffer per lane of the launch domain
               if (o.scalar) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << "] = v" << o.vals[s] << ";\n";
               else if (g_.flat) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q] = v" << o.vals[s] << ";\n";
+              else if (g_.fold_n > 0) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0] = v" << o.vals[s] << ";\n";
               else tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0 + " << ip(g_.ext[0], 6) << " * (q1 + " << ip(g_.ext[1], 6) << " * q2)] = v" << o.vals[s] << ";\n";
             }
             else if (mode == 4) {
@@ -1491,6 +1664,15 @@ class KernelBuilder {
       head << "  const bool inb = q < " << ip(g_.ext[0] * g_.ext[1] * g_.ext[2]) << ";\n";
       head << "  const long long q0 = q % " << ip(g_.ext[0]) << ", qr = q / " << ip(g_.ext[0]) << ";\n";
       head << "  const long long q1 = qr % " << ip(g_.ext[1]) << ", q2 = qr / " << ip(g_.ext[1]) << ";\n";
+    } else if (g_.fold_n > 0) {
+      // element / node of the lane: one 64-bit division per WORKGROUP (block-uniform), 32-bit steps per lane
+      const std::string n = std::to_string(g_.fold_n);
+      head << "  const long long q0 = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
+      head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+      head << "  const long long fb_ = (long long)blockIdx.x * " << qstep_str() << " - " << ip(g_.fold_off) << ";\n";
+      head << "  const long long fq_ = (fb_ >= 0 ? fb_ : fb_ - " << (g_.fold_n - 1) << ") / " << n << ";\n";
+      head << "  const int ft_ = (int)(fb_ - " << n << " * fq_) + (int)threadIdx.x;\n";
+      head << "  const long long q1 = fq_ + ft_ / " << n << ", q2 = ft_ % " << n << "; (void)q1; (void)q2;\n";
     } else {
     head << "  const long long q0 = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
     if (g_.nd == 2 && g_.ext[1] > 65535) {
@@ -1524,8 +1706,10 @@ class KernelBuilder {
       const IdxVal &iv = idx_[l.idxval];
       int64_t lo = iv.aff.c, hi = iv.aff.c;
       for (int d = 0; d < 3; ++d) {
-        int64_t e = iv.aff.k[d] * (g_.ext[d] - 1);
-        if (e < 0) lo += e; else hi += e;
+        int64_t clo, chi;
+        coord_range(d, clo, chi);
+        const int64_t e0 = iv.aff.k[d] * clo, e1 = iv.aff.k[d] * chi;
+        lo += std::min(e0, e1); hi += std::max(e0, e1);
       }
       if (!iv.ind.empty()) { lo = 0; hi = g_.ext[0] * g_.ext[1] * g_.ext[2] - 1; }
       int akey = l.arr == 3 ? 100 + l.slot : l.arr;   // 0 x, 1 theta, 2 y, 4 v, 100+ item columns
@@ -1664,6 +1848,12 @@ class KernelBuilder {
   bool carrier() const {
     return kind_ == KK_CONS || kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_JPROD;
   }
+  // values coordinate d takes over the launch domain (a folded group derives q1, q2 from q0)
+  void coord_range(int d, int64_t &lo, int64_t &hi) const {
+    lo = 0; hi = g_.ext[d] - 1;
+    if (g_.fold_n > 0 && d == 1) { lo = -((g_.fold_off + g_.fold_n - 1) / g_.fold_n); hi = std::max<int64_t>(g_.ext[0] - 1 - g_.fold_off, 0) / g_.fold_n; }
+    if (g_.fold_n > 0 && d == 2) { lo = 0; hi = g_.fold_n - 1; }
+  }
   int qstep() const {
     const bool blk = (kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_CONS || kind_ == KK_JPROD) && opt_.store_mode == 2;
     return (blk && opt_.overlap && opt_.block >= 256) ? opt_.block - 16 : opt_.block;
@@ -1787,6 +1977,119 @@ std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)>
     groups[best].scalars = scalars;
   }
   return groups;
+}
+
+// Orthogonal collocation (Group::fold_n): put the node x element boxes of the derivative rows — and the element lists
+// of constant_over_collocation — onto the lanes of the 1-D support grid they differentiate over.  `partial`: also boxes
+// with fewer nodes per element than the fold and element lists (scatter kinds only: their items are not contiguous in
+// the lane index, which the block store of the COO kinds needs).
+void fold_groups(const Model &m, std::vector<Group> &groups, int max_n, bool partial) {
+  typedef std::array<int64_t, 3> Map;   // variable index (1-based) = c + a*j + b*e
+  auto var_maps = [&](const Template &t, std::vector<Map> &out) {
+    for (const Node &nd : t.nodes) {
+      if (nd.op != IEM_OP_VAR) continue;
+      const IdxExpr &ix = t.idx[nd.a];
+      Map mp{ix.c0, 0, 0};
+      for (int j = 0; j < ix.nterms; ++j) {
+        const FieldDesc &f = t.ifields[ix.field[j]];
+        if (f.mode != IEM_F_AFFINE) return false;
+        mp[0] += ix.coef[j] * f.base;
+        if (t.nd >= 2) { mp[1] += ix.coef[j] * f.step[0]; mp[2] += ix.coef[j] * f.step[1]; }
+        else mp[2] += ix.coef[j] * f.step[0];
+      }
+      out.push_back(mp);
+    }
+    return true;
+  };
+  auto is_line = [](const Group &g) { return g.grid_id > 0 && g.nd == 1 && !g.flat; };
+  // lane-affine variable maps of a 1-D grid's own templates: (c at lane 0, stride)
+  auto line_maps = [&](const Group &g, std::vector<std::pair<int64_t, int64_t>> &out) {
+    for (int ti : g.tpls) {
+      if (g.folded.count(ti)) continue;
+      const Template &u = m.tpl[ti];
+      std::vector<Map> mm;
+      if (u.nd != 1 || !var_maps(u, mm)) continue;
+      const int64_t sh = g.lo[0] - u.origin[0];
+      for (const Map &mp : mm) if (mp[2] != 0) out.emplace_back(mp[0] + mp[2] * sh, mp[2]);
+    }
+  };
+  // 1. full boxes (fold_n nodes x ne elements, all templates of the flat group): they decide fold_n and fold_off by vote
+  for (size_t fi = 0; fi < groups.size(); ++fi) {
+    const Group &F = groups[fi];
+    if (F.grid_id <= 0 || !F.flat || F.nd != 2 || F.ext[0] < 2 || F.ext[0] > max_n || F.ext[1] < 1 || F.fold_n > 0) continue;
+    const int64_t n = F.ext[0], ne = F.ext[1];
+    bool full = true;
+    std::vector<Map> fm;
+    for (int ti : F.tpls) {
+      const Template &t = m.tpl[ti];
+      if (t.nd != 2 || t.dims[0] != n || t.dims[1] != ne || t.origin[0] != F.lo[0] || t.origin[1] != F.lo[1] || !var_maps(t, fm)) full = false;
+    }
+    if (!full) continue;
+    std::map<std::pair<size_t, int64_t>, int64_t> votes;   // (line group, offset) -> matching maps
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const Group &G = groups[gi];
+      if (!is_line(G) || (G.fold_n > 0 && G.fold_n != n) || G.ext[0] < n * ne) continue;
+      std::vector<std::pair<int64_t, int64_t>> gm;
+      line_maps(G, gm);
+      for (const Map &mp : fm) {
+        if (mp[1] == 0 || mp[2] != n * mp[1]) continue;   // the row's own node: full stride
+        for (auto &cg : gm) {
+          if (cg.second != mp[1] || (mp[0] - cg.first) % mp[1] != 0) continue;
+          const int64_t off = (mp[0] - cg.first) / mp[1];
+          if (off < 0 || off + n * ne > G.ext[0] || (G.fold_n > 0 && off != G.fold_off)) continue;
+          ++votes[{gi, off}];
+        }
+      }
+    }
+    if (votes.empty()) continue;
+    auto best = votes.begin();
+    for (auto it = votes.begin(); it != votes.end(); ++it) if (it->second > best->second) best = it;
+    Group &G = groups[best->first.first];
+    G.fold_n = n; G.fold_off = best->first.second;
+    for (int ti : F.tpls) { G.tpls.push_back(ti); G.folded.insert(ti); }
+    G.scalars.insert(G.scalars.end(), F.scalars.begin(), F.scalars.end());
+    groups.erase(groups.begin() + (long)fi);
+    --fi;
+  }
+  if (!partial) return;
+  // 2. element lists and narrower boxes whose variable maps advance by fold_n entries of a slab of the line per element
+  for (size_t fi = 0; fi < groups.size(); ++fi) {
+    const Group &F = groups[fi];
+    if (F.grid_id <= 0 || F.fold_n > 0 || F.nd > 2 || (F.nd == 2 && !F.flat) || F.ext[2] != 1) continue;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      Group &G = groups[gi];
+      if (gi == fi || G.fold_n == 0) continue;
+      const int64_t n = G.fold_n, w = F.nd == 2 ? F.ext[0] : 1, ne = F.nd == 2 ? F.ext[1] : F.ext[0];
+      if (w >= n || ne < 1 || n * ne > G.ext[0] + n) continue;
+      std::vector<std::pair<int64_t, int64_t>> gm;
+      line_maps(G, gm);
+      bool fits = true;
+      for (int ti : F.tpls) {
+        const Template &t = m.tpl[ti];
+        std::vector<Map> fm;
+        int64_t tw = t.nd == 2 ? t.dims[0] : 1, tne = t.nd == 2 ? t.dims[1] : t.dims[0];
+        if (t.nd != F.nd || tw != w || tne != ne || !var_maps(t, fm) || fm.empty()) { fits = false; break; }
+        for (const Map &mp : fm) {
+          bool hit = false;
+          if (mp[2] != 0 && mp[2] % n == 0)
+            for (auto &cg : gm) {
+              if (cg.second != mp[2] / n || (mp[0] - cg.first) % cg.second != 0) continue;
+              // owner lanes of the corner items lie on the line
+              const int64_t l0 = (mp[0] - cg.first) / cg.second, l1 = l0 + (mp[1] * (w - 1)) / cg.second + n * (ne - 1);
+              if (mp[1] % cg.second == 0 && l0 >= 0 && l1 < G.ext[0] && std::min(l0, l1) >= 0 && std::max(l0, l1) < G.ext[0]) hit = true;
+            }
+          if (!hit) { fits = false; break; }
+        }
+        if (!fits) break;
+      }
+      if (!fits) continue;
+      for (int ti : F.tpls) { G.tpls.push_back(ti); G.folded.insert(ti); }
+      G.scalars.insert(G.scalars.end(), F.scalars.begin(), F.scalars.end());
+      groups.erase(groups.begin() + (long)fi);
+      --fi;
+      break;
+    }
+  }
 }
 
 // min / max of an index expression over the template's item box — host-side safety check
@@ -1928,7 +2231,7 @@ Program generate(const Model &m, const Options &opt_in) {
   // The scatter kinds (grad, J'v, Hv) always keep the lane-fused groups: when several templates add
   // into the same entry, ONE lane issues those adds in program order (deterministic); side by side
   // they would come from different workgroups in arrival order.
-  const std::vector<Group> groups_fused = groups;
+  std::vector<Group> groups_fused = groups;
   bool split = false;
   if (!opt.no_fuse && opt.split_small > 0 && !opt.hess_merge) {   // the merged Hessian layout is defined on fused lanes
     // A support grid that fills only a fraction of the chip (<= split_small workgroups) is
@@ -1944,6 +2247,14 @@ Program generate(const Model &m, const Options &opt_in) {
       if (nb <= opt.split_small) solo.insert(g.tpls.begin(), g.tpls.end());
     }
     if (!solo.empty()) { groups = make_groups(m, [&](size_t ti) { return solo.count(ti) != 0; }, opt.flat2d != 0); split = true; }
+  }
+  // Orthogonal collocation: the scatter kinds put the node x element boxes (and the element lists) on the lanes of the
+  // support grid itself, so that every entry has ONE writer (pull_folded); fold_colloc = 2: the full boxes for every kind.
+  if (opt.fold_colloc > 0 && !opt.no_fuse) {
+    const size_t before = groups_fused.size();
+    fold_groups(m, groups_fused, opt.fold_max_n, true);
+    if (groups_fused.size() != before) split = true;   // (the scatter kinds then run on groups of their own)
+    if (opt.fold_colloc >= 2) fold_groups(m, groups, opt.fold_max_n, false);
   }
   std::ostringstream src;
   src << "// generated by libiem_hip (iem_codegen.cpp) — do not edit\n";
@@ -1989,6 +2300,8 @@ Program generate(const Model &m, const Options &opt_in) {
             if (outs[oi].grad_mode[s] < 0) continue;   // folded into another slot (merge_scatter)
             const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
             GSlot gs{kind, (int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
+            // a folded group derives q1, q2 from the lane: a destination that still depends on them is not an interval of the lane
+            if (g.fold_n > 0 && (iv.aff.k[1] != 0 || iv.aff.k[2] != 0)) gs.pure = false;
             for (int d = 0; d < 3; ++d) { gs.box_lo[d] = scalar ? 0 : outs[oi].qlo[d]; gs.box_n[d] = box_n[d]; if (!scalar && outs[oi].qhi[d] <= outs[oi].qlo[d]) gs.empty = true; }
             gs.count = gs.empty ? 0 : box_items;
             if (gs.pure) {
@@ -2008,6 +2321,7 @@ Program generate(const Model &m, const Options &opt_in) {
               }
               gs.lo = lo; gs.hi = hi; gs.injective = inj;
               gs.count = box_items;
+              if (outs[oi].fold == 2) gs.count = (box_n[0] - 1) / g.fold_n + 1;   // a pinned clone: one lane in fold_n
               for (int d = 0; d < 3; ++d) { gs.box_lo[d] = scalar ? 0 : outs[oi].qlo[d]; gs.box_n[d] = box_n[d]; }
               // a sum over the non-lane axes: the entry depends on the lane only, and every row of dims 1, 2 adds into it
               gs.axis_ok = !g.flat && !scalar && iv.aff.k[0] != 0 && iv.aff.k[1] == 0 && iv.aff.k[2] == 0 && box_n[1] * box_n[2] > 1 &&
@@ -2016,6 +2330,7 @@ Program generate(const Model &m, const Options &opt_in) {
               gs.uniform0 = !g.flat && !scalar && iv.aff.k[0] == 0 && box_n[0] > 1;
             } else {
               gs.lo = INT64_MIN; gs.hi = INT64_MAX;
+              if (outs[oi].fold == 2) gs.count = (box_n[0] - 1) / g.fold_n + 1;
             }
             gslots.push_back(gs);
           }
@@ -2137,17 +2452,23 @@ Program generate(const Model &m, const Options &opt_in) {
       for (q[2] = a.box_lo[2]; q[2] < a.box_lo[2] + a.box_n[2]; ++q[2])
         for (q[1] = a.box_lo[1]; q[1] < a.box_lo[1] + a.box_n[1]; ++q[1])
           for (q[0] = a.box_lo[0]; q[0] < a.box_lo[0] + a.box_n[0]; ++q[0]) {
-            int64_t d = iv.aff.c + iv.aff.k[0] * q[0] + iv.aff.k[1] * q[1] + iv.aff.k[2] * q[2];
+            int64_t c1 = q[1], c2 = q[2];
+            if (g.fold_n > 0) {   // derived coordinates; a pinned clone's items sit on the lanes with q2 == K
+              const int64_t l = q[0] - g.fold_off;
+              c1 = (l >= 0 ? l : l - (g.fold_n - 1)) / g.fold_n; c2 = l - g.fold_n * c1;
+              if (o.fold == 2 && c2 != o.pin_K) continue;
+            }
+            int64_t d = iv.aff.c + iv.aff.k[0] * q[0] + iv.aff.k[1] * c1 + iv.aff.k[2] * c2;
             for (auto &t : iv.ind) {
               const ILoad &il = kb.iloads()[t.second];
-              const int64_t p = il.pos.c + il.pos.k[0] * q[0] + il.pos.k[1] * q[1] + il.pos.k[2] * q[2];
+              const int64_t p = il.pos.c + il.pos.k[0] * q[0] + il.pos.k[1] * c1 + il.pos.k[2] * c2;
               const ArrayDesc &arr = m.arrs[kb.ia_arrays()[il.ia_slot]];
               if (p < 0 || p >= arr.n) throw std::runtime_error("index array position out of range");
               d += t.first * arr.i(p);
             }
             if (d < 0 || d >= m.nvar) throw std::runtime_error("scatter destination out of range");
             dest_of.push_back(d);
-            if (pos_of) pos_of->push_back(park + (o.scalar ? 0 : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
+            if (pos_of) pos_of->push_back(park + (o.scalar ? 0 : g.fold_n > 0 ? q[0] : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
           }
       return o.scalar ? (int64_t)1 : g.ext[0] * g.ext[1] * g.ext[2];
     };

@@ -92,6 +92,12 @@ struct Options {
   int64_t big_batch_jac = 4000, big_batch_hess = 4000;
   int big_xcd = 1;
   int big_tile = 1024;     // 0: keep the model's tile (the 512-lane, 48-slot form of the first measurements)
+  // Orthogonal collocation: 1 = the scatter kinds (grad! / jtprod! / hprod!) evaluate the node x element boxes of the
+  // derivative rows and the element lists of constant_over_collocation on the lanes of the support grid itself, every
+  // addend computed by the lane that owns its entry (KernelBuilder::pull_folded) — exclusive stores instead of the
+  // plan-driven gather; 2 = the full boxes join the support grid for every kind (shared loads; A/B); 0 = off
+  int fold_colloc = 1;
+  int fold_max_n = 6;      // ... for at most this many rows per element (the clones of a derivative row grow with its square)
   int pair_kernel = 1;     // 1: also emit the fused jac_coord! + hess_coord! launch (KK_PAIR, iem_jac_hess_coord)
   int store_wait = 0;      // experiment: s_waitcnt vmcnt(0) behind every flushed batch (paces a wave's outstanding stores)
   // runtime only (the generator ignores them)

@@ -313,7 +313,7 @@ def test_no_float_atomics_remain(name, grid_mode):
     v = np.random.default_rng(6).standard_normal(om.nvar)
     n_atomics = {}
     for ds in (2, 1, 0):
-        with iemlib.options(det_scatter=ds):
+        with iemlib.options(det_scatter=ds, fold_colloc=0):   # (folded collocation rows leave nothing to gather: next test)
             em = EmulatedModel(core, blob)
             plan = iemlib.emit_launch_plan(blob)
         n_atomics[ds] = em.source.count("iem_grad_atomic(OUT") + em.source.count("iem_grad_wave_uniform(OUT")     # calls, not the definitions
@@ -327,6 +327,47 @@ def test_no_float_atomics_remain(name, grid_mode):
     assert n_atomics[1] <= n_atomics[0]
     if name in ("quadrotor_oc3_40", "kinetic_20"):       # collocation: boundary-node entries get more than two addends
         assert n_atomics[1] < n_atomics[0]
+
+
+@pytest.mark.parametrize("name", ["quadrotor_oc3_40", "quadrotor_oc3_700", "kinetic_20", "hovercraft_oc4"])
+def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
+    """`fold_colloc` (default 1): the scatter kinds evaluate the node x element boxes of orthogonal-collocation derivative
+    rows — and the element lists of constant_over_collocation — on the lanes of the support grid itself; every addend of a
+    row (its own node, the other nodes of its element, the element's lower boundary = the last node of the element before)
+    is computed by the lane that owns the entry, summed in registers with the grid's own rows and stored ONCE.  Nothing of
+    jtprod! is left for float atomics, the gather plan or a zero fill on the uniform-grid models; what remains on the
+    hovercraft are its point constraints and way-points (a few items against many: deferred, as without collocation).
+    fold_colloc = 2 puts the full boxes on the support lanes for EVERY kind: same values, same COO positions."""
+    from infiniteexamodels.jl_amd import lib as iemlib
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om)
+    vc = np.random.default_rng(5).standard_normal(om.ncon)
+    v = np.random.default_rng(6).standard_normal(om.nvar)
+    count = lambda src: src.count("iem_grad_atomic(OUT") + src.count("iem_grad_wave_uniform(OUT")
+    with iemlib.options(det_scatter=0, fold_colloc=0):
+        before = count(iemlib.emit_source(blob)[0])
+    with iemlib.options(det_scatter=0):
+        em0 = EmulatedModel(core, blob)
+    assert count(em0.source) < before / 4
+    assert _rel(em0.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    em = EmulatedModel(core, blob)
+    plan = iemlib.emit_launch_plan(blob)
+    if name != "hovercraft_oc4":
+        assert count(em0.source) == 0 and "\ngather " not in plan and "\nzero 6 " not in plan
+    assert "q2 == " in em.source                       # pinned clones: node K of an element evaluates row J
+    assert _rel(em.grad(x), om.grad(x)) <= 1e-13
+    assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
+    with iemlib.options(fold_colloc=2):
+        em2 = EmulatedModel(core, blob)
+    assert _rel(em2.cons(x), om.cons(x)) <= 1e-13
+    assert np.array_equal(em2.jac_coord(x, om.nnzj), em.jac_coord(x, om.nnzj))
+    assert np.array_equal(em2.hess_coord(x, y, 0.7, om.nnzh), em.hess_coord(x, y, 0.7, om.nnzh))
+    assert _rel(em2.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-13
+    assert _rel(em2.jprod(x, v), om.jprod(x, v)) <= 1e-13 and _rel(em2.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    assert abs(em2.obj(x) - om.obj(x)) <= 1e-13 * max(1.0, abs(om.obj(x)))
 
 
 def test_a_few_items_against_many_are_deferred(lane_fused):
