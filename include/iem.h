@@ -313,10 +313,10 @@ void iem_free(void *p);
  *                  order (no float atomics); 0: one f64 atomic per wave (A/B runs)
  *   "pull_scatter" 1 (default): grad!/jtprod!/hprod! compute a stencil neighbour's addend (x[i-1] of a difference
  *                  row) on the neighbour's lane — exclusive stores, no zero fill; 0: atomics (A/B runs)
- *   "fold_colloc"  1 (default): on orthogonal-collocation models grad!/jtprod!/hprod! evaluate the node x element boxes of
- *                  the derivative rows (and the element lists of constant_over_collocation) on the lanes of the support grid
- *                  itself, every addend on the lane that owns its entry — exclusive stores, no gather plan; 2: the boxes join
- *                  the support grid for every kind (A/B); 0: off.  "fold_max_n" (6): at most this many rows per element
+ *   "fold_colloc"  orthogonal-collocation models: the node x element boxes of the derivative rows ride on the lanes of the
+ *                  support grid.  1: for grad!/jtprod!/hprod! (with the element lists of constant_over_collocation) — every
+ *                  addend on the lane that owns its entry, exclusive stores, no gather plan; 2 (default): also for every
+ *                  other kind (shared loads); 0: off.  "fold_max_n" (6): at most this many rows per element
  *   "det_scatter"  1 (default): scatter addends that would still be float atomics AND can meet more than one other addend in
  *                  their entry (collocation stencils, gathered indices) are parked per item and summed per entry in the
  *                  order of a plan built at create time (12 bytes of plan + 8 of scratch per addend, at most

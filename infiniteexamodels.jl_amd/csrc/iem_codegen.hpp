@@ -92,11 +92,13 @@ struct Options {
   int64_t big_batch_jac = 4000, big_batch_hess = 4000;
   int big_xcd = 1;
   int big_tile = 1024;     // 0: keep the model's tile (the 512-lane, 48-slot form of the first measurements)
-  // Orthogonal collocation: 1 = the scatter kinds (grad! / jtprod! / hprod!) evaluate the node x element boxes of the
-  // derivative rows and the element lists of constant_over_collocation on the lanes of the support grid itself, every
-  // addend computed by the lane that owns its entry (KernelBuilder::pull_folded) — exclusive stores instead of the
-  // plan-driven gather; 2 = the full boxes join the support grid for every kind (shared loads; A/B); 0 = off
-  int fold_colloc = 1;
+  // Orthogonal collocation: the node x element boxes of the derivative rows ride on the lanes of the support grid itself.
+  // 1 = for the scatter kinds (grad! / jtprod! / hprod!), together with the element lists of constant_over_collocation:
+  // every addend is computed by the lane that owns its entry (KernelBuilder::pull_folded) — exclusive stores instead of
+  // the plan-driven gather (quadrotor OC3, 5e5 public supports: jtprod! 417 -> 103 us); 2 (default) = the full boxes also
+  // for every other kind: a row and the dynamics at its node share their loads (cons! -10 %, jprod! -18 %, jac_coord!
+  // equal; profiles/r03_collocation_fold.json); 0 = off
+  int fold_colloc = 2;
   int fold_max_n = 6;      // ... for at most this many rows per element (the clones of a derivative row grow with its square)
   int pair_kernel = 1;     // 1: also emit the fused jac_coord! + hess_coord! launch (KK_PAIR, iem_jac_hess_coord)
   int store_wait = 0;      // experiment: s_waitcnt vmcnt(0) behind every flushed batch (paces a wave's outstanding stores)

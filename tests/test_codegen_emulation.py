@@ -337,7 +337,8 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
     is computed by the lane that owns the entry, summed in registers with the grid's own rows and stored ONCE.  Nothing of
     jtprod! is left for float atomics, the gather plan or a zero fill on the uniform-grid models; what remains on the
     hovercraft are its point constraints and way-points (a few items against many: deferred, as without collocation).
-    fold_colloc = 2 puts the full boxes on the support lanes for EVERY kind: same values, same COO positions."""
+    fold_colloc = 2 (the default) puts the full boxes on the support lanes for EVERY kind: same values, same COO positions
+    as with 1."""
     from infiniteexamodels.jl_amd import lib as iemlib
     core = cases.build_core(name)
     blob = core.to_blob()
@@ -360,7 +361,7 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
     assert _rel(em.grad(x), om.grad(x)) <= 1e-13
     assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
     assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
-    with iemlib.options(fold_colloc=2):
+    with iemlib.options(fold_colloc=1):
         em2 = EmulatedModel(core, blob)
     assert _rel(em2.cons(x), om.cons(x)) <= 1e-13
     assert np.array_equal(em2.jac_coord(x, om.nnzj), em.jac_coord(x, om.nnzj))

@@ -571,3 +571,44 @@ def test_raw_loop_forms_agree(name, torch_cuda):
         torch.cuda.synchronize()
         assert f == ref[0] and torch.equal(g, ref[1]) and torch.equal(c, ref[2]) and torch.equal(j, ref[3]) and torch.equal(h, ref[4]), kw
     gm.close()
+
+
+@pytest.mark.parametrize("name,builder", [("quadrotor_oc3", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).quadrotor(40_000, collocation=3)),
+                                          ("kinetic", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).kinetic_control(30_000)),
+                                          ("hovercraft_oc4", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).hovercraft(20_001, collocation=4))])
+def test_collocation_fold_variants_on_gpu(name, builder, torch_cuda):
+    """`fold_colloc` on grids of > 64 workgroups (the lane-fused shape): 1 (default) = the derivative rows of an
+    orthogonal-collocation model ride on the support lanes for grad! / jtprod! / hprod! (exclusive stores, no gather
+    plan), 2 = for every kind, 0 = the plan-driven gather.  Every variant agrees with the oracle; the COO kinds write the
+    same bytes in all three; jtprod! is bitwise reproducible from call to call."""
+    torch = torch_cuda
+    from infiniteexamodels.jl_amd import transcribe
+    from infiniteexamodels.jl_amd.model import ExaModel
+    from pyoracle import OracleModel
+    core = transcribe.exa_core(builder())
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    x, y = cases.eval_point_for(name, om, 3)
+    rng = np.random.default_rng(11)
+    v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+    xd, yd, vd, vcd = (torch.tensor(a, device="cuda") for a in (x, y, v, vc))
+    nanv = lambda n: torch.full((n,), float("nan"), device="cuda", dtype=torch.float64)
+    ref = dict(cons=om.cons(x), jac=om.jac_coord(x), jprod=om.jprod(x, v), jtprod=om.jtprod(x, vc), grad=om.grad(x), hprod=om.hprod(x, y, v, 0.3))
+    coo = {}
+    for fc in (1, 2, 0):
+        gm = ExaModel(core, device=0, blob=blob, options=dict(fold_colloc=fc))
+        out = dict(cons=gm.cons(xd, nanv(om.ncon)), jac=gm.jac_coord(xd, nanv(om.nnzj)), jprod=gm.jprod(xd, vd, nanv(om.ncon)),
+                   jtprod=gm.jtprod(xd, vcd, nanv(om.nvar)), grad=gm.grad(xd, nanv(om.nvar)), hprod=gm.hprod(xd, yd, vd, nanv(om.nvar), obj_weight=0.3))
+        for k, t in out.items():
+            _close(t.cpu().numpy(), ref[k], f"{k} (fold_colloc={fc})")
+        hv = gm.hess_coord(xd, yd, nanv(om.nnzh), obj_weight=0.3)
+        _close(hv.cpu().numpy(), om.hess_coord(x, y, 0.3), f"hess_coord (fold_colloc={fc})")
+        assert abs(gm.obj(xd) - om.obj(x)) <= RTOL * max(1.0, abs(om.obj(x)))
+        coo[fc] = (out["cons"].clone(), out["jac"].clone(), hv.clone())
+        first = out["jtprod"].clone()
+        for _ in range(5):
+            assert torch.equal(gm.jtprod(xd, vcd, nanv(om.nvar)), first), f"jtprod! not reproducible (fold_colloc={fc})"
+        gm.close()
+    for fc in (2, 0):
+        for a, b in zip(coo[1], coo[fc]):
+            assert torch.equal(a, b), f"cons! / jac_coord! / hess_coord! bytes differ between fold_colloc=1 and {fc}"
