@@ -254,23 +254,29 @@ int iem_csr_spmv(iem_model *m, int64_t n, const int32_t *d_rowptr, const int32_t
  * iteration; the reference hands it to MadNLPGPU + CUDSS, README.md:36-37) --------------------------------------------
  * The augmented system of a transcription whose supports couple through a derivative stencil only (transform.jl:535-557)
  * is block tridiagonal once its unknowns are grouped by support, plus a small dense border for finite / first-stage
- * variables.  The caller (kkt_chain.py; a Julia host likewise) owns the dense block arrays on the device and fills them
- * every iteration: D (S x nb x nb, the diagonal blocks, symmetric), B (S x nb x nb, B[k] = K[block k, block k-1]),
+ * variables — and its coupling blocks are NARROW: K[block k, block k-1] has entries only on a few rows R of block k (the
+ * derivative-approximation rows) and a few columns C of block k-1 (the differentiated states), a property block cyclic
+ * reduction preserves.  The caller (kkt_chain.py; a Julia host likewise) owns the block arrays on the device and fills
+ * them every iteration: D (S x nb x nb, the diagonal blocks, symmetric), Bt (S x nc x nc, Bt[k] = K[block k, block k-1]
+ * restricted to rows d_rows[0..nc) of block k and columns d_cols[0..nc) of block k-1; local indices, -1 = padding),
  * E (S x nb x ne, the coupling to the border), row-major.  iem_kkt_chain_factor runs block cyclic reduction in place
- * (hand-written kernels, csrc/iem_kkt_device.h): D becomes the inverses of the pivot blocks, X / Y / Z (same shapes as
- * B / B / E) and Gp (S x ne x ne, per-block border Schur terms: G_schur = G - sum_k Gp[k]) are outputs; d_info[0] =
+ * (hand-written kernels, csrc/iem_kkt_device.h; the inverses on the FP64 matrix cores): D becomes the inverses of the pivot
+ * blocks, Bt the couplings of every level, BR (S x nc x nc: the coupling of block i + s to i at the level that eliminated i),
+ * Z (as E) and Gp (S x ne x ne, per-block border Schur terms: G_schur = G - sum_k Gp[k]) are outputs; d_info[0] =
  * negative pivots (the inertia), d_info[1] = pivots below `tiny` (replaced by +-tiny: do not trust the factors).
- * iem_kkt_chain_solve: phase 0 reduces the right-hand side r (S x nb, in place) and writes rBp (S x ne: r_border_schur =
- * r_border - sum_k rBp[k]); the caller solves the ne x ne border system; phase 1 substitutes back (r becomes the solution).
- * d_B == NULL (and d_X == d_Y == NULL): the blocks couple to the border only (scenario blocks of a two-stage problem) — one
- * launch instead of the levels.  nb: multiple of 4 in 4..96, ne: multiple of 4 in 0..64 (two tiles of each must fit the 160 KB of LDS).  Asynchronous on the
- * handle's stream. */
-int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, double *d_D, double *d_B, double *d_X, double *d_Y, double *d_E,
-                         double *d_Z, double *d_Gp, int64_t *d_info, double tiny);
-int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, const double *d_Dinv, const double *d_X, const double *d_Y, const double *d_Z,
-                        double *d_r, double *d_rBp, const double *d_xB, int phase);
-/* HIP source of the solver's kernels for one (nb, ne) and its cache key — for offline builds (no device needed; malloc'ed) */
-int iem_kkt_source(int nb, int ne, char **out_src, uint64_t *out_key);
+ * iem_kkt_chain_solve: phase 0 reduces the right-hand side r (S x nb, in place; z: S x nb of scratch that must survive until
+ * phase 1) and writes rBp (S x ne: r_border_schur = r_border - sum_k rBp[k]); the caller solves the ne x ne border system;
+ * phase 1 substitutes back (r becomes the solution).
+ * d_Bt == NULL (and d_BR == d_rows == d_cols == d_z == NULL): the blocks couple to the border only (scenario blocks of a
+ * two-stage problem) — one launch instead of the levels.  nb: multiple of 4 in 4..96, ne: multiple of 4 in 0..64, nc: multiple
+ * of 4 in 4..48, nc <= nb.  Asynchronous on the handle's stream. */
+int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
+                         const int32_t *d_cols, double *d_E, double *d_Z, double *d_Gp, int64_t *d_info, double tiny);
+int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
+                        const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
+                        const double *d_xB, int phase);
+/* HIP source of the solver's kernels for one (nb, ne, nc) and its cache key — for offline builds (no device needed; malloc'ed) */
+int iem_kkt_source(int nb, int ne, int nc, char **out_src, uint64_t *out_key);
 
 /* ---- kernel generation (no device needed) ---------------------------------------
  * The evaluator of a model is specialised HIP source generated from its templates

@@ -1750,31 +1750,38 @@ int iem_comm_status(iem_model *m, int64_t *out_status) {
 
 /* ---- chain KKT solver ------------------------------------------------------------------------------ */
 namespace {
-std::string kkt_source(int nb, int ne) {
+std::string kkt_source(int nb, int ne, int nc) {
   std::string s = "// iem-flags: -O3 -ffp-contract=off -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
-  s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n";
+  s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
   s += kKktSource;
   return s;
 }
-int kkt_module(iem_model *m, int nb, int ne, iem_model::KktMod **out) {
-  if (nb < 4 || nb > 96 || nb % 4 || ne < 0 || ne > 64 || ne % 4 || 16LL * nb * (nb + 1) + 16LL * nb * (ne + 1) + 4096 > 160 * 1024)
-    return fail(IEM_E_ARG, "chain KKT: block size must be a multiple of 4 in 4..96, border size a multiple of 4 in 0..64, two tiles of each within 160 KB of LDS");
-  auto it = m->kkt_mods.find({nb, ne});
+// LDS of kkt_eliminate: the panel buffers of the inverse, and with a border one NB x NB and two NB x NE tiles; of kkt_update:
+// seven NC x NC tiles
+bool kkt_fits(int nb, int ne, int nc) {
+  const long long elim = 8LL * (10 * nb + 8 * (nb + 1)) + (ne > 0 ? 8LL * nb * (nb + 1) + 16LL * nb * (ne + 1) : 0) + 1024;
+  const long long upd = 56LL * nc * (nc + 1) + 1024;
+  return elim <= 160 * 1024 && upd <= 160 * 1024;
+}
+int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
+  if (nb < 4 || nb > 96 || nb % 4 || ne < 0 || ne > 64 || ne % 4 || nc < 4 || nc > 48 || nc % 4 || nc > nb || !kkt_fits(nb, ne, nc))
+    return fail(IEM_E_ARG, "chain KKT: block size must be a multiple of 4 in 4..96, border size a multiple of 4 in 0..64, coupling width a multiple of 4 in 4..48 (and <= the block size), tiles within the LDS of a CU");
+  auto it = m->kkt_mods.find({nb, ne * 64 + nc});
   if (it == m->kkt_mods.end()) {
     iem_model::KktMod km;
-    int rc = load_source(m, kkt_source(nb, ne), &km.mod);
+    int rc = load_source(m, kkt_source(nb, ne, nc), &km.mod);
     if (rc) return rc;
     HIP_TRY(hipModuleGetFunction(&km.elim, km.mod, "kkt_eliminate"));
     HIP_TRY(hipModuleGetFunction(&km.upd, km.mod, "kkt_update"));
     HIP_TRY(hipModuleGetFunction(&km.fwd, km.mod, "kkt_forward"));
     HIP_TRY(hipModuleGetFunction(&km.bwd, km.mod, "kkt_backward"));
-    it = m->kkt_mods.emplace(std::make_pair(nb, ne), km).first;
+    it = m->kkt_mods.emplace(std::make_pair(nb, ne * 64 + nc), km).first;
   }
   *out = &it->second;
   return IEM_OK;
 }
-struct KktArgsH { double *D, *B, *X, *Y, *E, *Z, *Gp; long long *info; long long S, s; int final_block; double tiny; };
-struct KktSolveArgsH { const double *D, *X, *Y, *Z; double *r, *rBp; const double *xB; long long S, s; int final_block; };
+struct KktArgsH { double *D, *Bt, *BR, *E, *Z, *Gp; const int *rows, *cols; long long *info; long long S, s; int final_block; double tiny; };
+struct KktSolveArgsH { const double *D, *Bt, *BR, *Z; const int *rows, *cols; double *r, *z, *rBp; const double *xB; long long S, s; int final_block; };
 int kkt_launch_raw(iem_model *m, hipFunction_t fn, void *args, size_t sz, long long grid, unsigned block) {
   if (grid <= 0) return IEM_OK;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -1785,24 +1792,24 @@ int kkt_launch(iem_model *m, hipFunction_t fn, KktArgsH a, long long grid, unsig
 int kkt_launch_solve(iem_model *m, hipFunction_t fn, KktSolveArgsH a, long long grid, unsigned block) { return kkt_launch_raw(m, fn, &a, sizeof a, grid, block); }
 }  // namespace
 
-int iem_kkt_source(int nb, int ne, char **out_src, uint64_t *out_key) {
-  const std::string s = kkt_source(nb, ne);
+int iem_kkt_source(int nb, int ne, int nc, char **out_src, uint64_t *out_key) {
+  const std::string s = kkt_source(nb, ne, nc);
   if (out_src) { *out_src = (char *)std::malloc(s.size() + 1); std::memcpy(*out_src, s.c_str(), s.size() + 1); }
   if (out_key) *out_key = iem::fnv1a64(s);
   return IEM_OK;
 }
 
-int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, double *d_D, double *d_B, double *d_X, double *d_Y, double *d_E,
-                         double *d_Z, double *d_Gp, int64_t *d_info, double tiny) {
-  const bool chained = d_B != nullptr;   // d_B == NULL: the blocks do not couple to each other (reach 0), only to the border
-  if (!m || S < 1 || !d_D || (chained && (!d_X || !d_Y)) || !d_info || (ne > 0 && (!d_E || !d_Z || !d_Gp))) return fail(IEM_E_ARG, "bad argument");
+int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
+                         const int32_t *d_cols, double *d_E, double *d_Z, double *d_Gp, int64_t *d_info, double tiny) {
+  const bool chained = d_Bt != nullptr;   // d_Bt == NULL: the blocks do not couple to each other (reach 0), only to the border
+  if (!m || S < 1 || !d_D || (chained && (!d_BR || !d_rows || !d_cols)) || !d_info || (ne > 0 && (!d_E || !d_Z || !d_Gp))) return fail(IEM_E_ARG, "bad argument");
   DevGuard dg_(m->device);
   iem_model::KktMod *km = nullptr;
-  int rc = kkt_module(m, nb, ne, &km);
+  int rc = kkt_module(m, nb, ne, nc, &km);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(d_info, 0, 24, m->stream));
-  const unsigned wg = (nb / 4) * (nb / 4) <= 128 ? 128u : 256u;   // KKT_T of csrc/iem_kkt_device.h
-  KktArgsH A{d_D, d_B, d_X, d_Y, d_E, d_Z, d_Gp, (long long *)d_info, (long long)S, 1, 0, tiny};
+  const unsigned wg = 64u * (unsigned)std::min((nb + 15) / 16, 4);   // KKT_T of csrc/iem_kkt_device.h: one wave per 16-row tile row, at most four
+  KktArgsH A{d_D, d_Bt, d_BR, d_E, d_Z, d_Gp, d_rows, d_cols, (long long *)d_info, (long long)S, 1, 0, tiny};
   if (!chained) {   // one launch: every block against the border
     A.final_block = 2;
     return kkt_launch(m, km->elim, A, S, wg);
@@ -1811,21 +1818,22 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, double *d_D, d
     A.s = s;
     const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
     if ((rc = kkt_launch(m, km->elim, A, n_elim, wg)) != IEM_OK) return rc;
-    if ((rc = kkt_launch(m, km->upd, A, n_surv, wg)) != IEM_OK) return rc;
+    if ((rc = kkt_launch(m, km->upd, A, n_surv, 256)) != IEM_OK) return rc;
   }
   A.final_block = 1;
   return kkt_launch(m, km->elim, A, 1, wg);
 }
 
-int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, const double *d_Dinv, const double *d_X, const double *d_Y, const double *d_Z,
-                        double *d_r, double *d_rBp, const double *d_xB, int phase) {
-  const bool chained = d_X != nullptr;   // as in iem_kkt_chain_factor
-  if (!m || S < 1 || !d_Dinv || (chained && !d_Y) || !d_r || (ne > 0 && (!d_Z || (phase == 0 && !d_rBp) || (phase == 1 && !d_xB)))) return fail(IEM_E_ARG, "bad argument");
+int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
+                        const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
+                        const double *d_xB, int phase) {
+  const bool chained = d_Bt != nullptr;   // as in iem_kkt_chain_factor
+  if (!m || S < 1 || !d_Dinv || (chained && (!d_BR || !d_rows || !d_cols || !d_z)) || !d_r || (ne > 0 && (!d_Z || (phase == 0 && !d_rBp) || (phase == 1 && !d_xB)))) return fail(IEM_E_ARG, "bad argument");
   DevGuard dg_(m->device);
   iem_model::KktMod *km = nullptr;
-  int rc = kkt_module(m, nb, ne, &km);
+  int rc = kkt_module(m, nb, ne, nc, &km);
   if (rc) return rc;
-  KktSolveArgsH A{d_Dinv, d_X, d_Y, d_Z, d_r, d_rBp, d_xB, (long long)S, 1, 0};
+  KktSolveArgsH A{d_Dinv, d_Bt, d_BR, d_Z, d_rows, d_cols, d_r, d_z, d_rBp, d_xB, (long long)S, 1, 0};
   if (!chained) {            // independent blocks: the border terms of all blocks (forward), every block's own solve (backward)
     if (phase != 0 && phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
     A.final_block = 2;
@@ -1836,7 +1844,7 @@ int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, const double *d
     for (long long s = 1; s < S; s *= 2) {
       A.s = s;
       const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
-      if ((rc = kkt_launch_solve(m, km->fwd, A, n_surv + (ne > 0 ? n_elim : 0), 64)) != IEM_OK) return rc;
+      if ((rc = kkt_launch_solve(m, km->fwd, A, n_surv + n_elim, 64)) != IEM_OK) return rc;
     }
     A.final_block = 1;
     return ne > 0 ? kkt_launch_solve(m, km->fwd, A, 1, 64) : IEM_OK;

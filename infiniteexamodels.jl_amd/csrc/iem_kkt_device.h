@@ -8,19 +8,28 @@
 //
 //        D_k = K[k, k]  (NB x NB, symmetric)      B_k = K[k, k-1]  (NB x NB)      E_k = K[k, border]  (NB x NE)
 //
-// (kkt_chain.py builds the grouping from the model's slab table and the Jacobian structure, and scatters the KKT values
-// into D | B | E | G every iteration.)  Factorisation = block CYCLIC REDUCTION: at level l (stride s = 2^l) the blocks
-// i = (2t+1) s are eliminated in parallel — kkt_eliminate inverts D_i in LDS (Gauss-Jordan without pivoting, variables
-// first: K is quasi-definite under the interior-point regularisation, so every pivot order is admissible; the signs of
-// the pivots are counted — the inertia an interior-point method asks for) and forms X_i = D_i^-1 B_i,
-// Y_i = D_i^-1 B_{i+s}', Z_i = D_i^-1 E_i; kkt_update folds them into the surviving neighbours j = 2t s:
-//        D_j -= B_j Y_p + B_q' X_q      B_j <- -B_j X_p  (the new coupling j <- j - 2s)      E_j -= B_j Z_p + B_q' Z_q
-// (p = j - s, q = j + s).  ceil(log2 S) levels, two launches each, every block a workgroup; the border's Schur
-// complement G - sum_i E_i' Z_i is accumulated per block (one partial per block, summed once: deterministic).
-// Solve: the same levels forward on the right-hand side (kkt_forward), the border system (tiny, dense), the levels
-// backward (kkt_backward).  FP64 throughout; no atomics on floating-point data.
+// The coupling is NARROW: B_k has entries only on a few rows R of block k (the derivative-approximation rows) and a few
+// columns C of block k - 1 (the differentiated states) — 9 x 9 of 40 x 40 for the quadrotor — and block cyclic reduction
+// PRESERVES that: eliminating a block updates its neighbours on R x R and C x C only, and the new coupling is again an
+// R x C block.  So a block is D_k (NB x NB) plus Bt_k = B_k[R, C] (NC x NC), and the factorisation moves one dense
+// block per support through HBM instead of four (the dense form — D, B, D^-1 B, D^-1 B' — was bound by exactly that
+// traffic: 18 GB per factorisation at 1e5 quadrotor supports, profiles/r03_kkt_chain.json).
 //
-// Compile-time: KKT_NB (block size, multiple of 4, <= 96), KKT_NE (border size, 0 or a multiple of 4, <= 64).
+// (kkt_chain.py builds the grouping from the model's slab table and the Jacobian structure, finds R and C, and scatters the
+// KKT values into D | Bt | E | G every iteration.)  Factorisation = block CYCLIC REDUCTION: at level l (stride s = 2^l) the
+// blocks i = (2t+1) s are eliminated in parallel — kkt_eliminate inverts D_i in place (block Gauss-Jordan on the FP64
+// matrix cores, no pivoting, variables first: K is quasi-definite under the interior-point regularisation, so every pivot
+// order is admissible; the signs of the pivots are counted — the inertia an interior-point method asks for), forms
+// Z_i = D_i^-1 E_i and the block's border term, and keeps BR_i = Bt_{i+s}; kkt_update folds the inverses into the surviving
+// neighbours j = 2t s (p = j - s, q = j + s):
+//        D_j[R,R] -= Bt_j Dp[C,C] Bt_j'     D_j[C,C] -= Bt_q' Dq[R,R] Bt_q     Bt_j <- -Bt_j Dp[C,R] Bt_p  (the coupling j <- j - 2s)
+// ceil(log2 S) levels, two launches each, every block a workgroup; the border's Schur complement G - sum_i E_i' Z_i is
+// accumulated per block (one partial per block, summed once: deterministic).  Solve: the same levels forward on the
+// right-hand side (kkt_forward: z_i = D_i^-1 r_i, survivors take the R / C entries of their neighbours' z), the border
+// system (tiny, dense), the levels backward (kkt_backward).  FP64 throughout; no atomics on floating-point data.
+//
+// Compile-time: KKT_NB (block size, multiple of 4, <= 96), KKT_NE (border size, 0 or a multiple of 4, <= 64), KKT_NC
+// (coupling rows / columns, multiple of 4, <= 48).
 #ifndef IEM_KKT_DEVICE_H
 #define IEM_KKT_DEVICE_H
 
@@ -30,92 +39,99 @@
 #ifndef KKT_NE
 #define KKT_NE 0
 #endif
-#if (KKT_NB / 4) * (KKT_NB / 4) <= 128
-#define KKT_T 128                 // threads per workgroup: one 4 x 4 tile per thread up to NB = 44 ...
-#else
-#define KKT_T 256                 // ... then 256 threads, one to three tiles each
+#ifndef KKT_NC
+#define KKT_NC 12
 #endif
-                                  // (one wave per block — no barriers at all — was measured SLOWER, 73 vs 42 us per block at NB = 40:
-                                  //  the sweep is bound by its FP64 instruction stream, and a lane then owns two tiles)
-#define KKT_LD (KKT_NB + 1)       // LDS row stride of an NB-wide matrix (odd: no bank conflicts down a column)
+#define KKT_LN (KKT_NC + 1)       // LDS row stride of an NC x NC coupling block
+// The dense block work runs on the FP64 matrix cores: v_mfma_f64_16x16x4_f64 (77 TFLOP/s measured on MI355X against 59 for
+// the vector FMA — and a quarter of the operand traffic of a 4 x 4 register tiling, whose LDS reads bound the first form of
+// these kernels: tools/probes/mfma_f64_probe.hip, profiles/r03_kkt_chain.json).  An NB x NB matrix is cut into R x R tiles of
+// 16 x 16 (R = ceil(NB / 16), the rim padded with zeros); wave w of the workgroup owns the tile rows w, w + W, ...
+// (W = min(R, 4) waves).  Within a tile lane l holds, in register r of its accumulator, the element
+//        row = (l >> 4) + 4 r ,  col = l & 15            (the instruction's C/D layout),
+// and feeds A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15] per step of four of the inner dimension.
+#define KKT_R ((KKT_NB + 15) / 16)
+#define KKT_RE ((KKT_NE + 15) / 16)
+#define KKT_W (KKT_R < 4 ? KKT_R : 4)
+#define KKT_T (64 * KKT_W)        // threads per workgroup
+#define KKT_TRW ((KKT_R + KKT_W - 1) / KKT_W)   // tile rows per wave
+#define KKT_LD (KKT_NB + 1)       // LDS row stride of an NB-wide matrix (odd: rows of a fragment fall into different banks)
 #define KKT_LE (KKT_NE + 1)
+typedef double kkt_d4 __attribute__((ext_vector_type(4)));
 
-// ---- register-tiled products ---------------------------------------------------------------------------------------
-// Every NB x NB (NB x NE) result is cut into 4 x 4 tiles INTERLEAVED at stride Q = NB / 4 (QE = NE / 4): tile (tr, tc)
-// holds rows tr + i Q and columns tc + j Q.  A thread owns the tiles tau = tid + n KKT_T (n < NT; one tile for NB <= 64),
-// so that per step of the inner product it reads 4 + 4 values from LDS for 16 fused multiply-adds (the plain
-// one-element-per-thread form reads 2 per multiply-add and is bound by LDS bandwidth: 13.9 ms per factorisation at 1e5
-// quadrotor supports), neighbouring threads read neighbouring columns (no bank conflict) and share the row (broadcast).
-#define KKT_Q (KKT_NB / 4)
-#define KKT_NT ((KKT_Q * KKT_Q + KKT_T - 1) / KKT_T)
-#define KKT_QE (KKT_NE / 4)
-#define KKT_NTE ((KKT_Q * KKT_QE + KKT_T - 1) / KKT_T)
-
-// acc[n][i][j] += sum_k A[(tr + i Q) LD + k] * Bm[k ldb + tc + j QC]      (A: NB x NB in LDS; Bm: NB x (4 QC) in LDS)
-template <int NT, int QC>
-__device__ __forceinline__ void kkt_mm(double (&acc)[NT][4][4], const double *A, const double *Bm, int ldb) {
+// acc[n][tc] += A[rows of tile row w + n W][:] * Bm[:][cols of tile column tc]      (A: NB x NB in LDS, stride lda; Bm: NB x ncols, stride ldb)
+template <int RC>
+__device__ __forceinline__ void kkt_mma(kkt_d4 (&acc)[KKT_TRW][RC], const double *A, int lda, const double *Bm, int ldb, int ncols) {
+  const int l = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, li = l & 15, lk = l >> 4;
+#pragma unroll 2
+  for (int k0 = 0; k0 < KKT_NB; k0 += 4) {
+    double b[RC];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int tau = (int)threadIdx.x + n * KKT_T;
-    if (tau >= KKT_Q * QC) continue;
-    const int tr = tau / QC, tc = tau - tr * QC;
-    const double *a0 = A + tr * KKT_LD, *b0 = Bm + tc;
-#pragma unroll 4
-    for (int k = 0; k < KKT_NB; ++k) {
-      double av[4], bv[4];
+    for (int tc = 0; tc < RC; ++tc) {
+      const int j = 16 * tc + li;
+      b[tc] = j < ncols ? Bm[(k0 + lk) * ldb + j] : 0.0;
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = a0[i * KKT_Q * KKT_LD + k];
+    for (int n = 0; n < KKT_TRW; ++n) {
+      const int tr = w + n * KKT_W;
+      if (tr >= KKT_R) continue;
+      const int i = 16 * tr + li;
+      const double a = i < KKT_NB ? A[i * lda + k0 + lk] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = b0[k * ldb + j * QC];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[n][i][j] += av[i] * bv[j];
+      for (int tc = 0; tc < RC; ++tc) acc[n][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[tc], acc[n][tc], 0, 0, 0);
     }
   }
 }
-template <int NT>
-__device__ __forceinline__ void kkt_zero(double (&acc)[NT][4][4]) {
+template <int RC>
+__device__ __forceinline__ void kkt_zero(kkt_d4 (&acc)[KKT_TRW][RC]) {
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int n = 0; n < KKT_TRW; ++n)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[n][i][j] = 0.0;
+    for (int tc = 0; tc < RC; ++tc) acc[n][tc] = kkt_d4{0.0, 0.0, 0.0, 0.0};
 }
-// G (global, row-major, `cols` = 4 QC wide) = sign * acc      /      G -= acc
-template <int NT, int QC, bool SUBTRACT>
-__device__ __forceinline__ void kkt_put(double *__restrict__ G, const double (&acc)[NT][4][4], double sign) {
+// G (global, row-major, `ncols` wide) = sign * acc      /      G -= acc
+template <int RC, bool SUBTRACT>
+__device__ __forceinline__ void kkt_put(double *__restrict__ G, const kkt_d4 (&acc)[KKT_TRW][RC], double sign, int ncols) {
+  const int l = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, li = l & 15, lk = l >> 4;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int tau = (int)threadIdx.x + n * KKT_T;
-    if (tau >= KKT_Q * QC) continue;
-    const int tr = tau / QC, tc = tau - tr * QC;
+  for (int n = 0; n < KKT_TRW; ++n) {
+    const int tr = w + n * KKT_W;
+    if (tr >= KKT_R) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int tc = 0; tc < RC; ++tc) {
+      const int j = 16 * tc + li;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double *g = G + (long long)(tr + i * KKT_Q) * (4 * QC) + tc + j * QC;
-        if (SUBTRACT) *g -= acc[n][i][j]; else *g = sign * acc[n][i][j];
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * tr + lk + 4 * r;
+        if (i < KKT_NB && j < ncols) {
+          double *g = G + (long long)i * ncols + j;
+          if (SUBTRACT) *g -= acc[n][tc][r]; else *g = sign * acc[n][tc][r];
+        }
       }
+    }
   }
 }
 // the same tiles into LDS (stride ld)
-template <int NT, int QC>
-__device__ __forceinline__ void kkt_put_lds(double *L, int ld, const double (&acc)[NT][4][4]) {
+template <int RC>
+__device__ __forceinline__ void kkt_put_lds(double *L, int ld, const kkt_d4 (&acc)[KKT_TRW][RC], int ncols) {
+  const int l = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, li = l & 15, lk = l >> 4;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int tau = (int)threadIdx.x + n * KKT_T;
-    if (tau >= KKT_Q * QC) continue;
-    const int tr = tau / QC, tc = tau - tr * QC;
+  for (int n = 0; n < KKT_TRW; ++n) {
+    const int tr = w + n * KKT_W;
+    if (tr >= KKT_R) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int tc = 0; tc < RC; ++tc) {
+      const int j = 16 * tc + li;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) L[(tr + i * KKT_Q) * ld + tc + j * QC] = acc[n][i][j];
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * tr + lk + 4 * r;
+        if (i < KKT_NB && j < ncols) L[i * ld + j] = acc[n][tc][r];
+      }
+    }
   }
 }
 // global (row-major, COLS wide) -> LDS (stride ld), optionally transposed.  All of a thread's loads are ISSUED before the
-// first one is consumed (a load -> store loop waits a full HBM round trip per element: 12 round trips per NB = 40 tile).
+// first one is consumed (a load -> store loop waits a full HBM round trip per element).
 template <int ROWS, int COLS>
 __device__ __forceinline__ void kkt_load_t(double *lds, const double *__restrict__ g, int ld, bool transpose) {
   constexpr int N = (ROWS * COLS + KKT_T - 1) / KKT_T;
@@ -135,27 +151,8 @@ __device__ __forceinline__ void kkt_load_t(double *lds, const double *__restrict
   }
 }
 #define kkt_load(lds, g, rows, cols, ld, transpose) kkt_load_t<rows, cols>(lds, g, ld, transpose)
-// the two halves separately, so that a tile needed LATER is already on its way while the current product runs
-#define KKT_NREG ((KKT_NB * KKT_NB + KKT_T - 1) / KKT_T)
-__device__ __forceinline__ void kkt_fetch(double (&tmp)[KKT_NREG], const double *__restrict__ g, bool on) {
-#pragma unroll
-  for (int n = 0; n < KKT_NREG; ++n) {
-    const int e = (int)threadIdx.x + n * KKT_T;
-    tmp[n] = (on && e < KKT_NB * KKT_NB) ? g[e] : 0.0;
-  }
-}
-__device__ __forceinline__ void kkt_stash(double *lds, const double (&tmp)[KKT_NREG], bool transpose) {
-#pragma unroll
-  for (int n = 0; n < KKT_NREG; ++n) {
-    const int e = (int)threadIdx.x + n * KKT_T;
-    if (e < KKT_NB * KKT_NB) {
-      const int r = e / KKT_NB, c = e - r * KKT_NB;
-      if (transpose) lds[c * KKT_LD + r] = tmp[n]; else lds[r * KKT_LD + c] = tmp[n];
-    }
-  }
-}
 // 1 / x: hardware reciprocal + two Newton steps (full double precision for the normal range the pivots live in; the
-// IEEE division sequence is three times as many FP64 instructions on the sweep's critical path)
+// IEEE division sequence is three times as many FP64 instructions on the critical path)
 __device__ __forceinline__ double kkt_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = r + r * (1.0 - x * r);
@@ -164,137 +161,193 @@ __device__ __forceinline__ double kkt_rcp(double x) {
 }
 
 struct KktArgs {
-  double *D, *B, *X, *Y, *E, *Z, *Gp;
+  double *D, *Bt, *BR, *E, *Z, *Gp;
+  const int *rows, *cols;   // KKT_NC each: local rows / columns of the coupling (-1: padding)
   long long *info;          // [0] negative pivots, [1] pivots below the threshold (replaced by +-tiny: the factorisation is not to be trusted)
   long long S, s;           // blocks, stride of this level
   int final_block;          // 1: the last remaining block (index 0), no chain neighbours
   double tiny;              // pivot threshold
 };
 
-// Gauss-Jordan steps k = KA Q .. KA Q + Q - 1 of the in-place inverse of the matrix held tile-wise in registers: pivot row /
-// column k = kq + KA Q sit in slot KA of the tiles with tr == kq / tc == kq — KA is a template parameter, so every register
-// index below is a compile-time constant (with a run-time slot the compiler emits a chain of 64-bit conditional moves per
-// element and the sweep is three times slower).  Per step only the pivot row and column travel through LDS.
-template <int KA>
-__device__ __forceinline__ void kkt_gj_sweep(double (&m)[KKT_NT][4][4], double *rk, double *ck, double tiny, int &neg_, int &bad_) {
-  for (int kq = 0; kq < KKT_Q; ++kq) {
-    const int k = kq + KA * KKT_Q;
+// Panel P (rows / columns 4P .. 4P + 3) of the in-place Gauss-Jordan inverse of the matrix held in the accumulator layout.
+// The four pivot steps of the panel are REGROUPED, not reformulated: with c_i(k) the entry of row i in pivot column k at
+// the time of step k and r_k the normalised pivot row at that time, the scalar algorithm does  M[i, :] -= c_i(k) r_k  for
+// k = 4P .. 4P + 3 — one v_mfma_f64_16x16x4 per tile (k = 4 is the instruction's inner dimension) once the c_i(k) and r_k
+// are known, and they follow from the 4 x 4 pivot block alone: every lane runs its four scalar steps (pivots in the given
+// order: K is quasi-definite, their signs are the inertia), carries them over its own column of the row panel (4 values)
+// and its own row of the column panel (4 values), and feeds the matrix cores.  Forming (pivot block)^-1 explicitly and
+// multiplying with it costs four digits on blocks with -delta_c pivots (1e6 entries next to O(1) ones) — the regrouped form
+// does the scalar algorithm's operations on the scalar algorithm's numbers.
+// The row panel already sits in the B-operand layout of its owner wave (register P % 4 of tile row P / 4), the column
+// panel is transposed through LDS: two buffers alternate, so that one barrier per panel is enough.  P is a template
+// parameter: every register index is a compile-time constant.
+#define KKT_LC 5                  // LDS row stride of the column panel (16 R rows: the rim is read, never used)
+#define KKT_LP (16 * KKT_R + 1)   // ... of the 4-row row panel
+#define KKT_PANEL_DOUBLES (2 * 16 * KKT_R * KKT_LC + 2 * 4 * KKT_LP)
+template <int P>
+__device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double *cpb, double *rpb, double tiny, int &neg_, int &bad_) {
+  constexpr int TS = P / 4, RS = P % 4, C0 = 4 * RS;      // tile row / column of the panel, register slot of its rows, first local column
+  constexpr int WS = TS % KKT_W, NS = TS / KKT_W;         // owner wave and slot of the panel's tile row
+  double *Cp = cpb + (P & 1) * (16 * KKT_R * KKT_LC), *Rp = rpb + (P & 1) * (4 * KKT_LP);
+  const int l = (int)threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), li = l & 15, lk = l >> 4;
+  const bool pcol = li >= C0 && li < C0 + 4;              // this lane holds panel columns (in tile column TS)
+  if (pcol) {
 #pragma unroll
-    for (int n = 0; n < KKT_NT; ++n) {
-      const int tau = (int)threadIdx.x + n * KKT_T;
-      if (tau >= KKT_Q * KKT_Q) continue;
-      const int tr = tau / KKT_Q, tc = tau - tr * KKT_Q;
-      if (tr == kq) {
+    for (int n = 0; n < KKT_TRW; ++n) {
+      const int tr = w + n * KKT_W;
+      if (tr >= KKT_R) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) rk[tc + b * KKT_Q] = m[n][KA][b];
-      }
-      if (tc == kq) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) ck[tr + a * KKT_Q] = m[n][a][KA];
-      }
+      for (int r = 0; r < 4; ++r) Cp[(16 * tr + lk + 4 * r) * KKT_LC + li - C0] = m[n][TS][r];
     }
-    __syncthreads();
-    double piv = rk[k];
+  }
+  if (w == WS) {
+#pragma unroll
+    for (int tc = 0; tc < KKT_R; ++tc) Rp[lk * KKT_LP + 16 * tc + li] = m[NS][tc][RS];
+  }
+  __syncthreads();
+  // the pivot block: four in-place Gauss-Jordan steps; mult[a][k] = the entry (a, k) at the time of step k, inv[k] = 1 / pivot k,
+  // snap[k][b] = the normalised pivot row k at the time of step k (b < k: what the inverse holds there by then; b = k: 1 / pivot;
+  // b > k: the entry the later pivot columns still see)
+  double pv[4][4], mult[4][4], snap[4][4], inv[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pv[a][b] = Rp[a * KKT_LP + 4 * P + b];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double piv = pv[k][k];
     if (threadIdx.x == 0) {
       if (piv < 0.0) ++neg_;
       if (!(fabs(piv) >= tiny)) ++bad_;
     }
     if (!(fabs(piv) >= tiny)) piv = piv < 0.0 ? -tiny : tiny;   // keep going with a bounded pivot; info[1] reports it
-    const double inv = kkt_rcp(piv);
+    inv[k] = kkt_rcp(piv);
 #pragma unroll
-    for (int n = 0; n < KKT_NT; ++n) {
-      const int tau = (int)threadIdx.x + n * KKT_T;
-      if (tau >= KKT_Q * KKT_Q) continue;
-      const int tr = tau / KKT_Q, tc = tau - tr * KKT_Q;
-      double rc[4], ci[4];
+    for (int b = 0; b < 4; ++b) if (b != k) pv[k][b] *= inv[k];
+    pv[k][k] = inv[k];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) ci[a] = ck[tr + a * KKT_Q] * inv;
+    for (int b = 0; b < 4; ++b) snap[k][b] = pv[k][b];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) rc[b] = rk[tc + b * KKT_Q];
-      // every element: the rank-1 step m -= c_r (1/piv) r_c ...
+    for (int a = 0; a < 4; ++a) {
+      if (a == k) { mult[a][k] = 0.0; continue; }
+      const double f = pv[a][k];
+      mult[a][k] = f;
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) m[n][a][b] -= ci[a] * rc[b];
-      // ... then the few threads that own a piece of the pivot row / column put the inverse's entries there
-      if (tr == kq) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) m[n][KA][b] = rc[b] * inv;
-      }
-      if (tc == kq) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) m[n][a][KA] = -ci[a];
-        if (tr == kq) m[n][KA][KA] = inv;
-      }
+      for (int b = 0; b < 4; ++b) if (b != k) pv[a][b] -= f * pv[k][b];
+      pv[a][k] = -f * inv[k];
     }
-    __syncthreads();
+  }
+  // B operand = entry j of the normalised pivot row lk at the time of ITS step: a combination of the row panel's column j
+  // with row lk of `snap` (the steps before it, already folded).  The panel's own columns enter as unit vectors (the
+  // in-place algorithm keeps the inverse where the identity of [A | I] would sit).
+  double sl[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) sl[b] = b > lk ? 0.0 : lk == 0 ? snap[0][b] : lk == 1 ? snap[1][b] : lk == 2 ? snap[2][b] : snap[3][b];
+  double bop[KKT_R], vin[KKT_R][4];
+#pragma unroll
+  for (int tc = 0; tc < KKT_R; ++tc) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) vin[tc][a] = Rp[a * KKT_LP + 16 * tc + li];
+    if (tc == TS) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vin[tc][a] = pcol ? (li - C0 == a ? 1.0 : 0.0) : vin[tc][a];
+    }
+    bop[tc] = sl[0] * vin[tc][0] + sl[1] * vin[tc][1] + sl[2] * vin[tc][2] + sl[3] * vin[tc][3];
+  }
+  // the panel's own columns restart from zero; its rows (owner wave) become the finished row panel: the four steps carried
+  // over each column, one after the other as the scalar algorithm does
+  if (pcol) {
+#pragma unroll
+    for (int n = 0; n < KKT_TRW; ++n) m[n][TS] = kkt_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  if (w == WS) {
+#pragma unroll
+    for (int tc = 0; tc < KKT_R; ++tc) {
+      double v[4] = {vin[tc][0], vin[tc][1], vin[tc][2], vin[tc][3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] *= inv[k];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) if (a != k) v[a] -= mult[a][k] * v[k];
+      }
+      m[NS][tc][RS] = lk == 0 ? v[0] : lk == 1 ? v[1] : lk == 2 ? v[2] : v[3];
+    }
+  }
+  // every other row i: its entries c_i(k) in the pivot columns at the time of step k, then M[i, :] -= sum_k c_i(k) r_k
+#pragma unroll
+  for (int n = 0; n < KKT_TRW; ++n) {
+    const int tr = w + n * KKT_W;
+    if (tr >= KKT_R) continue;
+    const int i = 16 * tr + li;
+    double c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = Cp[i * KKT_LC + k];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int mm = 0; mm < k; ++mm) c[k] -= c[mm] * snap[mm][k];
+    double a = -(lk == 0 ? c[0] : lk == 1 ? c[1] : lk == 2 ? c[2] : c[3]);
+    if (i >= 4 * P && i < 4 * P + 4) a = 0.0;
+#pragma unroll
+    for (int tc = 0; tc < KKT_R; ++tc) m[n][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[tc], m[n][tc], 0, 0, 0);
+  }
+}
+template <int P>
+__device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *cpb, double *rpb, double tiny, int &neg_, int &bad_) {
+  if constexpr (P < KKT_NB / 4) {
+    kkt_gj_panel<P>(m, cpb, rpb, tiny, neg_, bad_);
+    kkt_gj_all<P + 1>(m, cpb, rpb, tiny, neg_, bad_);
   }
 }
 
 // ---- level l, step 1: eliminate the blocks i = (2 t + 1) s --------------------------------------------------
 extern "C" __global__ __launch_bounds__(KKT_T) void kkt_eliminate(const KktArgs A) {
-  __shared__ double M[KKT_NB * KKT_LD], T[KKT_NB * KKT_LD], rk[KKT_NB], ck[KKT_NB];
+  __shared__ double panels[KKT_PANEL_DOUBLES];
+  double *cpb = panels, *rpb = panels + 2 * 16 * KKT_R * KKT_LC;
   __shared__ int neg_, bad_;
   // final_block: 0 = level of the chain; 1 = the last remaining block (index 0); 2 = NO chain coupling at all (scenario
   // blocks of a two-stage problem): every block is eliminated in this one launch, against the border only
   const long long i = A.final_block == 2 ? (long long)blockIdx.x : A.final_block ? 0 : (2 * (long long)blockIdx.x + 1) * A.s;
   if (i >= A.S) return;
-  const bool has_left = !A.final_block, has_right = !A.final_block && i + A.s < A.S;
+  const bool has_right = !A.final_block && i + A.s < A.S;
   double *Di = A.D + i * KKT_NB * KKT_NB;
-  // D_i in REGISTERS, tile-wise; in-place inverse by Gauss-Jordan with the pivots on the diagonal in the given order
-  // (variables first).  Per step only the pivot row and column travel through LDS (2 NB values), every thread updates
-  // the 16 elements it owns.
-  double m[KKT_NT][4][4];
+  const int l = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, li = l & 15, lk = l >> 4;
+  // D_i in the accumulator layout (rim tiles padded with zeros: the padding never mixes with the matrix — its operand
+  // rows and columns are zero in every update)
+  kkt_d4 m[KKT_TRW][KKT_R];
 #pragma unroll
-  for (int n = 0; n < KKT_NT; ++n) {
-    const int tau = (int)threadIdx.x + n * KKT_T;
-    const int tr = tau / KKT_Q, tc = tau - tr * KKT_Q;
+  for (int n = 0; n < KKT_TRW; ++n) {
+    const int tr = w + n * KKT_W;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int tc = 0; tc < KKT_R; ++tc)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) m[n][a][b] = tau < KKT_Q * KKT_Q ? Di[(long long)(tr + a * KKT_Q) * KKT_NB + tc + b * KKT_Q] : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * tr + lk + 4 * r, jj = 16 * tc + li;
+        m[n][tc][r] = (tr < KKT_R && ii < KKT_NB && jj < KKT_NB) ? Di[(long long)ii * KKT_NB + jj] : 0.0;
+      }
   }
   if (threadIdx.x == 0) { neg_ = 0; bad_ = 0; }
-  double pl[KKT_NREG], pr[KKT_NREG];       // B_i and B_{i+s}: on their way while the sweep runs
-  kkt_fetch(pl, A.B + i * KKT_NB * KKT_NB, has_left);
-  kkt_fetch(pr, A.B + (i + A.s) * KKT_NB * KKT_NB, has_right);
-  kkt_gj_sweep<0>(m, rk, ck, A.tiny, neg_, bad_);
-  kkt_gj_sweep<1>(m, rk, ck, A.tiny, neg_, bad_);
-  kkt_gj_sweep<2>(m, rk, ck, A.tiny, neg_, bad_);
-  kkt_gj_sweep<3>(m, rk, ck, A.tiny, neg_, bad_);
+  // the coupling of i + s to i leaves the chain with i: kept for the solves (the update overwrites Bt[i + s] with the
+  // coupling of the next level)
+  if (has_right)
+    for (int e = (int)threadIdx.x; e < KKT_NC * KKT_NC; e += KKT_T) A.BR[i * KKT_NC * KKT_NC + e] = A.Bt[(i + A.s) * KKT_NC * KKT_NC + e];
+  kkt_gj_all<0>(m, cpb, rpb, A.tiny, neg_, bad_);
   if (threadIdx.x == 0) {
     if (neg_) atomicAdd((unsigned long long *)A.info, (unsigned long long)neg_);
     if (bad_) atomicAdd((unsigned long long *)(A.info + 1), (unsigned long long)bad_);
   }
-  kkt_put<KKT_NT, KKT_Q, false>(Di, m, 1.0);          // D_i^-1 stays for the solves
-  kkt_put_lds<KKT_NT, KKT_Q>(M, KKT_LD, m);           // ... and is the left operand of the products below
-  if (has_left) {        // X_i = D_i^-1 B_i
-    kkt_stash(T, pl, false);
-    __syncthreads();
-    kkt_zero(m);
-    kkt_mm<KKT_NT, KKT_Q>(m, M, T, KKT_LD);
-    kkt_put<KKT_NT, KKT_Q, false>(A.X + i * KKT_NB * KKT_NB, m, 1.0);
-    __syncthreads();
-  }
-  if (has_right) {       // Y_i = D_i^-1 B_{i+s}'
-    kkt_stash(T, pr, true);
-    __syncthreads();
-    kkt_zero(m);
-    kkt_mm<KKT_NT, KKT_Q>(m, M, T, KKT_LD);
-    kkt_put<KKT_NT, KKT_Q, false>(A.Y + i * KKT_NB * KKT_NB, m, 1.0);
-    __syncthreads();
-  }
+  kkt_put<KKT_R, false>(Di, m, 1.0, KKT_NB);          // D_i^-1: all the chain ever needs of block i
 #if KKT_NE > 0
   {                      // Z_i = D_i^-1 E_i,  Gp_i = E_i' Z_i
-    __shared__ double EE[KKT_NB * KKT_LE], ZZ[KKT_NB * KKT_LE];
-    if (!has_left && !has_right) __syncthreads();     // M complete before it is read
+    __shared__ double M[KKT_NB * KKT_LD], EE[KKT_NB * KKT_LE], ZZ[KKT_NB * KKT_LE];
+    kkt_put_lds<KKT_R>(M, KKT_LD, m, KKT_NB);
     kkt_load(EE, A.E + i * KKT_NB * KKT_NE, KKT_NB, KKT_NE, KKT_LE, false);
     __syncthreads();
-    double z[KKT_NTE][4][4];
+    kkt_d4 z[KKT_TRW][KKT_RE];
     kkt_zero(z);
-    kkt_mm<KKT_NTE, KKT_QE>(z, M, EE, KKT_LE);
-    kkt_put<KKT_NTE, KKT_QE, false>(A.Z + i * KKT_NB * KKT_NE, z, 1.0);
-    kkt_put_lds<KKT_NTE, KKT_QE>(ZZ, KKT_LE, z);
+    kkt_mma<KKT_RE>(z, M, KKT_LD, EE, KKT_LE, KKT_NE);
+    kkt_put<KKT_RE, false>(A.Z + i * KKT_NB * KKT_NE, z, 1.0, KKT_NE);
+    kkt_put_lds<KKT_RE>(ZZ, KKT_LE, z, KKT_NE);
     __syncthreads();
     for (int e = (int)threadIdx.x; e < KKT_NE * KKT_NE; e += KKT_T) {
       const int r = e / KKT_NE, c = e - r * KKT_NE;
@@ -306,163 +359,229 @@ extern "C" __global__ __launch_bounds__(KKT_T) void kkt_eliminate(const KktArgs 
 #endif
 }
 
-// ---- level l, step 2: fold the eliminated neighbours into the survivors j = 2 t s ---------------------------------
-extern "C" __global__ __launch_bounds__(KKT_T) void kkt_update(const KktArgs A) {
-  __shared__ double T1[KKT_NB * KKT_LD], T2[KKT_NB * KKT_LD];
+// ---- level l, step 2: fold the eliminated neighbours p = j - s, q = j + s into the survivors j = 2 t s ----------------------
+// B_j = K[j, p] lives on the rows R of block j and the columns C of block p (KKT_NC x KKT_NC values, Bt[j]); with Dp, Dq the
+// inverses kkt_eliminate just wrote:
+//        D_j[R, R] -= Bt_j Dp[C, C] Bt_j'        D_j[C, C] -= Bt_q' Dq[R, R] Bt_q        Bt_j <- -Bt_j Dp[C, R] Bt_p
+//        E_j[R, :] -= Bt_j Z_p[C, :]             E_j[C, :] -= Bt_q' Z_q[R, :]
+// A handful of KKT_NC^3 products on gathered sub-blocks: 64 .. 256 threads, everything through LDS.
+#define KKT_TU 256
+extern "C" __global__ __launch_bounds__(KKT_TU) void kkt_update(const KktArgs A) {
+  __shared__ double Bj[KKT_NC * KKT_LN], Bo[KKT_NC * KKT_LN], G1[KKT_NC * KKT_LN], G2[KKT_NC * KKT_LN], T1[KKT_NC * KKT_LN], T2[KKT_NC * KKT_LN],
+      BN[KKT_NC * KKT_LN];
+  __shared__ int rr[KKT_NC], cc[KKT_NC];
   const long long j = 2 * (long long)blockIdx.x * A.s;
   if (j >= A.S) return;
   const long long p = j - A.s, q = j + A.s;
   const bool hp = j > 0, hq = q < A.S;
   if (!hp && !hq) return;
-  double u[KKT_NT][4][4];
-  kkt_zero(u);
-#if KKT_NE > 0
-  __shared__ double ZZ[KKT_NB * KKT_LE];
-  double ue[KKT_NTE][4][4];
-  kkt_zero(ue);
-#endif
-  double ra[KKT_NREG], rb[KKT_NREG], rc[KKT_NREG];
-  kkt_fetch(ra, A.B + j * KKT_NB * KKT_NB, hp);        // B_j = K[j, p]
-  kkt_fetch(rb, A.Y + p * KKT_NB * KKT_NB, hp);        // Y_p = D_p^-1 B_j'
-  kkt_fetch(rc, A.X + p * KKT_NB * KKT_NB, hp);        // X_p = D_p^-1 B_p
+  const int t = (int)threadIdx.x;
+  constexpr int NN = KKT_NC * KKT_NC;
+  for (int e = t; e < KKT_NC; e += KKT_TU) { rr[e] = A.rows[e]; cc[e] = A.cols[e]; }
+  __syncthreads();
+  double *Dj = A.D + j * KKT_NB * KKT_NB;
   if (hp) {
-    kkt_stash(T1, ra, false);
-    kkt_stash(T2, rb, false);
-#if KKT_NE > 0
-    kkt_load(ZZ, A.Z + p * KKT_NB * KKT_NE, KKT_NB, KKT_NE, KKT_LE, false);
-#endif
-    __syncthreads();
-  }
-  kkt_fetch(ra, A.B + q * KKT_NB * KKT_NB, hq);        // B_q' = K[j, q]   — in flight during the products below
-  kkt_fetch(rb, A.X + q * KKT_NB * KKT_NB, hq);        // X_q = D_q^-1 B_q
-  if (hp) {
-    kkt_mm<KKT_NT, KKT_Q>(u, T1, T2, KKT_LD);
-#if KKT_NE > 0
-    kkt_mm<KKT_NTE, KKT_QE>(ue, T1, ZZ, KKT_LE);
-#endif
-    __syncthreads();
-    kkt_stash(T2, rc, false);
-    __syncthreads();
-    {   // the new coupling of j to j - 2s (p's other neighbour; p - s >= 0 always)
-      double w[KKT_NT][4][4];
-      kkt_zero(w);
-      kkt_mm<KKT_NT, KKT_Q>(w, T1, T2, KKT_LD);
-      kkt_put<KKT_NT, KKT_Q, false>(A.B + j * KKT_NB * KKT_NB, w, -1.0);
+    const double *Dp = A.D + p * KKT_NB * KKT_NB;
+    for (int e = t; e < NN; e += KKT_TU) {
+      const int a = e / KKT_NC, b = e - a * KKT_NC;
+      Bj[a * KKT_LN + b] = A.Bt[j * NN + e];
+      Bo[a * KKT_LN + b] = A.Bt[p * NN + e];
+      const bool on = cc[a] >= 0;
+      G1[a * KKT_LN + b] = (on && cc[b] >= 0) ? Dp[cc[a] * KKT_NB + cc[b]] : 0.0;
+      G2[a * KKT_LN + b] = (on && rr[b] >= 0) ? Dp[cc[a] * KKT_NB + rr[b]] : 0.0;
     }
     __syncthreads();
+    for (int e = t; e < NN; e += KKT_TU) {
+      const int a = e / KKT_NC, b = e - a * KKT_NC;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < KKT_NC; ++k) { s1 += Bj[a * KKT_LN + k] * G1[k * KKT_LN + b]; s2 += Bj[a * KKT_LN + k] * G2[k * KKT_LN + b]; }
+      T1[a * KKT_LN + b] = s1; T2[a * KKT_LN + b] = s2;
+    }
+    __syncthreads();
+    for (int e = t; e < NN; e += KKT_TU) {
+      const int a = e / KKT_NC, b = e - a * KKT_NC;
+      double u = 0.0, bn = 0.0;
+      for (int k = 0; k < KKT_NC; ++k) { u += T1[a * KKT_LN + k] * Bj[b * KKT_LN + k]; bn += T2[a * KKT_LN + k] * Bo[k * KKT_LN + b]; }
+      if (rr[a] >= 0 && rr[b] >= 0) Dj[rr[a] * KKT_NB + rr[b]] -= u;
+      BN[a * KKT_LN + b] = -bn;
+    }
+#if KKT_NE > 0
+    for (int e = t; e < KKT_NC * KKT_NE; e += KKT_TU) {
+      const int a = e / KKT_NE, c = e - a * KKT_NE;
+      if (rr[a] < 0) continue;
+      double u = 0.0;
+      for (int k = 0; k < KKT_NC; ++k) if (cc[k] >= 0) u += Bj[a * KKT_LN + k] * A.Z[(p * KKT_NB + cc[k]) * KKT_NE + c];
+      A.E[(j * KKT_NB + rr[a]) * KKT_NE + c] -= u;
+    }
+#endif
+    __threadfence_block();
+    __syncthreads();       // (R and C may share an entry of D_j: the two halves touch it one after the other)
   }
   if (hq) {
-    kkt_stash(T1, ra, true);
-    kkt_stash(T2, rb, false);
-#if KKT_NE > 0
-    kkt_load(ZZ, A.Z + q * KKT_NB * KKT_NE, KKT_NB, KKT_NE, KKT_LE, false);
-#endif
+    const double *Dq = A.D + q * KKT_NB * KKT_NB;
+    for (int e = t; e < NN; e += KKT_TU) {
+      const int a = e / KKT_NC, b = e - a * KKT_NC;
+      Bo[a * KKT_LN + b] = A.Bt[q * NN + e];
+      G1[a * KKT_LN + b] = (rr[a] >= 0 && rr[b] >= 0) ? Dq[rr[a] * KKT_NB + rr[b]] : 0.0;
+    }
     __syncthreads();
-    kkt_mm<KKT_NT, KKT_Q>(u, T1, T2, KKT_LD);
+    for (int e = t; e < NN; e += KKT_TU) {
+      const int a = e / KKT_NC, b = e - a * KKT_NC;
+      double s1 = 0.0;
+      for (int k = 0; k < KKT_NC; ++k) s1 += Bo[k * KKT_LN + a] * G1[k * KKT_LN + b];
+      T1[a * KKT_LN + b] = s1;
+    }
+    __syncthreads();
+    for (int e = t; e < NN; e += KKT_TU) {
+      const int a = e / KKT_NC, b = e - a * KKT_NC;
+      double u = 0.0;
+      for (int k = 0; k < KKT_NC; ++k) u += T1[a * KKT_LN + k] * Bo[k * KKT_LN + b];
+      if (cc[a] >= 0 && cc[b] >= 0) Dj[cc[a] * KKT_NB + cc[b]] -= u;
+    }
 #if KKT_NE > 0
-    kkt_mm<KKT_NTE, KKT_QE>(ue, T1, ZZ, KKT_LE);
+    for (int e = t; e < KKT_NC * KKT_NE; e += KKT_TU) {
+      const int a = e / KKT_NE, c = e - a * KKT_NE;
+      if (cc[a] < 0) continue;
+      double u = 0.0;
+      for (int k = 0; k < KKT_NC; ++k) if (rr[k] >= 0) u += Bo[k * KKT_LN + a] * A.Z[(q * KKT_NB + rr[k]) * KKT_NE + c];
+      A.E[(j * KKT_NB + cc[a]) * KKT_NE + c] -= u;
+    }
 #endif
   }
-  kkt_put<KKT_NT, KKT_Q, true>(A.D + j * KKT_NB * KKT_NB, u, 1.0);
-#if KKT_NE > 0
-  kkt_put<KKT_NTE, KKT_QE, true>(A.E + j * KKT_NB * KKT_NE, ue, 1.0);
-#endif
+  if (hp)
+    for (int e = t; e < NN; e += KKT_TU) { const int a = e / KKT_NC, b = e - a * KKT_NC; A.Bt[j * NN + e] = BN[a * KKT_LN + b]; }
 }
 
 // ---- solves --------------------------------------------------------------------------------------------------------
 struct KktSolveArgs {
-  const double *D, *X, *Y, *Z;   // D holds the inverses
+  const double *D, *Bt, *BR, *Z;   // D holds the inverses; Bt[i] / BR[i]: the couplings of an eliminated block i to i - s / of i + s to i
+  const int *rows, *cols;
   double *r;                     // S x NB: right-hand side in, solution out
+  double *z;                     // S x NB: D_i^-1 r_i of the eliminated blocks (forward -> backward)
   double *rBp;                   // S x NE: per block  Z_i' r_i  (forward);  unused backward
   const double *xB;              // NE: the border's solution (backward)
   long long S, s;
   int final_block;
 };
-// y[c] (+)= sum_k M[k][c] * v[k]   (M row-major NB x cols: coalesced down the rows)
+// y[c] = sum_k M[k][c] * v[k]   (M row-major NB x cols: coalesced down the rows)
 __device__ __forceinline__ double kkt_tdot(const double *__restrict__ M, const double *v, int cols, int c) {
   double acc = 0.0;
   for (int k = 0; k < KKT_NB; ++k) acc += M[(long long)k * cols + c] * v[k];
   return acc;
 }
-// forward, level l: survivors  r_j -= Y_p' r_p + X_q' r_q ;  eliminated  rBp_i = Z_i' r_i   (64 threads per block of unknowns)
+// forward, level l:   eliminated  z_i = D_i^-1 r_i,  rBp_i = Z_i' r_i ;
+//                     survivors   r_j[R] -= BR_p (D_p^-1 r_p)[C] ,  r_j[C] -= Bt_q' (D_q^-1 r_q)[R]      (64 threads per block)
 extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs A) {
-  __shared__ double v[KKT_NB];
+  __shared__ double v[KKT_NB], zc[KKT_NC], zr[KKT_NC];
+  __shared__ int rr[KKT_NC], cc[KKT_NC];
   const long long n_surv = A.final_block ? 0 : (A.S + 2 * A.s - 1) / (2 * A.s);   // (final_block 1 / 2: only the border terms below)
   const int t = (int)threadIdx.x;
+  constexpr int NN = KKT_NC * KKT_NC;
   if ((long long)blockIdx.x < n_surv) {
     const long long j = 2 * (long long)blockIdx.x * A.s, p = j - A.s, q = j + A.s;
-    double acc = 0.0;
+    for (int e = t; e < KKT_NC; e += 64) { rr[e] = A.rows[e]; cc[e] = A.cols[e]; zc[e] = 0.0; zr[e] = 0.0; }
     if (j > 0) {
       for (int e = t; e < KKT_NB; e += 64) v[e] = A.r[p * KKT_NB + e];
       __syncthreads();
-      for (int c = t; c < KKT_NB; c += 64) acc += kkt_tdot(A.Y + p * KKT_NB * KKT_NB, v, KKT_NB, c);
+      // row cc[a] of the (symmetric) inverse: four lanes per row, 16 rows per pass
+      for (int a0 = 0; a0 < KKT_NC; a0 += 16) {
+        const int a = a0 + (t >> 2);
+        double acc = 0.0;
+        if (a < KKT_NC && cc[a] >= 0) { const double *row = A.D + (p * KKT_NB + cc[a]) * KKT_NB; for (int k = t & 3; k < KKT_NB; k += 4) acc += row[k] * v[k]; }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+        if (a < KKT_NC && (t & 3) == 0) zc[a] = acc;
+      }
       __syncthreads();
     }
     if (q < A.S) {
       for (int e = t; e < KKT_NB; e += 64) v[e] = A.r[q * KKT_NB + e];
       __syncthreads();
-      for (int c = t; c < KKT_NB; c += 64) acc += kkt_tdot(A.X + q * KKT_NB * KKT_NB, v, KKT_NB, c);
+      for (int a0 = 0; a0 < KKT_NC; a0 += 16) {
+        const int a = a0 + (t >> 2);
+        double acc = 0.0;
+        if (a < KKT_NC && rr[a] >= 0) { const double *row = A.D + (q * KKT_NB + rr[a]) * KKT_NB; for (int k = t & 3; k < KKT_NB; k += 4) acc += row[k] * v[k]; }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+        if (a < KKT_NC && (t & 3) == 0) zr[a] = acc;
+      }
     }
-    // (NB <= 64 is NOT assumed: each thread owns the columns c = t, t + 64, ... — but acc sums them; handle > 64 separately)
-#if KKT_NB <= 64
-    if (t < KKT_NB) A.r[j * KKT_NB + t] -= acc;
-#else
-    // one column per pass
-    (void)acc;
-    for (int c = t; c < KKT_NB; c += 64) {
-      double a2 = 0.0;
-      if (j > 0) { for (int k = 0; k < KKT_NB; ++k) a2 += A.Y[(p * KKT_NB + k) * KKT_NB + c] * A.r[p * KKT_NB + k]; }
-      if (q < A.S) { for (int k = 0; k < KKT_NB; ++k) a2 += A.X[(q * KKT_NB + k) * KKT_NB + c] * A.r[q * KKT_NB + k]; }
-      A.r[j * KKT_NB + c] -= a2;
-    }
-#endif
+    __syncthreads();
+    if (j > 0)
+      for (int a = t; a < KKT_NC; a += 64) {
+        if (rr[a] < 0) continue;
+        double acc = 0.0;
+        for (int c = 0; c < KKT_NC; ++c) acc += A.BR[p * NN + a * KKT_NC + c] * zc[c];
+        A.r[j * KKT_NB + rr[a]] -= acc;
+      }
+    __threadfence_block();
+    __syncthreads();
+    if (q < A.S)
+      for (int a = t; a < KKT_NC; a += 64) {
+        if (cc[a] < 0) continue;
+        double acc = 0.0;
+        for (int k = 0; k < KKT_NC; ++k) acc += A.Bt[q * NN + k * KKT_NC + a] * zr[k];
+        A.r[j * KKT_NB + cc[a]] -= acc;
+      }
     return;
   }
-#if KKT_NE > 0
   const long long e_idx = (long long)blockIdx.x - n_surv;
   const long long i = A.final_block == 2 ? e_idx : A.final_block ? 0 : (2 * e_idx + 1) * A.s;
   if (i >= A.S) return;
   for (int e = t; e < KKT_NB; e += 64) v[e] = A.r[i * KKT_NB + e];
   __syncthreads();
+  if (!A.final_block)
+    for (int c = t; c < KKT_NB; c += 64) A.z[i * KKT_NB + c] = kkt_tdot(A.D + i * KKT_NB * KKT_NB, v, KKT_NB, c);
+#if KKT_NE > 0
   for (int c = t; c < KKT_NE; c += 64) A.rBp[i * KKT_NE + c] = kkt_tdot(A.Z + i * KKT_NB * KKT_NE, v, KKT_NE, c);
 #endif
 }
-// backward, level l: eliminated  x_i = D_i^-1 r_i - X_i x_p - Y_i x_q - Z_i x_B
+// backward, level l: eliminated  x_i = z_i - D_i^-1[:, R] (Bt_i x_p[C]) - D_i^-1[:, C] (BR_i' x_q[R]) - Z_i x_B
 extern "C" __global__ __launch_bounds__(64) void kkt_backward(const KktSolveArgs A) {
-  __shared__ double ri[KKT_NB], xp[KKT_NB], xq[KKT_NB], xb[KKT_NE > 0 ? KKT_NE : 1];
+  __shared__ double ri[KKT_NB], xc[KKT_NC], xr[KKT_NC], t1[KKT_NC], t2[KKT_NC], xb[KKT_NE > 0 ? KKT_NE : 1];
+  __shared__ int rr[KKT_NC], cc[KKT_NC];
   const long long i = A.final_block == 2 ? (long long)blockIdx.x : A.final_block ? 0 : (2 * (long long)blockIdx.x + 1) * A.s;
   if (i >= A.S) return;
   const int t = (int)threadIdx.x;
+  constexpr int NN = KKT_NC * KKT_NC;
   const bool hp = !A.final_block, hq = !A.final_block && i + A.s < A.S;
-  for (int e = t; e < KKT_NB; e += 64) {
-    ri[e] = A.r[i * KKT_NB + e];
-    xp[e] = hp ? A.r[(i - A.s) * KKT_NB + e] : 0.0;
-    xq[e] = hq ? A.r[(i + A.s) * KKT_NB + e] : 0.0;
+  for (int e = t; e < KKT_NC; e += 64) {      // (no coupling tables without a chain: final_block 1 / 2 never read them)
+    const int re = hp ? A.rows[e] : -1, ce = hp ? A.cols[e] : -1;
+    rr[e] = re; cc[e] = ce;
+    xc[e] = (hp && ce >= 0) ? A.r[(i - A.s) * KKT_NB + ce] : 0.0;
+    xr[e] = (hq && re >= 0) ? A.r[(i + A.s) * KKT_NB + re] : 0.0;
   }
+  if (A.final_block) for (int e = t; e < KKT_NB; e += 64) ri[e] = A.r[i * KKT_NB + e];
 #if KKT_NE > 0
   for (int e = t; e < KKT_NE; e += 64) xb[e] = A.xB[e];
 #endif
   __syncthreads();
+  for (int a = t; a < KKT_NC; a += 64) {
+    double s1 = 0.0, s2 = 0.0;
+    if (hp) for (int c = 0; c < KKT_NC; ++c) s1 += A.Bt[i * NN + a * KKT_NC + c] * xc[c];
+    if (hq) for (int k = 0; k < KKT_NC; ++k) s2 += A.BR[i * NN + k * KKT_NC + a] * xr[k];
+    t1[a] = s1; t2[a] = s2;
+  }
+  __syncthreads();
+  const double *Di = A.D + i * KKT_NB * KKT_NB;
   constexpr int NOUT = (KKT_NB + 63) / 64;
   double out[NOUT];
 #pragma unroll
   for (int n = 0; n < NOUT; ++n) {
-    const int r = t + 64 * n;
+    const int c = t + 64 * n;
     out[n] = 0.0;
-    if (r >= KKT_NB) continue;
-    // D^-1 is symmetric: walk its column r (coalesced); X, Y, Z rows are read strided (NB x NB is small, L2-resident)
-    double acc = kkt_tdot(A.D + i * KKT_NB * KKT_NB, ri, KKT_NB, r);
-    if (hp) { const double *Xr = A.X + (i * KKT_NB + r) * KKT_NB; for (int c = 0; c < KKT_NB; ++c) acc -= Xr[c] * xp[c]; }
-    if (hq) { const double *Yr = A.Y + (i * KKT_NB + r) * KKT_NB; for (int c = 0; c < KKT_NB; ++c) acc -= Yr[c] * xq[c]; }
+    if (c >= KKT_NB) continue;
+    // D^-1 is symmetric: its rows rr[a] / cc[a] are the columns the formula asks for (coalesced over c)
+    double acc = A.final_block ? kkt_tdot(Di, ri, KKT_NB, c) : A.z[i * KKT_NB + c];
+    if (hp) for (int a = 0; a < KKT_NC; ++a) if (rr[a] >= 0) acc -= Di[rr[a] * KKT_NB + c] * t1[a];
+    if (hq) for (int a = 0; a < KKT_NC; ++a) if (cc[a] >= 0) acc -= Di[cc[a] * KKT_NB + c] * t2[a];
 #if KKT_NE > 0
-    { const double *Zr = A.Z + (i * KKT_NB + r) * KKT_NE; for (int c = 0; c < KKT_NE; ++c) acc -= Zr[c] * xb[c]; }
+    { const double *Zr = A.Z + (i * KKT_NB + c) * KKT_NE; for (int e = 0; e < KKT_NE; ++e) acc -= Zr[e] * xb[e]; }
 #endif
     out[n] = acc;
   }
 #pragma unroll
   for (int n = 0; n < NOUT; ++n) {
-    const int r = t + 64 * n;
-    if (r < KKT_NB) A.r[i * KKT_NB + r] = out[n];   // block i's own entries: nobody else reads or writes them at this level
+    const int c = t + 64 * n;
+    if (c < KKT_NB) A.r[i * KKT_NB + c] = out[n];   // block i's own entries: nobody else reads or writes them at this level
   }
 }
 

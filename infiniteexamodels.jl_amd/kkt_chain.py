@@ -13,10 +13,11 @@ MadNLPGPU + CUDSS (``/root/reference/README.md:36-37``).  ROCm 7.2 has no CUDSS;
   a small dense border.
 
 :class:`ChainLayout` derives that grouping from the model's slab table (``core.slabs``) and the Jacobian structure — no
-model-specific code — and :class:`ChainKKT` keeps the dense blocks ``D | B | E | G`` on the device, fills them from the
+model-specific code — and :class:`ChainKKT` keeps the blocks ``D | Bt | E | G`` on the device, fills them from the
 CSR values ``kkt.KKTSystem.assemble`` produces (one ``index_copy_``), and calls the hand-written kernels behind
-``iem_kkt_chain_factor / iem_kkt_chain_solve`` (``csrc/iem_kkt_device.h``: Gauss-Jordan inverses of the pivot blocks in
-LDS, ⌈log₂ S⌉ levels of block cyclic reduction, per-block border Schur terms, pivot signs counted for the inertia).
+``iem_kkt_chain_factor / iem_kkt_chain_solve`` (``csrc/iem_kkt_device.h``: block Gauss-Jordan inverses of the pivot blocks
+on the FP64 matrix cores, ⌈log₂ S⌉ levels of block cyclic reduction over NARROW couplings — only the rows / columns the
+stencil touches —, per-block border Schur terms, pivot signs counted for the inertia).
 Two-dimensional models whose blocks would be too large (pandemic at 100 scenarios: 1 701 unknowns per time support) are
 refused with a clear message — :class:`kkt.KKTSystem` remains the general path.
 """
@@ -29,12 +30,14 @@ import numpy as np
 
 from . import lib as _lib
 
-MAX_NB, MAX_NE = 96, 64
+MAX_NB, MAX_NE, MAX_NC = 96, 64, 48
 
 
-def fits_lds(nb: int, ne: int) -> bool:
-    """two nb x nb tiles + two nb x ne tiles of doubles (odd row strides) in the 160 KB of a CU (csrc/iem_kkt_device.h)"""
-    return 16 * nb * (nb + 1) + 16 * nb * (ne + 1) + 4096 <= 160 * 1024
+def fits_lds(nb: int, ne: int, nc: int = 4) -> bool:
+    """LDS of the kernels (csrc/iem_kkt_device.h): the panel buffers of the inverse and, with a border, one nb x nb and two
+    nb x ne tiles of doubles (odd row strides); seven nc x nc tiles — each kernel within the 160 KB of a CU."""
+    elim = 8 * (10 * nb + 8 * (nb + 1)) + (8 * nb * (nb + 1) + 16 * nb * (ne + 1) if ne else 0) + 1024
+    return elim <= 160 * 1024 and 56 * nc * (nc + 1) + 1024 <= 160 * 1024
 
 
 def _ceil4(n: int) -> int:
@@ -95,33 +98,88 @@ class ChainLayout:
         R = max(self.reach, 1)                      # supports per block: a row then spans at most two consecutive blocks
         self.supports_per_block = R
         chain = np.concatenate([vc, hi])            # variables, then rows (a row sits with the LAST support it touches)
-        blk = np.where(chain >= 0, chain // R, -1)
-        self.S = int(blk.max()) + 1 if (blk >= 0).any() else 0
-        if self.S < 1:
-            raise _lib.IemError("chain KKT: no unknown lies on the chain")
         n = self.nvar + self.ncon
         kind = (np.arange(n) >= self.nvar).astype(np.int64)
-        on = blk >= 0
+        on = chain >= 0
         ids = np.nonzero(on)[0]
-        order = ids[np.lexsort((ids, kind[ids], blk[ids]))]          # by block, variables first, then by index
-        counts = np.bincount(blk[ids], minlength=self.S)
-        start = np.concatenate([[0], np.cumsum(counts)])
-        loc = np.full(n, -1, dtype=np.int64)
-        loc[order] = np.arange(order.size) - start[blk[order]]
-        border = np.nonzero(~on)[0]                                  # border: variables first, then rows (already in that order)
-        loc[border] = np.arange(border.size)
+        border = np.nonzero(~on)[0]                 # border: variables first, then rows (already in that order)
+        jrn, jcn = jr.numpy(), jc.numpy()
+
+        def arrange(phase):
+            """Blocks of R supports starting at support -phase: (blk, loc, counts, nb, coupling rows, coupling columns).
+            Inside a block the unknowns sit in FIXED places — variables before rows, each kind by the support's position in
+            the block, then by index, every (kind, position) group at the same base in every block — so that a block with
+            fewer unknowns (the first support has no difference row, the last block may be short) leaves holes instead of
+            shifting the others: the coupling then lives on the same few local rows / columns in every block."""
+            blk = np.where(on, (chain + phase) // R, -1)
+            off = np.where(on, (chain + phase) % R, 0)
+            S = int(blk.max()) + 1 if on.any() else 0
+            order = ids[np.lexsort((ids, off[ids], kind[ids], blk[ids]))]
+            g = (blk[order] * 2 + kind[order]) * R + off[order]
+            first = np.concatenate([[True], g[1:] != g[:-1]]) if order.size else np.zeros(0, bool)
+            pos = np.arange(order.size)
+            ordinal = pos - np.maximum.accumulate(np.where(first, pos, 0))
+            size = np.zeros((2, R), dtype=np.int64)
+            np.maximum.at(size, (kind[order], off[order]), ordinal + 1)
+            base = np.zeros((2, R), dtype=np.int64)
+            base[0] = np.concatenate([[0], np.cumsum(size[0])[:-1]])
+            base[1] = size[0].sum() + np.concatenate([[0], np.cumsum(size[1])[:-1]])
+            loc = np.full(n, -1, dtype=np.int64)
+            loc[order] = base[kind[order], off[order]] + ordinal
+            loc[border] = np.arange(border.size)
+            counts = np.bincount(blk[ids], minlength=S)
+            nb = _ceil4(size.sum())
+            # the coupling K[block k, block k-1]: J entries whose row sits one block after the variable, and the transposes
+            # of those whose variable sits one block after the row
+            kr, kc = blk[self.nvar + jrn], blk[jcn]
+            low = (kr >= 0) & (kc >= 0) & (kr == kc + 1)
+            up = (kr >= 0) & (kc >= 0) & (kc == kr + 1)
+            rows = np.unique(np.concatenate([loc[self.nvar + jrn[low]], loc[jcn[up]]]))
+            cols = np.unique(np.concatenate([loc[jcn[low]], loc[self.nvar + jrn[up]]]))
+            return blk, loc, counts, nb, rows, cols, S
+
+        best = None
+        for phase in range(R):                      # where the blocks start decides how WIDE the coupling is (collocation: blocks that
+            cand = arrange(phase)                   # end on an element boundary couple through the boundary node only)
+            key = (max(cand[4].size, cand[5].size), cand[3], phase)
+            if best is None or key < best[0]:
+                best = (key, cand)
+        blk, loc, counts, nb, rows, cols, self.S = best[1]
+        self.phase = best[0][2]
+        if self.S < 1:
+            raise _lib.IemError("chain KKT: no unknown lies on the chain")
         self.blk, self.loc, self.counts = blk, loc, counts
         self.n_border = int(border.size)
-        self.nb, self.ne = _ceil4(counts.max()), _ceil4(border.size)
+        self.nb, self.ne = nb, _ceil4(border.size)
         if self.nb > max_nb or self.ne > max_ne or not fits_lds(self.nb, self.ne):
             raise _lib.IemError(f"chain KKT: blocks of {int(counts.max())} unknowns / a border of {border.size} exceed the dense-block solver's "
-                                f"limits ({max_nb} / {max_ne}, two tiles of each in LDS); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
+                                f"limits ({max_nb} / {max_ne}, the tiles of a block in LDS); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
+        # The coupling is NARROW: entries on a few local rows R of block k (the derivative-approximation rows of its first
+        # support) and a few local columns C of block k-1 (the differentiated states) — from the Jacobian's structure here;
+        # set_coupling() widens it if the caller's K holds more (a Hessian entry across two supports).
+        self.set_coupling(rows, cols)
 
-    # offsets of D | B | E | G in the flat block buffer
+    def set_coupling(self, rows, cols):
+        """Local rows (of block k) and columns (of block k-1) the coupling blocks live on; ``nc`` = their padded count."""
+        self.rowsR, self.colsC = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        self.nc = max(_ceil4(max(self.rowsR.size, self.colsC.size)), 4)
+        if self.reach > 0 and (self.nc > MAX_NC or self.nc > self.nb or not fits_lds(self.nb, self.ne, self.nc)):
+            raise _lib.IemError(f"chain KKT: the coupling between neighbouring blocks spans {self.rowsR.size} rows / {self.colsC.size} columns "
+                                f"(limit {MAX_NC}); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
+        self._ridx = np.full(self.nb, -1, dtype=np.int64); self._ridx[self.rowsR] = np.arange(self.rowsR.size)
+        self._cidx = np.full(self.nb, -1, dtype=np.int64); self._cidx[self.colsC] = np.arange(self.colsC.size)
+
+    def coupling_tables(self):
+        """``(rows, cols)`` as int32 arrays of length ``nc`` (-1 = padding) for the kernels."""
+        r = np.full(self.nc, -1, dtype=np.int32); r[:self.rowsR.size] = self.rowsR
+        c = np.full(self.nc, -1, dtype=np.int32); c[:self.colsC.size] = self.colsC
+        return r, c
+
+    # offsets of D | Bt | E | G in the flat block buffer
     def offsets(self):
-        S, nb, ne = self.S, self.nb, self.ne
+        S, nb, ne, nc = self.S, self.nb, self.ne, self.nc
         oD, oB = 0, S * nb * nb
-        oE = oB + S * nb * nb
+        oE = oB + S * nc * nc
         oG = oE + S * nb * ne
         return oD, oB, oE, oG, oG + ne * ne
 
@@ -140,7 +198,12 @@ class ChainLayout:
         if bad.any():
             raise _lib.IemError("chain KKT: an entry couples blocks that are not neighbours (the chain grouping does not fit this model)")
         dest[diag] = oD + (kr[diag] * nb + lr[diag]) * nb + lc[diag]
-        dest[low] = oB + (kr[low] * nb + lr[low]) * nb + lc[low]
+        if low.any():
+            ri, ci = self._ridx[lr[low]], self._cidx[lc[low]]
+            if (ri < 0).any() or (ci < 0).any():       # K couples more than the Jacobian showed: widen R / C and start over
+                self.set_coupling(np.union1d(self.rowsR, lr[low]), np.union1d(self.colsC, lc[low]))
+                return self.scatter_plan(rows, cols)
+            dest[low] = oB + (kr[low] * self.nc + ri) * self.nc + ci
         e = (kr >= 0) & (kc < 0)
         dest[e] = oE + (kr[e] * nb + lr[e]) * ne + lc[e]
         g = (kr < 0) & (kc < 0)
@@ -149,11 +212,14 @@ class ChainLayout:
         return src, dest[src]
 
     def pad_positions(self):
-        """Flat positions of the unit diagonal of the padding (blocks shorter than ``nb``, border shorter than ``ne``)."""
+        """Flat positions of the unit diagonal of the padding (the places of a block no unknown occupies, the border's tail)."""
         oD, _, _, oG, _ = self.offsets()
         nb, ne = self.nb, self.ne
-        k = np.repeat(np.arange(self.S), nb - self.counts)
-        l = np.concatenate([np.arange(c, nb) for c in self.counts]) if (self.counts < nb).any() else np.zeros(0, np.int64)
+        free = np.ones(self.S * nb, dtype=bool)
+        on = self.blk >= 0
+        free[self.blk[on] * nb + self.loc[on]] = False
+        slot = np.nonzero(free)[0]
+        k, l = slot // nb, slot % nb
         pd = oD + (k * nb + l) * nb + l
         lb = np.arange(self.n_border, ne)
         return np.concatenate([pd, oG + lb * ne + lb]).astype(np.int64)
@@ -182,17 +248,19 @@ class ChainKKT:
         src, dest = L.scatter_plan(rows, kkt.colind.cpu().numpy())
         self._src, self._dest = torch.as_tensor(src, device=dev), torch.as_tensor(dest, device=dev)
         self._pad = torch.as_tensor(L.pad_positions(), device=dev)
-        oD, oB, oE, oG, total = L.offsets()
-        S, nb, ne = L.S, L.nb, L.ne
+        oD, oB, oE, oG, total = L.offsets()          # (after scatter_plan: it may have widened the coupling)
+        S, nb, ne, nc = L.S, L.nb, L.ne, L.nc
         f64 = dict(dtype=torch.float64, device=dev)
         self.flat = torch.zeros(total, **f64)
         self.D, self.B = self.flat[oD:oB], self.flat[oB:oE]
         self.E, self.G = self.flat[oE:oG], self.flat[oG:total].view(ne, ne)
-        nxy = S * nb * nb if L.reach > 0 else 1
-        self.X, self.Y = torch.empty(nxy, **f64), torch.empty(nxy, **f64)
+        self.BR = torch.zeros(S * nc * nc if L.reach > 0 else 1, **f64)
+        rt, ct = L.coupling_tables()
+        self._rows, self._cols = torch.as_tensor(rt, device=dev), torch.as_tensor(ct, device=dev)
         self.Z, self.Gp = torch.empty(max(S * nb * ne, 1), **f64), torch.empty(max(S * ne * ne, 1), **f64)
         self.info = torch.zeros(3, dtype=torch.int64, device=dev)
         self._r = torch.zeros(S * nb, **f64)
+        self._z = torch.empty(S * nb if L.reach > 0 else 1, **f64)
         self._rBp = torch.empty(max(S * ne, 1), **f64)
         on, pos, border = L.positions()
         self._on, self._pos, self._border = (torch.as_tensor(a, device=dev) for a in (on, pos, border))
@@ -213,8 +281,9 @@ class ChainKKT:
         m._sync_stream()
         p = lambda a: C.c_void_p(a.data_ptr())
         chained = L.reach > 0      # reach 0 (scenario blocks of a two-stage problem): one launch, no levels
-        _lib.check(m._L.iem_kkt_chain_factor(m._h, L.S, L.nb, L.ne, p(self.D), p(self.B) if chained else None, p(self.X) if chained else None,
-                                            p(self.Y) if chained else None, p(self.E), p(self.Z), p(self.Gp), p(self.info), float(tiny)))
+        _lib.check(m._L.iem_kkt_chain_factor(m._h, L.S, L.nb, L.ne, L.nc, p(self.D), p(self.B) if chained else None, p(self.BR) if chained else None,
+                                            p(self._rows) if chained else None, p(self._cols) if chained else None, p(self.E), p(self.Z), p(self.Gp),
+                                            p(self.info), float(tiny)))
         if L.ne:
             Gs = self.G - self.Gp[:L.S * L.ne * L.ne].view(L.S, L.ne, L.ne).sum(0)
             self._Gs = Gs
@@ -263,7 +332,8 @@ class ChainKKT:
         m._sync_stream()
         p = lambda a: C.c_void_p(a.data_ptr())
         chained = L.reach > 0
-        args = (m._h, L.S, L.nb, L.ne, p(self.D), p(self.X) if chained else None, p(self.Y) if chained else None, p(self.Z), p(r), p(self._rBp))
+        args = (m._h, L.S, L.nb, L.ne, L.nc, p(self.D), p(self.B) if chained else None, p(self.BR) if chained else None,
+                p(self._rows) if chained else None, p(self._cols) if chained else None, p(self.Z), p(r), p(self._z) if chained else None, p(self._rBp))
         xB = None
         _lib.check(m._L.iem_kkt_chain_solve(*args, None, 0))
         if L.ne:

@@ -157,9 +157,9 @@ def lib():
     L.iem_csr_values.argtypes = [vp, i64, vp, vp, vp, vp]
     L.iem_csr_values32.argtypes = [vp, i64, vp, vp, vp, vp]
     L.iem_csr_spmv.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp]
-    L.iem_kkt_chain_factor.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl]
-    L.iem_kkt_chain_solve.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]
-    L.iem_kkt_source.argtypes = [i32, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.iem_kkt_chain_factor.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, dbl]
+    L.iem_kkt_chain_solve.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.iem_kkt_source.argtypes = [i32, i32, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     L.iem_emit_source.restype = i32
     L.iem_free.argtypes = [vp]
@@ -234,11 +234,12 @@ def emit_source(blob: bytes):
     return src, int(key.value)
 
 
-def kkt_source(nb: int, ne: int):
-    """HIP source of the chain KKT solver's kernels for block size ``nb`` / border size ``ne`` and its cache key."""
+def kkt_source(nb: int, ne: int, nc: int = 12):
+    """HIP source of the chain KKT solver's kernels for block size ``nb`` / border size ``ne`` / coupling width ``nc`` and its
+    cache key."""
     L = lib()
     p, key = C.c_void_p(), C.c_uint64()
-    check(L.iem_kkt_source(int(nb), int(ne), C.byref(p), C.byref(key)))
+    check(L.iem_kkt_source(int(nb), int(ne), int(nc), C.byref(p), C.byref(key)))
     try:
         src = C.string_at(p).decode()
     finally:

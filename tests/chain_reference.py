@@ -5,15 +5,20 @@ import numpy as np
 
 
 def fill_blocks(layout, rows, cols, vals):
+    """Dense D | B | E | G of the layout (the device keeps B restricted to its rows R / columns C: expanded here)."""
+    src, dest = layout.scatter_plan(rows, cols)          # (first: it may widen the coupling, which moves the offsets)
     oD, oB, oE, oG, total = layout.offsets()
     flat = np.zeros(total)
     flat[layout.pad_positions()] = 1.0
-    src, dest = layout.scatter_plan(rows, cols)
     assert np.unique(dest).size == dest.size, "every kept KKT entry has a dense position of its own"
     flat[dest] = vals[src]
-    S, nb, ne = layout.S, layout.nb, layout.ne
-    return (flat[oD:oB].reshape(S, nb, nb).copy(), flat[oB:oE].reshape(S, nb, nb).copy(),
-            flat[oE:oG].reshape(S, nb, ne).copy(), flat[oG:total].reshape(ne, ne).copy())
+    S, nb, ne, nc = layout.S, layout.nb, layout.ne, layout.nc
+    Bt = flat[oB:oE].reshape(S, nc, nc)
+    B = np.zeros((S, nb, nb))
+    R, C = layout.rowsR, layout.colsC
+    if R.size and C.size:
+        B[:, R[:, None], C[None, :]] = Bt[:, :R.size, :C.size]
+    return (flat[oD:oB].reshape(S, nb, nb).copy(), B, flat[oE:oG].reshape(S, nb, ne).copy(), flat[oG:total].reshape(ne, ne).copy())
 
 
 def factor(D, B, E):

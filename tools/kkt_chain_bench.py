@@ -55,8 +55,8 @@ res = float((ck._matvec(sol) - rhs).abs().max().item() / max(1.0, float(rhs.abs(
 res0 = float((ck._matvec(ck.solve(rhs, refine=0)) - rhs).abs().max().item())
 pos, neg, doubtful = ck.inertia()
 flops = L.S * (2.0 * L.nb ** 3 * (1 + 2 + 3) + 2.0 * L.nb * L.nb * L.ne * 4)      # inverse + X, Y + three update products (+ border terms)
-print(json.dumps({"workload": args.workload, "supports": args.supports, "n": n, "nnz_K": kkt.nnz, "chain": {"S": L.S, "nb": L.nb, "ne": L.ne, "reach": L.reach, "group": L.group},
+print(json.dumps({"workload": args.workload, "supports": args.supports, "n": n, "nnz_K": kkt.nnz, "chain": {"S": L.S, "nb": L.nb, "ne": L.ne, "nc": L.nc, "reach": L.reach, "group": L.group, "phase": L.phase},
                   "setup_s": {"model_and_csr_plan": t1 - t0, "chain_layout_and_plan": t2 - t1}, "ms": ms,
                   "factor_GFLOP_dense": flops / 1e9, "factor_TFLOPs": flops / (ms["factor"] * 1e-3) / 1e12,
-                  "block_bytes": int(ck.flat.numel() * 8 + (ck.X.numel() + ck.Y.numel() + ck.Z.numel()) * 8),
+                  "block_bytes": int(ck.flat.numel() * 8 + (ck.BR.numel() + ck.Z.numel()) * 8),
                   "rel_residual_after_refinement": res, "abs_residual_without": res0, "inertia": [pos, neg, doubtful], "ncon": gm.meta.ncon}))
