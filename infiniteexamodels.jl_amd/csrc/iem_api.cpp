@@ -1753,6 +1753,9 @@ namespace {
 std::string kkt_source(int nb, int ne, int nc) {
   std::string s = "// iem-flags: -O3 -ffp-contract=off -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
+  // blocks of up to three 16-row tiles: kkt_eliminate is bound by latency x occupancy — a register budget for four waves per
+  // SIMD (5 spilled registers) factors 10 % faster than the 2 - 3 waves the compiler settles for (profiles/r03_kkt_chain.json)
+  if (nb <= 48) s += "#define KKT_WPE 4\n";
   s += kKktSource;
   return s;
 }

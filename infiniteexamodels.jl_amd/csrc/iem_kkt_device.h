@@ -184,11 +184,12 @@ struct KktArgs {
 #define KKT_LC 5                  // LDS row stride of the column panel (16 R rows: the rim is read, never used)
 #define KKT_LP (16 * KKT_R + 1)   // ... of the 4-row row panel
 #define KKT_PANEL_DOUBLES (2 * 16 * KKT_R * KKT_LC + 2 * 4 * KKT_LP)
+#define KKT_GJ_DOUBLES 32          // per panel: snap[4][4] (the normalised pivot rows), then its lower triangle (zeros above the diagonal)
 template <int P>
-__device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double *cpb, double *rpb, double tiny, int &neg_, int &bad_) {
+__device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double *cpb, double *rpb, double *gjb, double tiny, int &neg_, int &bad_) {
   constexpr int TS = P / 4, RS = P % 4, C0 = 4 * RS;      // tile row / column of the panel, register slot of its rows, first local column
   constexpr int WS = TS % KKT_W, NS = TS / KKT_W;         // owner wave and slot of the panel's tile row
-  double *Cp = cpb + (P & 1) * (16 * KKT_R * KKT_LC), *Rp = rpb + (P & 1) * (4 * KKT_LP);
+  double *Cp = cpb + (P & 1) * (16 * KKT_R * KKT_LC), *Rp = rpb + (P & 1) * (4 * KKT_LP), *Gj = gjb + (P & 1) * KKT_GJ_DOUBLES;
   const int l = (int)threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), li = l & 15, lk = l >> 4;
   const bool pcol = li >= C0 && li < C0 + 4;              // this lane holds panel columns (in tile column TS)
   if (pcol) {
@@ -200,49 +201,60 @@ __device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double
       for (int r = 0; r < 4; ++r) Cp[(16 * tr + lk + 4 * r) * KKT_LC + li - C0] = m[n][TS][r];
     }
   }
+  // The OWNER wave of the panel's rows runs the four pivot steps on the 4 x 4 pivot block — once per block, not once per
+  // wave: it collects the block from its own lanes (element (a, b) sits in lane 16 a + C0 + b), every lane of the wave then
+  // holds the same numbers; mult[a][k] = the entry (a, k) at the time of step k, inv[k] = 1 / pivot k, snap[k][b] = the
+  // normalised pivot row k at the time of step k (b < k: what the inverse holds there by then; b = k: 1 / pivot; b > k: the
+  // entry the later pivot columns still see).  The other waves get `snap` through LDS, behind the panel's one barrier.
+  double mult[4][4], inv[4];
   if (w == WS) {
 #pragma unroll
     for (int tc = 0; tc < KKT_R; ++tc) Rp[lk * KKT_LP + 16 * tc + li] = m[NS][tc][RS];
+    const double own = m[NS][TS][RS];
+    const int olo = __double2loint(own), ohi = __double2hiint(own);
+    double pv[4][4], snap[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        pv[a][b] = __hiloint2double(__builtin_amdgcn_readlane(ohi, 16 * a + C0 + b), __builtin_amdgcn_readlane(olo, 16 * a + C0 + b));
+    int neg = 0, bad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double piv = pv[k][k];
+      if (piv < 0.0) ++neg;
+      if (!(fabs(piv) >= tiny)) { ++bad; piv = piv < 0.0 ? -tiny : tiny; }   // keep going with a bounded pivot; info[1] reports it
+      inv[k] = kkt_rcp(piv);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) if (b != k) pv[k][b] *= inv[k];
+      pv[k][k] = inv[k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) snap[k][b] = pv[k][b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (a == k) { mult[a][k] = 0.0; continue; }
+        const double f = pv[a][k];
+        mult[a][k] = f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) if (b != k) pv[a][b] -= f * pv[k][b];
+        pv[a][k] = -f * inv[k];
+      }
+    }
+    if (l == 0) {
+      neg_ += neg; bad_ += bad;      // (one wave per panel, a barrier between panels)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { Gj[4 * k + b] = snap[k][b]; Gj[16 + 4 * k + b] = b <= k ? snap[k][b] : 0.0; }
+    }
   }
   __syncthreads();
-  // the pivot block: four in-place Gauss-Jordan steps; mult[a][k] = the entry (a, k) at the time of step k, inv[k] = 1 / pivot k,
-  // snap[k][b] = the normalised pivot row k at the time of step k (b < k: what the inverse holds there by then; b = k: 1 / pivot;
-  // b > k: the entry the later pivot columns still see)
-  double pv[4][4], mult[4][4], snap[4][4], inv[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) pv[a][b] = Rp[a * KKT_LP + 4 * P + b];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    double piv = pv[k][k];
-    if (threadIdx.x == 0) {
-      if (piv < 0.0) ++neg_;
-      if (!(fabs(piv) >= tiny)) ++bad_;
-    }
-    if (!(fabs(piv) >= tiny)) piv = piv < 0.0 ? -tiny : tiny;   // keep going with a bounded pivot; info[1] reports it
-    inv[k] = kkt_rcp(piv);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) if (b != k) pv[k][b] *= inv[k];
-    pv[k][k] = inv[k];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) snap[k][b] = pv[k][b];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (a == k) { mult[a][k] = 0.0; continue; }
-      const double f = pv[a][k];
-      mult[a][k] = f;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) if (b != k) pv[a][b] -= f * pv[k][b];
-      pv[a][k] = -f * inv[k];
-    }
-  }
   // B operand = entry j of the normalised pivot row lk at the time of ITS step: a combination of the row panel's column j
-  // with row lk of `snap` (the steps before it, already folded).  The panel's own columns enter as unit vectors (the
-  // in-place algorithm keeps the inverse where the identity of [A | I] would sit).
+  // with row lk of the lower triangle of `snap` (the steps before it, already folded).  The panel's own columns enter as
+  // unit vectors (the in-place algorithm keeps the inverse where the identity of [A | I] would sit).
   double sl[4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) sl[b] = b > lk ? 0.0 : lk == 0 ? snap[0][b] : lk == 1 ? snap[1][b] : lk == 2 ? snap[2][b] : snap[3][b];
+  for (int b = 0; b < 4; ++b) sl[b] = Gj[16 + 4 * lk + b];
   double bop[KKT_R], vin[KKT_R][4];
 #pragma unroll
   for (int tc = 0; tc < KKT_R; ++tc) {
@@ -274,6 +286,7 @@ __device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double
     }
   }
   // every other row i: its entries c_i(k) in the pivot columns at the time of step k, then M[i, :] -= sum_k c_i(k) r_k
+  const double u01 = Gj[1], u02 = Gj[2], u03 = Gj[3], u12 = Gj[6], u13 = Gj[7], u23 = Gj[11];
 #pragma unroll
   for (int n = 0; n < KKT_TRW; ++n) {
     const int tr = w + n * KKT_W;
@@ -282,10 +295,9 @@ __device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double
     double c[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) c[k] = Cp[i * KKT_LC + k];
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-#pragma unroll
-      for (int mm = 0; mm < k; ++mm) c[k] -= c[mm] * snap[mm][k];
+    c[1] -= c[0] * u01;
+    c[2] -= c[0] * u02; c[2] -= c[1] * u12;
+    c[3] -= c[0] * u03; c[3] -= c[1] * u13; c[3] -= c[2] * u23;
     double a = -(lk == 0 ? c[0] : lk == 1 ? c[1] : lk == 2 ? c[2] : c[3]);
     if (i >= 4 * P && i < 4 * P + 4) a = 0.0;
 #pragma unroll
@@ -293,17 +305,22 @@ __device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double
   }
 }
 template <int P>
-__device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *cpb, double *rpb, double tiny, int &neg_, int &bad_) {
+__device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *cpb, double *rpb, double *gjb, double tiny, int &neg_, int &bad_) {
   if constexpr (P < KKT_NB / 4) {
-    kkt_gj_panel<P>(m, cpb, rpb, tiny, neg_, bad_);
-    kkt_gj_all<P + 1>(m, cpb, rpb, tiny, neg_, bad_);
+    kkt_gj_panel<P>(m, cpb, rpb, gjb, tiny, neg_, bad_);
+    kkt_gj_all<P + 1>(m, cpb, rpb, gjb, tiny, neg_, bad_);
   }
 }
 
 // ---- level l, step 1: eliminate the blocks i = (2 t + 1) s --------------------------------------------------
-extern "C" __global__ __launch_bounds__(KKT_T) void kkt_eliminate(const KktArgs A) {
-  __shared__ double panels[KKT_PANEL_DOUBLES];
-  double *cpb = panels, *rpb = panels + 2 * 16 * KKT_R * KKT_LC;
+#ifdef KKT_WPE
+#define KKT_OCC __attribute__((amdgpu_waves_per_eu(KKT_WPE, KKT_WPE)))   // register budget for KKT_WPE waves per SIMD: the kernel is bound by latency x occupancy
+#else
+#define KKT_OCC
+#endif
+extern "C" __global__ __launch_bounds__(KKT_T) KKT_OCC void kkt_eliminate(const KktArgs A) {
+  __shared__ double panels[KKT_PANEL_DOUBLES + 2 * KKT_GJ_DOUBLES];
+  double *cpb = panels, *rpb = panels + 2 * 16 * KKT_R * KKT_LC, *gjb = panels + KKT_PANEL_DOUBLES;
   __shared__ int neg_, bad_;
   // final_block: 0 = level of the chain; 1 = the last remaining block (index 0); 2 = NO chain coupling at all (scenario
   // blocks of a two-stage problem): every block is eliminated in this one launch, against the border only
@@ -331,7 +348,7 @@ extern "C" __global__ __launch_bounds__(KKT_T) void kkt_eliminate(const KktArgs 
   // coupling of the next level)
   if (has_right)
     for (int e = (int)threadIdx.x; e < KKT_NC * KKT_NC; e += KKT_T) A.BR[i * KKT_NC * KKT_NC + e] = A.Bt[(i + A.s) * KKT_NC * KKT_NC + e];
-  kkt_gj_all<0>(m, cpb, rpb, A.tiny, neg_, bad_);
+  kkt_gj_all<0>(m, cpb, rpb, gjb, A.tiny, neg_, bad_);
   if (threadIdx.x == 0) {
     if (neg_) atomicAdd((unsigned long long *)A.info, (unsigned long long)neg_);
     if (bad_) atomicAdd((unsigned long long *)(A.info + 1), (unsigned long long)bad_);

@@ -17,7 +17,8 @@ ap.add_argument("--supports", type=int, default=100_000)
 ap.add_argument("--iters", type=int, default=10)
 args = ap.parse_args()
 mk = {"quadrotor": lambda: workloads.quadrotor(args.supports), "quadrotor_oc3": lambda: workloads.quadrotor(args.supports, collocation=3),
-      "farmer": lambda: workloads.farmer(args.supports), "opf": lambda: workloads.opf(args.supports), "hovercraft": lambda: workloads.hovercraft(args.supports)}[args.workload]
+      "farmer": lambda: workloads.farmer(args.supports), "opf": lambda: workloads.opf(args.supports), "hovercraft": lambda: workloads.hovercraft(args.supports),
+      "kinetic": lambda: workloads.kinetic_control(args.supports)}[args.workload]
 t0 = time.perf_counter()
 core = transcribe.exa_core(mk())
 gm = ExaModel(core, device=0)
