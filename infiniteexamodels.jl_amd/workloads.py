@@ -53,14 +53,18 @@ def quadrotor(num_supports: int = 100, backend=None, supports=None, collocation:
     return im
 
 
-def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None, xi_supports=None) -> InfiniteModel:
+def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None, xi_supports=None, collocation: int = 0) -> InfiniteModel:
     """``/root/reference/ESCAPE34/pandemic.jl:4-34`` — SIR optimal control.
     ξ supports are synthetic (equispaced in [0.1, 0.6]) instead of Julia-RNG
-    ``Uniform(0.1, 0.6)`` draws (``:16``)."""
+    ``Uniform(0.1, 0.6)`` draws (``:16``).  ``collocation = 3`` gives ``/root/reference/examples/pandemic.jl:11,17,33``:
+    ``OrthogonalCollocation(3)`` on the non-uniform t grid and ``constant_over_collocation(u, t)`` — derivative rows over
+    node × element × scenario boxes."""
+    from . import infinite as io
     gamma, beta, N = 0.303, 0.727, 1e5                                              # :8-10
     extra_ts = [0.001, 0.002, 0.004, 0.008, 0.02, 0.04, 0.08, 0.2, 0.4, 0.8]         # :11
     im = InfiniteModel(backend)
-    t = im.infinite_parameter("t", 0.0, 200.0, num_supports=num_supports)            # :15
+    t = im.infinite_parameter("t", 0.0, 200.0, num_supports=num_supports,
+                              **({"derivative_method": io.OrthogonalCollocation(collocation)} if collocation else {}))   # :15
     xi = im.infinite_parameter("ξ", supports=(xi_supports if xi_supports is not None
                                               else np.linspace(0.1, 0.6, num_scenarios)))   # :16
     im.add_supports(t, extra_ts)                                                     # :17
@@ -80,6 +84,8 @@ def pandemic(num_supports: int = 100, num_scenarios: int = 4, backend=None, xi_s
     im.constraint(d(i) == xi * e - gamma * i, name="i_constr")                       # :30
     im.constraint(d(r) == gamma * i, name="r_constr")                                # :31
     im.constraint(i <= 0.02, name="imax_constr")                                     # :32
+    if collocation:
+        im.constant_over_collocation(u, t)                                           # examples/pandemic.jl:33
     return im
 
 

@@ -171,6 +171,7 @@ def small_cases():
         "quadrotor_oc3_700": lambda: workloads.quadrotor(700, collocation=3),
         "pandemic_20x3": lambda: workloads.pandemic(20, 3),
         "pandemic_300x7": lambda: workloads.pandemic(300, 7),
+        "pandemic_oc3_20x3": lambda: workloads.pandemic(20, 3, collocation=3),    # examples/pandemic.jl: collocation x scenarios (node x element x scenario boxes)
         "farmer_1": lambda: workloads.farmer(1),
         "farmer_5": lambda: workloads.farmer(5),
         "farmer_1000": lambda: workloads.farmer(1000),
