@@ -11,7 +11,7 @@ echo "profile ok"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard_stats -- python3 $R/bench.py --emulate-shard 3/8 --steps 200 --warmup 20 --no-cpu-baseline --no-cold > $O/shard_bench.json 2> $O/shard_bench.err ) || exit 1
 echo "shard stats ok"
 for i in 1 2 3 4 5 6 7 8 9 10; do
-  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-cold > $O/run_$i.json 2> $O/run_$i.err || exit 1
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-cold --no-variants > $O/run_$i.json 2> $O/run_$i.err || exit 1
   python3 - $O/run_$i.json $i <<'PY' >> $O/bench_runs.txt
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j["roofline"]
