@@ -71,7 +71,8 @@ struct Group {
   // item box of an OrthogonalCollocation(3) derivative)
   bool flat = false;
   // FOLDED templates (orthogonal collocation): the 1-D grid also carries templates whose items form node x element boxes
-  // (w x ne, w <= fold_n) or element lists.  Every lane derives  q1 = floor((q0 - fold_off) / fold_n)  (the element) and
+  // (w x ne, w <= fold_n) or element lists — on a 2-D grid (t x xi) boxes with the second grid dimension behind them
+  // (w x ne x n_xi).  Every lane derives  qe = floor((q0 - fold_off) / fold_n)  (the element) and
   // q2 = (q0 - fold_off) mod fold_n  (the node within it); a folded template's item (j, e) is evaluated by lane
   // fold_off + j + fold_n * e ("natural", w = fold_n) or by the lane that owns the entry it adds into (a "pinned" clone:
   // lanes with q2 == K evaluate item (J, q1 + de)).  A scheduling decision only, like every grid id.
@@ -305,18 +306,25 @@ class KernelBuilder {
   struct Pin { int64_t J, K, de; };
   bool is_folded(int ti) const { return g_.fold_n > 0 && g_.folded.count(ti) != 0; }
   // node x element box of a folded template: w nodes (1 for an element list), ne elements
-  static void fold_box(const Template &t, int64_t &w, int64_t &ne) {
-    if (t.nd >= 2) { w = t.dims[0]; ne = t.dims[1]; } else { w = 1; ne = t.dims[0]; }
+  // a folded template's box: w nodes (1 for an element list) x ne elements [x the grid's second dimension]
+  void fold_box(const Template &t, int64_t &w, int64_t &ne) const {
+    const int own = t.nd - (g_.nd - 1);          // dimensions of the node x element part
+    if (own >= 2) { w = t.dims[0]; ne = t.dims[1]; } else { w = 1; ne = t.dims[0]; }
   }
-  static void fold_steps(const Template &t, const FieldDesc &f, int64_t &sj, int64_t &se) {
-    if (t.nd >= 2) { sj = f.step[0]; se = f.step[1]; } else { sj = 0; se = f.step[0]; }
+  void fold_steps(const Template &t, const FieldDesc &f, int64_t &sj, int64_t &se, int64_t &sx) const {
+    const int own = t.nd - (g_.nd - 1);
+    if (own >= 2) { sj = f.step[0]; se = f.step[1]; } else { sj = 0; se = f.step[0]; }
+    sx = g_.nd == 2 ? f.step[own] : 0;
   }
-  // value  base + sj*j + se*e  of a folded template's item as a function of the lane.  An element stride that is a
-  // multiple of fold_n is rewritten on q0 (n*q1 = q0 - off - q2): node-indexed slabs are then read and written at
+  // value  base + sj*j + se*e [+ sx*xi]  of a folded template's item as a function of the lane.  An element stride that is
+  // a multiple of fold_n is rewritten on q0 (n*qe = q0 - off - q2): node-indexed slabs are then read and written at
   // c + k*q0, the SAME index value the templates of the grid itself use — loads merge, scatter slots meet in registers.
-  AffQ fold_aff(const TGeo &G, int64_t base, int64_t sj, int64_t se) const {
+  // (On a 1-D grid an element stride that is not such a multiple — the row ordinal of an element list — stays on the
+  // element coordinate, which q1 carries there; a 2-D grid has its own q1 and folds full boxes only.)
+  AffQ fold_aff(const TGeo &G, int64_t base, int64_t sj, int64_t se, int64_t sx) const {
     const int64_t n = g_.fold_n, off = g_.fold_off;
     AffQ a;
+    if (g_.nd == 2 && se % n != 0) throw std::runtime_error("internal: element stride of a box folded onto a 2-D grid");
     if (G.fold == 1) {
       if (se % n == 0) { const int64_t b = se / n; a.c = base - b * off; a.k[0] = b; a.k[2] = sj - b; }
       else { a.c = base; a.k[1] = se; a.k[2] = sj; }
@@ -325,6 +333,7 @@ class KernelBuilder {
       if (se % n == 0) { const int64_t b = se / n; a.c = c - b * (off + G.K); a.k[0] = b; }
       else { a.c = c; a.k[1] = se; }
     }
+    if (g_.nd == 2) { a.c += sx * G.sh[1]; a.k[1] = sx; }
     return a;
   }
 
@@ -343,7 +352,7 @@ class KernelBuilder {
     G.scalar = scalar;
     std::ostringstream os;
     if (scalar) {
-      os << (g_.fold_n > 0 ? "(q0 == 0)" : "(q0 == 0 && q1 == 0 && q2 == 0)");
+      os << (g_.fold_n > 0 ? (g_.nd == 2 ? "(q0 == 0 && q1 == 0)" : "(q0 == 0)") : "(q0 == 0 && q1 == 0 && q2 == 0)");
     } else if (is_folded(ti)) {
       const int64_t n = g_.fold_n, off = g_.fold_off;
       int64_t w, ne;
@@ -352,7 +361,7 @@ class KernelBuilder {
       if (pin) {
         G.fold = 2; G.J = pin->J; G.K = pin->K; G.de = pin->de;
         const int64_t q1lo = -pin->de, q1hi = ne - pin->de;   // q1 + de in [0, ne)
-        os << " && q2 == " << pin->K << "LL && q1 >= " << coefstr(q1lo) << " && q1 < " << ip(q1hi);
+        os << " && q2 == " << pin->K << "LL && qe >= " << coefstr(q1lo) << " && qe < " << ip(q1hi);
         G.qlo[0] = off + pin->K + n * q1lo; G.qhi[0] = off + pin->K + n * (q1hi - 1) + 1;
       } else {
         if (w != n) throw std::runtime_error("internal: natural geometry of a partial folded template");
@@ -360,6 +369,13 @@ class KernelBuilder {
         G.qlo[0] = off; G.qhi[0] = off + n * ne;
         if (G.qlo[0] > 0) os << " && q0 >= " << coefstr(G.qlo[0]);
         if (G.qhi[0] < g_.ext[0]) os << " && q0 < " << ip(G.qhi[0]);
+      }
+      if (g_.nd == 2) {      // the grid's second dimension is the box's last
+        const int dx = t.nd - 1;
+        G.sh[1] = g_.lo[1] - t.origin[dx];
+        G.qlo[1] = -G.sh[1]; G.qhi[1] = t.dims[dx] - G.sh[1];
+        if (G.qlo[1] > 0) os << " && q1 >= " << coefstr(G.qlo[1]);
+        if (G.qhi[1] < g_.ext[1]) os << " && q1 < " << ip(G.qhi[1]);
       }
     } else {
       os << "inb";
@@ -377,9 +393,9 @@ class KernelBuilder {
 
   AffQ field_aff(const Template &t, const FieldDesc &f, const TGeo &G) const {
     if (G.fold) {
-      int64_t sj, se;
-      fold_steps(t, f, sj, se);
-      return fold_aff(G, f.base, sj, se);
+      int64_t sj, se, sx;
+      fold_steps(t, f, sj, se, sx);
+      return fold_aff(G, f.base, sj, se, sx);
     }
     AffQ a;
     a.c = f.base;
@@ -417,7 +433,8 @@ class KernelBuilder {
     if (G.fold) {   // item ordinal j + w*e
       int64_t w, ne;
       fold_box(t, w, ne);
-      AffQ a = fold_aff(G, off, t.nd >= 2 ? scale : 0, t.nd >= 2 ? scale * w : scale);
+      const int own = t.nd - (g_.nd - 1);
+      AffQ a = fold_aff(G, off, own >= 2 ? scale : 0, own >= 2 ? scale * w : scale, g_.nd == 2 ? scale * w * ne : 0);
       a.space = 3;
       return a;
     }
@@ -882,12 +899,14 @@ class KernelBuilder {
     auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; };
     // pure lane-affine destinations of the grid's own templates — and of the natural folded ones (a row's own node: a
     // state no row of the grid itself touches still has ONE owner per entry): (space, k0) -> constants
-    std::map<std::pair<int, int64_t>, std::vector<int64_t>> canon;
+    std::map<std::array<int64_t, 3>, std::vector<int64_t>> canon;     // (space, lane stride, stride of the grid's second dimension)
+    const bool two_d = g_.nd == 2;
     for (const Output &o : outs_) {
       if (o.scalar || o.fold == 2) continue;
       for (size_t s = 0; s < o.grad_idx.size(); ++s) {
         const IdxVal &iv = idx_[o.grad_idx[s]];
-        if (iv.ind.empty() && iv.aff.k[0] != 0 && iv.aff.k[1] == 0 && iv.aff.k[2] == 0) canon[{iv.aff.space, iv.aff.k[0]}].push_back(iv.aff.c);
+        if (iv.ind.empty() && iv.aff.k[0] != 0 && (two_d || iv.aff.k[1] == 0) && iv.aff.k[2] == 0)
+          canon[{(int64_t)iv.aff.space, iv.aff.k[0], two_d ? iv.aff.k[1] : 0}].push_back(iv.aff.c);
       }
     }
     std::map<std::array<int64_t, 4>, std::vector<int>> moved;   // (template, J, K, de) -> slots
@@ -900,24 +919,25 @@ class KernelBuilder {
       fold_box(t, w, ne);
       for (size_t s = 0; s < o.grad_idx.size(); ++s) {
         if (o.grad_mode[s] < 0) continue;
-        // raw destination (0-based): c + a*j + b*e
+        // raw destination (0-based): c + a*j + b*e [+ x*xi, which every lane of the family shares]
         const IdxExpr &ix = t.idx[o.grad_tidx[s]];
-        int64_t c = ix.c0 - 1, a = 0, b = 0;
+        int64_t c = ix.c0 - 1, a = 0, b = 0, xk = 0;
         bool affine = true;
         for (int j = 0; j < ix.nterms; ++j) {
           const FieldDesc &f = t.ifields[ix.field[j]];
           if (f.mode != IEM_F_AFFINE) { affine = false; break; }
-          int64_t sj, se;
-          fold_steps(t, f, sj, se);
-          c += ix.coef[j] * f.base; a += ix.coef[j] * sj; b += ix.coef[j] * se;
+          int64_t sj, se, sx;
+          fold_steps(t, f, sj, se, sx);
+          c += ix.coef[j] * f.base; a += ix.coef[j] * sj; b += ix.coef[j] * se; xk += ix.coef[j] * sx;
         }
         if (!affine || b == 0 || b % n != 0) continue;
+        if (two_d) c += xk * (g_.lo[1] - t.origin[t.nd - 1]);     // (as fold_aff: the constant at q1 = 0)
         const int64_t bp = b / n;
         const int space = idx_[o.grad_idx[s]].aff.space;
         // the owner map  entry = c* + bp*q0: the grid's own slot of that stride nearest to this one, else the slot's own lanes
         int64_t cstar = c - bp * off;
         bool found = false;
-        auto it = canon.find({space, bp});
+        auto it = canon.find({(int64_t)space, bp, two_d ? xk : 0});
         if (it != canon.end())
           for (int64_t cg : it->second) {
             if ((c - cg) % bp != 0) continue;
@@ -1138,7 +1158,7 @@ class KernelBuilder {
           for (size_t hs = 0; hs < h.grad_idx.size() && !done_; ++hs) {
             const IdxVal &hv = idx_[h.grad_idx[hs]];
             if (h.grad_mode[hs] < 0 || !hv.ind.empty() || hv.aff.c != iv.aff.c) continue;
-            if (g_.fold_n > 0 && (hv.aff.k[1] != 0 || hv.aff.k[2] != 0)) continue;   // (derived coordinates are not 0 on lane 0)
+            if (g_.fold_n > 0 && ((g_.nd == 1 && hv.aff.k[1] != 0) || hv.aff.k[2] != 0)) continue;   // (derived coordinates are not 0 on lane 0)
             h.vals[hs] = add(h.vals[hs], mk(VGUARD, outs_[oi].guard, outs_[oi].vals[s], -1, -1, 0));
             outs_[oi].grad_mode[s] = -1;
             done_ = true;
@@ -1598,12 +1618,17 @@ class KernelBuilder {
             else if (mode == 5) {   // parked for the plan-driven gather: one slot of the aux buffer per lane of the launch domain
               if (o.scalar) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << "] = v" << o.vals[s] << ";\n";
               else if (g_.flat) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q] = v" << o.vals[s] << ";\n";
-              else if (g_.fold_n > 0) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0] = v" << o.vals[s] << ";\n";
+              else if (g_.fold_n > 0 && g_.nd == 1) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0] = v" << o.vals[s] << ";\n";
+              else if (g_.fold_n > 0) tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0 + " << ip(g_.ext[0], 6) << " * q1] = v" << o.vals[s] << ";\n";
               else tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + q0 + " << ip(g_.ext[0], 6) << " * (q1 + " << ip(g_.ext[1], 6) << " * q2)] = v" << o.vals[s] << ";\n";
             }
             else if (mode == 4) {
               // row = position in dims 1, 2 of this output's box, lane = position in dim 0
               const int64_t n0 = o.qhi[0] - o.qlo[0], n1 = o.qhi[1] - o.qlo[1];
+              if (g_.fold_n > 0)      // (q2 is the node of the lane there, not a grid coordinate: the grid has two dimensions)
+                tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + (q1 - " << coefstr(o.qlo[1]) << ") * " << ip(n0, 6) << " + (q0 - "
+                     << coefstr(o.qlo[0]) << ")] = v" << o.vals[s] << ";\n";
+              else
               tail << "  if (" << g << ") AUX[" << ip(o.axis_off.at((int)s), 6) << " + ((q1 - " << coefstr(o.qlo[1]) << ") + " << ip(n1, 6) << " * (q2 - "
                    << coefstr(o.qlo[2]) << ")) * " << ip(n0, 6) << " + (q0 - " << coefstr(o.qlo[0]) << ")] = v" << o.vals[s] << ";\n";
             }
@@ -1668,11 +1693,20 @@ class KernelBuilder {
       // element / node of the lane: one 64-bit division per WORKGROUP (block-uniform), 32-bit steps per lane
       const std::string n = std::to_string(g_.fold_n);
       head << "  const long long q0 = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
-      head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
       head << "  const long long fb_ = (long long)blockIdx.x * " << qstep_str() << " - " << ip(g_.fold_off) << ";\n";
       head << "  const long long fq_ = (fb_ >= 0 ? fb_ : fb_ - " << (g_.fold_n - 1) << ") / " << n << ";\n";
       head << "  const int ft_ = (int)(fb_ - " << n << " * fq_) + (int)threadIdx.x;\n";
-      head << "  const long long q1 = fq_ + ft_ / " << n << ", q2 = ft_ % " << n << "; (void)q1; (void)q2;\n";
+      head << "  const long long qe = fq_ + ft_ / " << n << ", q2 = ft_ % " << n << "; (void)qe; (void)q2;\n";
+      if (g_.nd == 1) {
+        head << "  const long long q1 = qe; (void)q1;\n";      // (a 1-D grid has no second dimension: q1 carries the element)
+        head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+      } else if (g_.ext[1] > 65535) {
+        head << "  const long long q1 = (long long)blockIdx.y + (long long)gridDim.y * blockIdx.z;\n";
+        head << "  const bool inb = q0 < " << ip(g_.ext[0]) << " && q1 < " << ip(g_.ext[1]) << ";\n";
+      } else {
+        head << "  const long long q1 = blockIdx.y;\n";
+        head << "  const bool inb = q0 < " << ip(g_.ext[0]) << ";\n";
+      }
     } else {
     head << "  const long long q0 = (long long)blockIdx.x * " << qstep_str() << " + threadIdx.x;\n";
     if (g_.nd == 2 && g_.ext[1] > 65535) {
@@ -1851,7 +1885,7 @@ class KernelBuilder {
   // values coordinate d takes over the launch domain (a folded group derives q1, q2 from q0)
   void coord_range(int d, int64_t &lo, int64_t &hi) const {
     lo = 0; hi = g_.ext[d] - 1;
-    if (g_.fold_n > 0 && d == 1) { lo = -((g_.fold_off + g_.fold_n - 1) / g_.fold_n); hi = std::max<int64_t>(g_.ext[0] - 1 - g_.fold_off, 0) / g_.fold_n; }
+    if (g_.fold_n > 0 && g_.nd == 1 && d == 1) { lo = -((g_.fold_off + g_.fold_n - 1) / g_.fold_n); hi = std::max<int64_t>(g_.ext[0] - 1 - g_.fold_off, 0) / g_.fold_n; }
     if (g_.fold_n > 0 && d == 2) { lo = 0; hi = g_.fold_n - 1; }
   }
   int qstep() const {
@@ -1984,58 +2018,70 @@ std::vector<Group> make_groups(const Model &m, const std::function<bool(size_t)>
 // with fewer nodes per element than the fold and element lists (scatter kinds only: their items are not contiguous in
 // the lane index, which the block store of the COO kinds needs).
 void fold_groups(const Model &m, std::vector<Group> &groups, int max_n, bool partial) {
-  typedef std::array<int64_t, 3> Map;   // variable index (1-based) = c + a*j + b*e
-  auto var_maps = [&](const Template &t, std::vector<Map> &out) {
+  typedef std::array<int64_t, 4> Map;   // variable index (1-based) = c + a*j + b*e + x*xi
+  // `lead`: dimensions of the node x element part of the box (2 for a full box, 1 for an element list); a further
+  // dimension is the second dimension of the grid the box is folded onto
+  auto var_maps = [&](const Template &t, int lead, std::vector<Map> &out) {
     for (const Node &nd : t.nodes) {
       if (nd.op != IEM_OP_VAR) continue;
       const IdxExpr &ix = t.idx[nd.a];
-      Map mp{ix.c0, 0, 0};
+      Map mp{ix.c0, 0, 0, 0};
       for (int j = 0; j < ix.nterms; ++j) {
         const FieldDesc &f = t.ifields[ix.field[j]];
         if (f.mode != IEM_F_AFFINE) return false;
         mp[0] += ix.coef[j] * f.base;
-        if (t.nd >= 2) { mp[1] += ix.coef[j] * f.step[0]; mp[2] += ix.coef[j] * f.step[1]; }
+        if (lead >= 2) { mp[1] += ix.coef[j] * f.step[0]; mp[2] += ix.coef[j] * f.step[1]; }
         else mp[2] += ix.coef[j] * f.step[0];
+        if (t.nd > lead) mp[3] += ix.coef[j] * f.step[lead];
       }
       out.push_back(mp);
     }
     return true;
   };
   auto is_line = [](const Group &g) { return g.grid_id > 0 && g.nd == 1 && !g.flat; };
-  // lane-affine variable maps of a 1-D grid's own templates: (c at lane 0, stride)
-  auto line_maps = [&](const Group &g, std::vector<std::pair<int64_t, int64_t>> &out) {
+  auto is_sheet = [](const Group &g) { return g.grid_id > 0 && g.nd == 2 && !g.flat; };
+  // lane-affine variable maps of a grid's own templates: (c at lane 0 [row 0], lane stride, stride of the second dimension)
+  auto line_maps = [&](const Group &g, std::vector<std::array<int64_t, 3>> &out) {
     for (int ti : g.tpls) {
       if (g.folded.count(ti)) continue;
       const Template &u = m.tpl[ti];
       std::vector<Map> mm;
-      if (u.nd != 1 || !var_maps(u, mm)) continue;
-      const int64_t sh = g.lo[0] - u.origin[0];
-      for (const Map &mp : mm) if (mp[2] != 0) out.emplace_back(mp[0] + mp[2] * sh, mp[2]);
+      if (u.nd != g.nd || !var_maps(u, 1, mm)) continue;
+      const int64_t sh0 = g.lo[0] - u.origin[0], sh1 = g.nd == 2 ? g.lo[1] - u.origin[1] : 0;
+      for (const Map &mp : mm) if (mp[2] != 0) out.push_back({mp[0] + mp[2] * sh0 + mp[3] * sh1, mp[2], mp[3]});
     }
   };
-  // 1. full boxes (fold_n nodes x ne elements, all templates of the flat group): they decide fold_n and fold_off by vote
+  // 1. full boxes (fold_n nodes x ne elements [x the second dimension of a 2-D grid], all templates of the flat group):
+  // they decide fold_n and fold_off by vote
   for (size_t fi = 0; fi < groups.size(); ++fi) {
     const Group &F = groups[fi];
-    if (F.grid_id <= 0 || !F.flat || F.nd != 2 || F.ext[0] < 2 || F.ext[0] > max_n || F.ext[1] < 1 || F.fold_n > 0) continue;
+    if (F.grid_id <= 0 || !F.flat || (F.nd != 2 && F.nd != 3) || F.ext[0] < 2 || F.ext[0] > max_n || F.ext[1] < 1 || F.fold_n > 0) continue;
     const int64_t n = F.ext[0], ne = F.ext[1];
     bool full = true;
     std::vector<Map> fm;
     for (int ti : F.tpls) {
       const Template &t = m.tpl[ti];
-      if (t.nd != 2 || t.dims[0] != n || t.dims[1] != ne || t.origin[0] != F.lo[0] || t.origin[1] != F.lo[1] || !var_maps(t, fm)) full = false;
+      if (t.nd != F.nd || !var_maps(t, 2, fm)) { full = false; break; }
+      for (int d = 0; d < F.nd; ++d) if (t.dims[d] != F.ext[d] || t.origin[d] != F.lo[d]) full = false;
+      // (a box on a 2-D grid: every integer field must advance by whole elements — fold_aff has no element coordinate there)
+      if (F.nd == 3) for (const FieldDesc &f : t.ifields) if (f.step[1] % n != 0) full = false;
+      if (F.nd == 3) for (const FieldDesc &f : t.ffields) if (f.step[1] % n != 0) full = false;
     }
     if (!full) continue;
-    std::map<std::pair<size_t, int64_t>, int64_t> votes;   // (line group, offset) -> matching maps
+    std::map<std::pair<size_t, int64_t>, int64_t> votes;   // (target group, offset) -> matching maps
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       const Group &G = groups[gi];
-      if (!is_line(G) || (G.fold_n > 0 && G.fold_n != n) || G.ext[0] < n * ne) continue;
-      std::vector<std::pair<int64_t, int64_t>> gm;
+      if (!(F.nd == 2 ? is_line(G) : is_sheet(G)) || (G.fold_n > 0 && G.fold_n != n) || G.ext[0] < n * ne) continue;
+      if (F.nd == 3 && (F.lo[2] < G.lo[1] || F.lo[2] + F.ext[2] > G.lo[1] + G.ext[1])) continue;   // the box's last dimension lies on the grid's second
+      std::vector<std::array<int64_t, 3>> gm;
       line_maps(G, gm);
       for (const Map &mp : fm) {
         if (mp[1] == 0 || mp[2] != n * mp[1]) continue;   // the row's own node: full stride
         for (auto &cg : gm) {
-          if (cg.second != mp[1] || (mp[0] - cg.first) % mp[1] != 0) continue;
-          const int64_t off = (mp[0] - cg.first) / mp[1];
+          if (cg[1] != mp[1] || cg[2] != mp[3]) continue;
+          const int64_t c = mp[0] + (F.nd == 3 ? mp[3] * (G.lo[1] - F.lo[2]) : 0);     // the box's map at the grid's row 0
+          if ((c - cg[0]) % mp[1] != 0) continue;
+          const int64_t off = (c - cg[0]) / mp[1];
           if (off < 0 || off + n * ne > G.ext[0] || (G.fold_n > 0 && off != G.fold_off)) continue;
           ++votes[{gi, off}];
         }
@@ -2052,31 +2098,31 @@ void fold_groups(const Model &m, std::vector<Group> &groups, int max_n, bool par
     --fi;
   }
   if (!partial) return;
-  // 2. element lists and narrower boxes whose variable maps advance by fold_n entries of a slab of the line per element
+  // 2. element lists and narrower boxes whose variable maps advance by fold_n entries of a slab of a (1-D) line per element
   for (size_t fi = 0; fi < groups.size(); ++fi) {
     const Group &F = groups[fi];
     if (F.grid_id <= 0 || F.fold_n > 0 || F.nd > 2 || (F.nd == 2 && !F.flat) || F.ext[2] != 1) continue;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
       Group &G = groups[gi];
-      if (gi == fi || G.fold_n == 0) continue;
+      if (gi == fi || G.fold_n == 0 || G.nd != 1) continue;
       const int64_t n = G.fold_n, w = F.nd == 2 ? F.ext[0] : 1, ne = F.nd == 2 ? F.ext[1] : F.ext[0];
       if (w >= n || ne < 1 || n * ne > G.ext[0] + n) continue;
-      std::vector<std::pair<int64_t, int64_t>> gm;
+      std::vector<std::array<int64_t, 3>> gm;
       line_maps(G, gm);
       bool fits = true;
       for (int ti : F.tpls) {
         const Template &t = m.tpl[ti];
         std::vector<Map> fm;
         int64_t tw = t.nd == 2 ? t.dims[0] : 1, tne = t.nd == 2 ? t.dims[1] : t.dims[0];
-        if (t.nd != F.nd || tw != w || tne != ne || !var_maps(t, fm) || fm.empty()) { fits = false; break; }
+        if (t.nd != F.nd || tw != w || tne != ne || !var_maps(t, t.nd, fm) || fm.empty()) { fits = false; break; }
         for (const Map &mp : fm) {
           bool hit = false;
           if (mp[2] != 0 && mp[2] % n == 0)
             for (auto &cg : gm) {
-              if (cg.second != mp[2] / n || (mp[0] - cg.first) % cg.second != 0) continue;
+              if (cg[1] != mp[2] / n || (mp[0] - cg[0]) % cg[1] != 0 || mp[1] % cg[1] != 0) continue;
               // owner lanes of the corner items lie on the line
-              const int64_t l0 = (mp[0] - cg.first) / cg.second, l1 = l0 + (mp[1] * (w - 1)) / cg.second + n * (ne - 1);
-              if (mp[1] % cg.second == 0 && l0 >= 0 && l1 < G.ext[0] && std::min(l0, l1) >= 0 && std::max(l0, l1) < G.ext[0]) hit = true;
+              const int64_t l0 = (mp[0] - cg[0]) / cg[1], l1 = l0 + (mp[1] * (w - 1)) / cg[1] + n * (ne - 1);
+              if (std::min(l0, l1) >= 0 && std::max(l0, l1) < G.ext[0]) hit = true;
             }
           if (!hit) { fits = false; break; }
         }
@@ -2301,7 +2347,7 @@ Program generate(const Model &m, const Options &opt_in) {
             const IdxVal &iv = kb->idxvals()[outs[oi].grad_idx[s]];
             GSlot gs{kind, (int)builders.size(), (int)oi, (int)s, 0, 0, false, false, iv.aff, iv.ind.empty()};
             // a folded group derives q1, q2 from the lane: a destination that still depends on them is not an interval of the lane
-            if (g.fold_n > 0 && (iv.aff.k[1] != 0 || iv.aff.k[2] != 0)) gs.pure = false;
+            if (g.fold_n > 0 && ((g.nd == 1 && iv.aff.k[1] != 0) || iv.aff.k[2] != 0)) gs.pure = false;
             for (int d = 0; d < 3; ++d) { gs.box_lo[d] = scalar ? 0 : outs[oi].qlo[d]; gs.box_n[d] = box_n[d]; if (!scalar && outs[oi].qhi[d] <= outs[oi].qlo[d]) gs.empty = true; }
             gs.count = gs.empty ? 0 : box_items;
             if (gs.pure) {
@@ -2455,7 +2501,9 @@ Program generate(const Model &m, const Options &opt_in) {
             int64_t c1 = q[1], c2 = q[2];
             if (g.fold_n > 0) {   // derived coordinates; a pinned clone's items sit on the lanes with q2 == K
               const int64_t l = q[0] - g.fold_off;
-              c1 = (l >= 0 ? l : l - (g.fold_n - 1)) / g.fold_n; c2 = l - g.fold_n * c1;
+              const int64_t el = (l >= 0 ? l : l - (g.fold_n - 1)) / g.fold_n;
+              c2 = l - g.fold_n * el;
+              if (g.nd == 1) c1 = el;      // (a 2-D grid keeps its own q1)
               if (o.fold == 2 && c2 != o.pin_K) continue;
             }
             int64_t d = iv.aff.c + iv.aff.k[0] * q[0] + iv.aff.k[1] * c1 + iv.aff.k[2] * c2;
@@ -2468,7 +2516,7 @@ Program generate(const Model &m, const Options &opt_in) {
             }
             if (d < 0 || d >= m.nvar) throw std::runtime_error("scatter destination out of range");
             dest_of.push_back(d);
-            if (pos_of) pos_of->push_back(park + (o.scalar ? 0 : g.fold_n > 0 ? q[0] : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
+            if (pos_of) pos_of->push_back(park + (o.scalar ? 0 : q[0] + g.ext[0] * (q[1] + g.ext[1] * q[2])));
           }
       return o.scalar ? (int64_t)1 : g.ext[0] * g.ext[1] * g.ext[2];
     };

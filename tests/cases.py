@@ -172,6 +172,7 @@ def small_cases():
         "pandemic_20x3": lambda: workloads.pandemic(20, 3),
         "pandemic_300x7": lambda: workloads.pandemic(300, 7),
         "pandemic_oc3_20x3": lambda: workloads.pandemic(20, 3, collocation=3),    # examples/pandemic.jl: collocation x scenarios (node x element x scenario boxes)
+        "pandemic_oc3_40x3": lambda: workloads.pandemic(40, 3, collocation=3),    # ... with a time axis of more than 64 supports: a 2-D grid the boxes are folded onto
         "farmer_1": lambda: workloads.farmer(1),
         "farmer_5": lambda: workloads.farmer(5),
         "farmer_1000": lambda: workloads.farmer(1000),

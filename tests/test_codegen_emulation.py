@@ -329,7 +329,7 @@ def test_no_float_atomics_remain(name, grid_mode):
         assert n_atomics[1] < n_atomics[0]
 
 
-@pytest.mark.parametrize("name", ["quadrotor_oc3_40", "quadrotor_oc3_700", "kinetic_20", "hovercraft_oc4"])
+@pytest.mark.parametrize("name", ["quadrotor_oc3_40", "quadrotor_oc3_700", "kinetic_20", "hovercraft_oc4", "pandemic_oc3_40x3"])
 def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
     """`fold_colloc` (default 1): the scatter kinds evaluate the node x element boxes of orthogonal-collocation derivative
     rows — and the element lists of constant_over_collocation — on the lanes of the support grid itself; every addend of a
@@ -337,6 +337,7 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
     is computed by the lane that owns the entry, summed in registers with the grid's own rows and stored ONCE.  Nothing of
     jtprod! is left for float atomics, the gather plan or a zero fill on the uniform-grid models; what remains on the
     hovercraft are its point constraints and way-points (a few items against many: deferred, as without collocation).
+    examples/pandemic.jl: node x element x scenario boxes on the 2-D t x xi grid.
     fold_colloc = 2 (the default) puts the full boxes on the support lanes for EVERY kind: same values, same COO positions
     as with 1."""
     from infiniteexamodels.jl_amd import lib as iemlib
@@ -351,11 +352,11 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
         before = count(iemlib.emit_source(blob)[0])
     with iemlib.options(det_scatter=0):
         em0 = EmulatedModel(core, blob)
-    assert count(em0.source) < before / 4
+    assert count(em0.source) < before / (2 if name.startswith("pandemic") else 4)     # (pandemic: the u(t) column and the initial conditions remain)
     assert _rel(em0.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
     em = EmulatedModel(core, blob)
     plan = iemlib.emit_launch_plan(blob)
-    if name != "hovercraft_oc4":
+    if name not in ("hovercraft_oc4", "pandemic_oc3_40x3"):     # (pandemic: u(t) is written from the t x xi grid AND by the rows that hold it constant over an element, on the t grid)
         assert count(em0.source) == 0 and "\ngather " not in plan and "\nzero 6 " not in plan
     assert "q2 == " in em.source                       # pinned clones: node K of an element evaluates row J
     assert _rel(em.grad(x), om.grad(x)) <= 1e-13

@@ -575,7 +575,8 @@ def test_raw_loop_forms_agree(name, torch_cuda):
 
 @pytest.mark.parametrize("name,builder", [("quadrotor_oc3", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).quadrotor(40_000, collocation=3)),
                                           ("kinetic", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).kinetic_control(30_000)),
-                                          ("hovercraft_oc4", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).hovercraft(20_001, collocation=4))])
+                                          ("hovercraft_oc4", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).hovercraft(20_001, collocation=4)),
+                                          ("pandemic_oc3", lambda: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).pandemic(3_000, 12, collocation=3))])
 def test_collocation_fold_variants_on_gpu(name, builder, torch_cuda):
     """`fold_colloc` on grids of > 64 workgroups (the lane-fused shape): 1 (default) = the derivative rows of an
     orthogonal-collocation model ride on the support lanes for grad! / jtprod! / hprod! (exclusive stores, no gather

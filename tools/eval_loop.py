@@ -59,6 +59,9 @@ def measure(args):
     elif args.workload == "kinetic":
         im = workloads.kinetic_control(args.supports)
         desc = f"kinetic control (examples/kinetic_control.jl), OrthogonalCollocation(4), {args.supports} public supports"
+    elif args.workload == "pandemic_oc3":
+        im = workloads.pandemic(args.nt, args.nxi, collocation=3)
+        desc = f"pandemic SIR, examples/pandemic.jl variant (OrthogonalCollocation(3), u constant over elements), Nt={args.nt + 10} public x Nxi={args.nxi}"
     elif args.workload == "quadrotor_oc3":
         im = workloads.quadrotor(args.supports, collocation=3)
         desc = f"quadrotor ESCAPE34 variant (OrthogonalCollocation(3), piecewise-constant controls), {args.supports} public supports"
