@@ -1821,7 +1821,7 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double
     A.s = s;
     const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
     if ((rc = kkt_launch(m, km->elim, A, n_elim, wg)) != IEM_OK) return rc;
-    if ((rc = kkt_launch(m, km->upd, A, n_surv, 256)) != IEM_OK) return rc;
+    if ((rc = kkt_launch(m, km->upd, A, n_surv, nc <= 8 ? 64u : nc <= 16 ? 128u : 256u)) != IEM_OK) return rc;   // KKT_TU
   }
   A.final_block = 1;
   return kkt_launch(m, km->elim, A, 1, wg);

@@ -382,7 +382,7 @@ extern "C" __global__ __launch_bounds__(KKT_T) KKT_OCC void kkt_eliminate(const 
 //        D_j[R, R] -= Bt_j Dp[C, C] Bt_j'        D_j[C, C] -= Bt_q' Dq[R, R] Bt_q        Bt_j <- -Bt_j Dp[C, R] Bt_p
 //        E_j[R, :] -= Bt_j Z_p[C, :]             E_j[C, :] -= Bt_q' Z_q[R, :]
 // A handful of KKT_NC^3 products on gathered sub-blocks: 64 .. 256 threads, everything through LDS.
-#define KKT_TU 256
+#define KKT_TU (KKT_NC <= 8 ? 64 : KKT_NC <= 16 ? 128 : 256)      // a thread per element of an NC x NC product, up to 256
 extern "C" __global__ __launch_bounds__(KKT_TU) void kkt_update(const KktArgs A) {
   __shared__ double Bj[KKT_NC * KKT_LN], Bo[KKT_NC * KKT_LN], G1[KKT_NC * KKT_LN], G2[KKT_NC * KKT_LN], T1[KKT_NC * KKT_LN], T2[KKT_NC * KKT_LN],
       BN[KKT_NC * KKT_LN];
