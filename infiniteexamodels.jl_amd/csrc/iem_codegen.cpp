@@ -2425,7 +2425,9 @@ Program generate(const Model &m, const Options &opt_in) {
     auto is_small = [&](const GSlot &b) { return b.pure && b.count > 0 && b.count <= 65536 && b.count * 32 <= maxcount[b.kind]; };
     for (size_t i = 0; i < gslots.size(); ++i) {
       const GSlot &a = gslots[i];
-      if (shared_dest[i] || !a.pure || !a.injective || a.count == 0 || is_small(a)) continue;
+      // (a sum over a non-lane axis is written once per entry by iem_axis_sum_kernel: the few items that also reach its entries
+      //  — pandemic with collocation: the rows that hold u constant over an element — are added behind it, like behind a store)
+      if (shared_dest[i] || !a.pure || !(a.injective || (a.axis_ok && opt.det_axis)) || a.count == 0 || is_small(a)) continue;
       bool big_clash = false;
       std::vector<size_t> smalls;
       for (size_t j = 0; j < gslots.size() && !big_clash; ++j) {

@@ -352,7 +352,7 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
         before = count(iemlib.emit_source(blob)[0])
     with iemlib.options(det_scatter=0):
         em0 = EmulatedModel(core, blob)
-    assert count(em0.source) < before / (2 if name.startswith("pandemic") else 4)     # (pandemic: the u(t) column and the initial conditions remain)
+    assert count(em0.source) < before / (2 if name.startswith("pandemic") else 4)     # (pandemic: the rows that hold u(t) constant and the initial conditions remain — deferred with the default options)
     assert _rel(em0.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
     em = EmulatedModel(core, blob)
     plan = iemlib.emit_launch_plan(blob)
