@@ -358,7 +358,7 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
     plan = iemlib.emit_launch_plan(blob)
     if name not in ("hovercraft_oc4", "pandemic_oc3_40x3"):     # (pandemic: u(t) is written from the t x xi grid AND by the rows that hold it constant over an element, on the t grid)
         assert count(em0.source) == 0 and "\ngather " not in plan and "\nzero 6 " not in plan
-    assert "q2 == " in em.source                       # pinned clones: node K of an element evaluates row J
+    assert " && qe >= " in em.source                   # pinned clones: node K of an element evaluates row J
     assert _rel(em.grad(x), om.grad(x)) <= 1e-13
     assert _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
     assert _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
@@ -370,6 +370,35 @@ def test_collocation_rows_are_folded_onto_the_support_lanes(name, grid_mode):
     assert _rel(em2.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-13
     assert _rel(em2.jprod(x, v), om.jprod(x, v)) <= 1e-13 and _rel(em2.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
     assert abs(em2.obj(x) - om.obj(x)) <= 1e-13 * max(1.0, abs(om.obj(x)))
+
+
+@pytest.mark.parametrize("order", [4, 6, 8])
+@pytest.mark.parametrize("family", ["quadrotor", "pandemic"])
+def test_fold_across_collocation_orders(family, order, lane_fused):
+    """OrthogonalCollocation(order) has order - 1 rows per element: the fold and its pinned clones for 3, 5 rows (a clone per
+    row and node: 9, 25 of them per derivative), and the plan-driven gather beyond `fold_max_n` = 6 rows — on a 1-D grid
+    (quadrotor) and on a 2-D one (pandemic: collocation x scenarios).  Every kind against the oracle."""
+    from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
+    im = workloads.quadrotor(40, collocation=order) if family == "quadrotor" else workloads.pandemic(30, 3, collocation=order)
+    core = transcribe.exa_core(im)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    em = EmulatedModel(core, blob)
+    plan = iemlib.emit_launch_plan(blob)
+    rng = np.random.default_rng(order)
+    x = np.abs(om.x0 + 0.1 * rng.standard_normal(om.nvar)) + 0.05
+    y, v, vc = rng.standard_normal(om.ncon), rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
+    assert _rel(em.cons(x), om.cons(x)) <= 1e-13 and _rel(em.jac_coord(x, om.nnzj), om.jac_coord(x)) <= 1e-13
+    assert _rel(em.hess_coord(x, y, 0.7, om.nnzh), om.hess_coord(x, y, 0.7)) <= 1e-13
+    assert _rel(em.jprod(x, v), om.jprod(x, v)) <= 1e-13 and _rel(em.jtprod(x, vc), om.jtprod(x, vc)) <= 1e-13
+    assert _rel(em.grad(x), om.grad(x)) <= 1e-13 and _rel(em.hprod(x, y, v, 0.7), om.hprod(x, y, v, 0.7)) <= 1e-13
+    folded = " && qe >= " in em.source          # the guard of a pinned clone
+    assert folded == (order - 1 <= 6)
+    parked = sum(int(l.split()[3]) for l in plan.splitlines() if l.startswith("gather 6 "))
+    if folded and family == "quadrotor":
+        assert parked == 0
+    if not folded:
+        assert parked > 1000          # (the rows of every element through the plan)
 
 
 def test_a_few_items_against_many_are_deferred(lane_fused):
