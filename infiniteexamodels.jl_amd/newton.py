@@ -1,0 +1,157 @@
+"""A device-resident Lagrange–Newton solver for the solver slot of ``ExaTranscriptionBackend``.
+
+The reference hands its ``ExaModel`` to MadNLP (+ CUDSS) or Ipopt (``/root/reference/README.md:36-37``,
+``ext/InfiniteExaModelsMadNLP.jl:41-66``); per iteration such a solver calls ``obj, grad!, cons!, jac_coord!, hess_coord!``
+and factorises the augmented system once.  For EQUALITY-constrained models without variable bounds — the quadrotor and
+hovercraft tracking problems of the reference's examples — that iteration is all there is to the method: Newton on the KKT
+conditions ``∇f + J'y = 0, c(x) = c_E`` with the regularised system ``[H + δw I, J'; J, −δc I]``, the inertia correction
+interior-point codes use (δw grows until the factorisation reports ``ncon`` negative pivots) and backtracking on the KKT
+residual.  Everything stays on the device: the five evaluation calls, the CSR assembly (``kkt.KKTSystem``), the chain KKT
+factorisation and solve (``kkt_chain.ChainKKT``); the host sees a few scalars per iteration.
+
+Models with bounds or inequality rows are REFUSED (an interior-point method is a different project — DESIGN.md §9); models
+whose supports do not form a chain fall back to a dense factorisation when small, and are refused otherwise.
+
+    backend = ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8), backend=MI355XBackend())
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, List
+
+import numpy as np
+
+
+@dataclass
+class NewtonResult:
+    solution: Any                 # x (device tensor)
+    multipliers: Any              # y:  ∇f(x) + J(x)'y = 0
+    objective: float
+    iterations: int
+    status: str                   # "first_order" | "max_iter" | "small_step"
+    kkt_residual: float
+    elapsed_s: float
+    history: List[Dict[str, Any]] = field(default_factory=list)
+
+
+class _Dense:
+    """models without a chain (finite-parameter problems): the assembled matrix as a dense one"""
+
+    def __init__(self, kkt):
+        self.kkt = kkt
+
+    def load(self):
+        import torch
+        k = self.kkt
+        rp, ci = k.rowptr.to(torch.int64), k.colind.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(k.n, device=k.vals.device), rp[1:] - rp[:-1])
+        self.A = torch.zeros(k.n, k.n, dtype=torch.float64, device=k.vals.device).index_put_((rows, ci), k.vals, accumulate=True)
+        return self
+
+    def factor(self):
+        return self
+
+    def inertia(self):
+        import torch
+        ev = torch.linalg.eigvalsh(self.A)
+        neg = int((ev < 0).sum().item())
+        return self.kkt.n - neg, neg, int((ev.abs() <= 1e-14 * max(1.0, float(ev.abs().max().item()))).sum().item())
+
+    def solve(self, rhs, refine: int = 1):
+        import torch
+        x = torch.linalg.solve(self.A, rhs)
+        for _ in range(refine):
+            x = x + torch.linalg.solve(self.A, rhs - self.A @ x)
+        return x
+
+
+class LagrangeNewtonSolver:
+    """``solver(model, x0, y0, **options) -> NewtonResult`` — the callable ``ExaTranscriptionBackend`` expects."""
+
+    def __init__(self, tol: float = 1e-8, max_iter: int = 50, delta_w: float = 1e-8, delta_c: float = 1e-10, refine: int = 1,
+                 dense_limit: int = 3000, log=None):
+        self.opt = dict(tol=tol, max_iter=max_iter, delta_w=delta_w, delta_c=delta_c, refine=refine, dense_limit=dense_limit, log=log)
+
+    def __call__(self, model, x0=None, y0=None, **options) -> NewtonResult:
+        import torch
+        from . import lib as _lib
+        from .kkt import KKTSystem
+        from .kkt_chain import ChainKKT
+        o = dict(self.opt); o.update(options)
+        t_start = time.perf_counter()
+        meta = model.meta
+        n, m = meta.nvar, meta.ncon
+        if np.isfinite(meta.lvar).any() or np.isfinite(meta.uvar).any() or not np.array_equal(meta.lcon, meta.ucon):
+            raise _lib.IemError("LagrangeNewtonSolver: the model has variable bounds or inequality rows; this solver takes equality-constrained "
+                                "models only (an interior-point method is not part of this package)")
+        dev = model.device
+        kkt = KKTSystem(model)
+        try:
+            lin = ChainKKT(kkt)
+        except _lib.IemError:
+            if kkt.n > int(o["dense_limit"]):
+                kkt.close()
+                raise
+            lin = _Dense(kkt)
+        T = lambda a: a.to(dev, torch.float64).clone() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev).clone()
+        x = T(meta.x0 if x0 is None else x0)
+        y = torch.zeros(m, dtype=torch.float64, device=dev) if y0 is None else T(y0)
+        ceq = T(meta.lcon)
+        g, c, jtv = torch.empty_like(x), torch.empty(m, dtype=torch.float64, device=dev), torch.empty_like(x)
+        jv = torch.empty(meta.nnzj, dtype=torch.float64, device=dev)
+        hv = torch.empty(meta.nnzh, dtype=torch.float64, device=dev)
+
+        def residual(xx, yy):
+            model.grad(xx, g); model.cons(xx, c); model.jtprod(xx, yy, jtv)
+            return torch.cat([g + jtv, c - ceq])
+
+        hist: List[Dict[str, Any]] = []
+        status, stalled = "max_iter", 0
+        r = residual(x, y)
+        rn = float(r.abs().max().item())
+        it = 0
+        for it in range(int(o["max_iter"]) + 1):
+            rn = float(r.abs().max().item())
+            hist.append(dict(iter=it, kkt_residual=rn, obj=model.obj(x)))
+            if o["log"]:
+                o["log"](hist[-1])
+            if rn <= o["tol"]:
+                status = "first_order"
+                break
+            if it == int(o["max_iter"]):
+                break
+            t0 = time.perf_counter()
+            model.jac_hess_coord(x, y, jv, hv, obj_weight=1.0)
+            # inertia correction as in Ipopt / MadNLP: the factorisation reports the pivot signs; while they are not
+            # (nvar, ncon, 0) the Hessian block is shifted by a growing delta_w and the system factorised again
+            dw, tries = float(o["delta_w"]), 0
+            while True:
+                kkt.assemble(hv, jv, None, dw, float(o["delta_c"]))
+                lin.load().factor()
+                pos, neg, doubtful = lin.inertia()
+                tries += 1
+                if (neg == m and doubtful == 0) or tries >= 12:
+                    break
+                dw = max(1e-4, dw * 10.0)
+            d = lin.solve(-r, refine=int(o["refine"]))
+            dx, dy = d[:n], d[n:]
+            step, rt = 1.0, None
+            for _ in range(24):                               # backtracking on the KKT residual
+                rt = residual(x + step * dx, y + step * dy)
+                if float(rt.abs().max().item()) < rn:
+                    stalled = 0
+                    break
+                step *= 0.5
+            else:                                             # no decrease down to 1e-7 of the step: take it (the next
+                stalled += 1                                  # linearisation differs), give up after three in a row
+                if stalled >= 3:
+                    status = "small_step"
+                    break
+            x, y, r = x + step * dx, y + step * dy, rt
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            hist[-1].update(step=step, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw, factorisations=tries)
+        kkt.close()
+        return NewtonResult(solution=x, multipliers=y, objective=float(hist[-1]["obj"]), iterations=it, status=status, kkt_residual=rn,
+                            elapsed_s=time.perf_counter() - t_start, history=hist)

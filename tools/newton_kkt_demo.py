@@ -20,57 +20,11 @@ from infiniteexamodels.jl_amd.model import ExaModel
 
 
 def newton(gm, iters=12, delta_w=1e-8, delta_c=1e-10, tol=1e-8, log=None):
-    """Returns (x, y, history); every vector stays on the device."""
-    n, m = gm.meta.nvar, gm.meta.ncon
-    kkt = KKTSystem(gm)
-    ck = ChainKKT(kkt)
-    dev = gm.device
-    x = torch.tensor(gm.meta.x0, device=dev)
-    y = torch.zeros(m, dtype=torch.float64, device=dev)
-    lcon = torch.tensor(gm.meta.lcon, device=dev)      # equality rows: lcon == ucon
-    g, c = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev)
-    jv, hv = torch.empty(gm.meta.nnzj, dtype=torch.float64, device=dev), torch.empty(gm.meta.nnzh, dtype=torch.float64, device=dev)
-    jtv = torch.empty(n, dtype=torch.float64, device=dev)
-    hist = []
-
-    def residual(x, y):
-        gm.grad(x, g); gm.cons(x, c); gm.jtprod(x, y, jtv)
-        return torch.cat([g + jtv, c - lcon])
-
-    r = residual(x, y)
-    for it in range(iters):
-        rn = float(r.abs().max().item())
-        hist.append(dict(iter=it, kkt_residual=rn, obj=gm.obj(x)))
-        if log:
-            log(hist[-1])
-        if rn <= tol:
-            break
-        t0 = time.perf_counter()
-        gm.jac_hess_coord(x, y, jv, hv, obj_weight=1.0)
-        # inertia correction as in Ipopt / MadNLP: the factorisation reports the pivot signs; while they are not
-        # (nvar, ncon, 0) the Hessian block is shifted by a growing delta_w and the system factorised again
-        dw, tries = delta_w, 0
-        while True:
-            kkt.assemble(hv, jv, None, dw, delta_c)
-            ck.load().factor()
-            pos, neg, doubtful = ck.inertia()
-            tries += 1
-            if (neg == m and doubtful == 0) or tries >= 12:
-                break
-            dw = max(1e-4, dw * 10.0)
-        d = ck.solve(-r, refine=1)
-        dx, dy = d[:n], d[n:]
-        step = 1.0
-        for _ in range(20):                               # backtracking on the KKT residual
-            rt = residual(x + step * dx, y + step * dy)
-            if float(rt.abs().max().item()) < rn or step < 1e-6:
-                break
-            step *= 0.5
-        x, y, r = x + step * dx, y + step * dy, rt
-        torch.cuda.synchronize()
-        hist[-1].update(step=step, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw, factorisations=tries)
-    kkt.close()
-    return x, y, hist
+    """Returns (x, y, history); every vector stays on the device.  (The method itself lives in the package:
+    ``infiniteexamodels.jl_amd.newton.LagrangeNewtonSolver`` — what ``ExaTranscriptionBackend`` takes in its solver slot.)"""
+    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    res = LagrangeNewtonSolver(tol=tol, max_iter=iters, delta_w=delta_w, delta_c=delta_c, log=log)(gm)
+    return res.solution, res.multipliers, res.history
 
 
 if __name__ == "__main__":
