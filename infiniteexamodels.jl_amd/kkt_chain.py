@@ -302,12 +302,20 @@ class ChainKKT:
         n = self.layout.nvar + self.layout.ncon
         return n - neg, neg, int(info[1])
 
-    def solve(self, rhs, refine: int = 1):
+    def solve(self, rhs, refine=1, rtol: float = 1e-9):
         """``K x = rhs`` (device tensor of length ``nvar + ncon``) with the current factors; ``refine`` steps of iterative
-        refinement against the CSR matrix."""
-        t = self._torch
+        refinement against the CSR matrix — or ``refine = "auto"``: up to two steps, each only while the residual exceeds
+        ``rtol * max|rhs|`` (one product with the CSR matrix decides; a solve is eight times that)."""
         x = self._solve_once(rhs)
-        for _ in range(refine):
+        if refine == "auto":
+            bound = rtol * max(1.0, float(rhs.abs().max().item()))
+            for _ in range(2):
+                res = rhs - self._matvec(x)
+                if float(res.abs().max().item()) <= bound:
+                    break
+                x = x + self._solve_once(res)
+            return x
+        for _ in range(int(refine)):
             res = rhs - self._matvec(x)
             x = x + self._solve_once(res)
         return x

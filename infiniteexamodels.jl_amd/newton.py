@@ -58,10 +58,10 @@ class _Dense:
         neg = int((ev < 0).sum().item())
         return self.kkt.n - neg, neg, int((ev.abs() <= 1e-14 * max(1.0, float(ev.abs().max().item()))).sum().item())
 
-    def solve(self, rhs, refine: int = 1):
+    def solve(self, rhs, refine=1, rtol=0.0):
         import torch
         x = torch.linalg.solve(self.A, rhs)
-        for _ in range(refine):
+        for _ in range(1 if refine == "auto" else int(refine)):
             x = x + torch.linalg.solve(self.A, rhs - self.A @ x)
         return x
 
@@ -69,9 +69,11 @@ class _Dense:
 class LagrangeNewtonSolver:
     """``solver(model, x0, y0, **options) -> NewtonResult`` — the callable ``ExaTranscriptionBackend`` expects."""
 
-    def __init__(self, tol: float = 1e-8, max_iter: int = 50, delta_w: float = 1e-8, delta_c: float = 1e-10, refine: int = 1,
-                 dense_limit: int = 3000, log=None):
-        self.opt = dict(tol=tol, max_iter=max_iter, delta_w=delta_w, delta_c=delta_c, refine=refine, dense_limit=dense_limit, log=log)
+    def __init__(self, tol: float = 1e-8, max_iter: int = 50, delta_w: float = 1e-8, delta_c: float = 1e-10, refine="auto",
+                 linear_rtol: float = 1e-7, dense_limit: int = 3000, log=None):
+        # (refine = "auto": a linear solve is refined only while its residual exceeds linear_rtol * |rhs| — an inexact Newton step)
+        self.opt = dict(tol=tol, max_iter=max_iter, delta_w=delta_w, delta_c=delta_c, refine=refine, linear_rtol=linear_rtol,
+                        dense_limit=dense_limit, log=log)
 
     def __call__(self, model, x0=None, y0=None, **options) -> NewtonResult:
         import torch
@@ -134,7 +136,7 @@ class LagrangeNewtonSolver:
                 if (neg == m and doubtful == 0) or tries >= 12:
                     break
                 dw = max(1e-4, dw * 10.0)
-            d = lin.solve(-r, refine=int(o["refine"]))
+            d = lin.solve(-r, refine=o["refine"], rtol=float(o["linear_rtol"]))
             dx, dy = d[:n], d[n:]
             step, rt = 1.0, None
             for _ in range(24):                               # backtracking on the KKT residual
