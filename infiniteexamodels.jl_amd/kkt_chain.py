@@ -114,13 +114,13 @@ class ChainLayout:
             blk = np.where(on, (chain + phase) // R, -1)
             off = np.where(on, (chain + phase) % R, 0)
             S = int(blk.max()) + 1 if on.any() else 0
-            order = ids[np.lexsort((ids, off[ids], kind[ids], blk[ids]))]
-            g = (blk[order] * 2 + kind[order]) * R + off[order]
+            gk = (blk[ids] * 2 + kind[ids]) * R + off[ids]       # (block, kind, position in the block); ids ascend: a stable sort keeps index order
+            perm = np.argsort(gk, kind="stable")
+            order, g = ids[perm], gk[perm]
             first = np.concatenate([[True], g[1:] != g[:-1]]) if order.size else np.zeros(0, bool)
             pos = np.arange(order.size)
             ordinal = pos - np.maximum.accumulate(np.where(first, pos, 0))
-            size = np.zeros((2, R), dtype=np.int64)
-            np.maximum.at(size, (kind[order], off[order]), ordinal + 1)
+            size = np.bincount(g, minlength=S * 2 * R).reshape(S, 2, R).max(axis=0) if S else np.zeros((2, R), dtype=np.int64)   # largest (kind, position) group over the blocks
             base = np.zeros((2, R), dtype=np.int64)
             base[0] = np.concatenate([[0], np.cumsum(size[0])[:-1]])
             base[1] = size[0].sum() + np.concatenate([[0], np.cumsum(size[1])[:-1]])
