@@ -275,6 +275,38 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
                         const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
                         const double *d_xB, int phase);
+/* The same solver as ONE object — what a host without the Python layer (a Julia MadNLP linear-solver wrapper) binds.
+ * iem_kkt_create analyses the model once on the host: grouping of the unknowns (variable u, then the multiplier of row
+ * u - nvar) into chain blocks + border from the slab table and the Jacobian / Hessian structure, the narrow coupling, and a
+ * gather plan from the positions of hess_coord! / jac_coord! values to the block entries (duplicates of the COO layout are
+ * summed in a fixed order); it owns the device buffers.  Per iteration:
+ *   iem_kkt_assemble(k, d_hess, d_jac, d_sigma, delta_w, delta_c)   K = [H + diag(sigma) + delta_w I, J'; J, -delta_c I]
+ *                                                                  (d_hess / d_jac: what the handle's iem_hess_coord / iem_jac_coord
+ *                                                                   wrote; d_sigma: nvar doubles or NULL)
+ *   iem_kkt_factor(k, inertia)        block cyclic reduction + the border's Schur complement; inertia[3] = {positive, negative,
+ *                                     doubtful} pivots of K (a correctly regularised system has ncon negative ones); synchronises
+ *   iem_kkt_solve(k, d_rhs, d_sol)    K sol = rhs (nvar + ncon doubles each; no refinement — K x for a residual is
+ *                                     iem_hprod + iem_jtprod / iem_jprod + the diagonal terms)
+ * Models whose blocks / border / coupling exceed the solver's limits (96 / 64 / 48) are refused by iem_kkt_create. */
+typedef struct iem_kkt iem_kkt;
+typedef struct {
+  int64_t S, n, n_border, block_doubles;   /* blocks, unknowns, border unknowns, doubles of the block buffer D | Bt | E | G */
+  int32_t nb, ne, nc, reach, group, phase;
+} iem_kkt_info_t;
+int iem_kkt_create(iem_model *m, int group /* 0: the parameter group the stencil runs along */, iem_kkt **out);
+int iem_kkt_destroy(iem_kkt *k);
+int iem_kkt_info(const iem_kkt *k, iem_kkt_info_t *out);
+/* the grouping itself (host arrays; any of them may be NULL): block (-1: border) and place of every unknown, the coupling's rows / columns (nc each, -1 padded) */
+int iem_kkt_layout(const iem_kkt *k, int64_t *h_blk, int64_t *h_loc, int32_t *h_rows, int32_t *h_cols);
+/* the host analysis alone, from a blob (no device needed; every array malloc'ed — iem_free): the grouping as above and the
+ * gather plan  flat[dest[i]] = sum over k in [seg[i], seg[i + 1]) of source(perm[k]),  sources indexing the virtual array
+ * hess values | jac values | sigma + delta_w per variable | -delta_c per row | 1.0 (the padding's unit diagonal) */
+int iem_kkt_analyse_blob(const void *blob, size_t nbytes, int group, iem_kkt_info_t *info, int64_t **out_blk, int64_t **out_loc, int32_t **out_rows,
+                         int32_t **out_cols, int64_t **out_dest, uint32_t **out_seg, uint32_t **out_perm, int64_t *out_n_dest, int64_t *out_n_perm);
+int iem_kkt_assemble(iem_kkt *k, const double *d_hess, const double *d_jac, const double *d_sigma, double delta_w, double delta_c);
+int iem_kkt_factor(iem_kkt *k, int64_t *out_inertia);
+int iem_kkt_solve(iem_kkt *k, const double *d_rhs, double *d_sol);
+
 /* HIP source of the solver's kernels for one (nb, ne, nc) and its cache key — for offline builds (no device needed; malloc'ed) */
 int iem_kkt_source(int nb, int ne, int nc, char **out_src, uint64_t *out_key);
 

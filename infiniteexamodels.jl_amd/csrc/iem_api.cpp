@@ -24,6 +24,8 @@
 
 #include "../../include/iem.h"
 #include "iem_codegen.hpp"
+#include "iem_kkt_host.hpp"
+#include <memory>
 #include "iem_model.hpp"
 #include "iem_shard.hpp"
 
@@ -207,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_PAIR + 1] = {}, reads_halo_v[iem::KK_PAIR + 1] = {}, carrier[iem::KK_PAIR + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr; };
+  struct KktMod { hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1778,6 +1780,9 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.upd, km.mod, "kkt_update"));
     HIP_TRY(hipModuleGetFunction(&km.fwd, km.mod, "kkt_forward"));
     HIP_TRY(hipModuleGetFunction(&km.bwd, km.mod, "kkt_backward"));
+    HIP_TRY(hipModuleGetFunction(&km.gather, km.mod, "kkt_gather"));
+    HIP_TRY(hipModuleGetFunction(&km.move, km.mod, "kkt_move"));
+    HIP_TRY(hipModuleGetFunction(&km.colsum, km.mod, "kkt_colsum"));
     it = m->kkt_mods.emplace(std::make_pair(nb, ne * 64 + nc), km).first;
   }
   *out = &it->second;
@@ -1864,6 +1869,230 @@ int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const d
     const long long n_elim = (S - s + 2 * s - 1) / (2 * s);
     if ((rc = kkt_launch_solve(m, km->bwd, A, n_elim, 64)) != IEM_OK) return rc;
   }
+  return IEM_OK;
+}
+
+/* ---- the chain KKT solver as ONE object behind the C-ABI (what a host without the Python layer binds) ---------------------- */
+struct iem_kkt {
+  iem_model *m = nullptr;
+  iem::KktLayout L;
+  iem_model::KktMod *km = nullptr;
+  double *d_flat = nullptr, *d_BR = nullptr, *d_Z = nullptr, *d_Gp = nullptr, *d_r = nullptr, *d_z = nullptr, *d_rBp = nullptr, *d_xB = nullptr, *d_part = nullptr;
+  int32_t *d_rows = nullptr, *d_cols = nullptr;
+  long long *d_dest = nullptr, *d_on = nullptr, *d_pos = nullptr, *d_border = nullptr, *d_bloc = nullptr, *d_info = nullptr;
+  unsigned *d_seg = nullptr, *d_perm = nullptr;
+  int64_t n_dest = 0, n_on = 0, n_h = 0, n_j = 0;
+  std::vector<double> Gs;        // the border's Schur complement (host), set by iem_kkt_factor
+  bool factored = false;
+};
+
+namespace {
+int kkt_upload_bytes(void **d, const void *h, size_t bytes) {
+  HIP_TRY(hipMalloc(d, std::max<size_t>(bytes, 8)));
+  if (bytes) HIP_TRY(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+  return IEM_OK;
+}
+#define kkt_upload(dptr, vec) kkt_upload_bytes((void **)(dptr), (vec).data(), (vec).size() * sizeof((vec)[0]))
+// column sums of a device S x w matrix, to the host
+int kkt_colsum_host(iem_kkt *k, const double *d_in, int64_t rows, int64_t w, std::vector<double> &out) {
+  iem_model *m = k->m;
+  const int64_t per = 256, nwg = (rows + per - 1) / per;
+  struct { const double *in; double *out; long long rows, w, rows_per_wg; } A{d_in, k->d_part, (long long)rows, (long long)w, (long long)per};
+  int rc = kkt_launch_raw(m, k->km->colsum, &A, sizeof A, nwg, 256);
+  if (rc) return rc;
+  std::vector<double> part((size_t)(nwg * w));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipMemcpy(part.data(), k->d_part, part.size() * 8, hipMemcpyDeviceToHost));
+  out.assign((size_t)w, 0.0);
+  for (int64_t b = 0; b < nwg; ++b) for (int64_t c = 0; c < w; ++c) out[(size_t)c] += part[(size_t)(b * w + c)];
+  return IEM_OK;
+}
+}  // namespace
+
+int iem_kkt_analyse_blob(const void *blob, size_t nbytes, int group, iem_kkt_info_t *info, int64_t **out_blk, int64_t **out_loc, int32_t **out_rows,
+                         int32_t **out_cols, int64_t **out_dest, uint32_t **out_seg, uint32_t **out_perm, int64_t *out_n_dest, int64_t *out_n_perm) {
+  if (!blob || !info) return fail(IEM_E_ARG, "null argument");
+  try {
+    iem::Model M;
+    iem::parse_blob(blob, nbytes, M);
+    std::vector<int64_t> jr((size_t)M.nnzj), jc((size_t)M.nnzj), hr((size_t)M.nnzh), hc((size_t)M.nnzh);
+    jac_structure_host(M, jr.data(), jc.data(), 0);
+    hess_structure_host(M, hr.data(), hc.data(), 0);
+    iem::KktLayout L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 64, 48);
+    iem::KktPlan P = iem::kkt_plan(L, hr, hc, jr, jc);
+    info->S = L.S; info->n = L.nvar + L.ncon; info->n_border = L.n_border; info->nb = L.nb; info->ne = L.ne; info->nc = L.nc;
+    info->reach = L.reach; info->group = L.group; info->phase = L.phase; info->block_doubles = L.total();
+    auto dup = [](const void *src, size_t bytes) { void *p = std::malloc(std::max<size_t>(bytes, 8)); if (bytes) std::memcpy(p, src, bytes); return p; };
+    if (out_blk) *out_blk = (int64_t *)dup(L.blk.data(), L.blk.size() * 8);
+    if (out_loc) *out_loc = (int64_t *)dup(L.loc.data(), L.loc.size() * 8);
+    if (out_rows) *out_rows = (int32_t *)dup(L.rowsR.data(), L.rowsR.size() * 4);
+    if (out_cols) *out_cols = (int32_t *)dup(L.colsC.data(), L.colsC.size() * 4);
+    if (out_dest) *out_dest = (int64_t *)dup(P.dest.data(), P.dest.size() * 8);
+    if (out_seg) *out_seg = (uint32_t *)dup(P.seg.data(), P.seg.size() * 4);
+    if (out_perm) *out_perm = (uint32_t *)dup(P.perm.data(), P.perm.size() * 4);
+    if (out_n_dest) *out_n_dest = (int64_t)P.dest.size();
+    if (out_n_perm) *out_n_perm = (int64_t)P.perm.size();
+  } catch (const std::exception &e) {
+    return fail(IEM_E_ARG, e.what());
+  }
+  return IEM_OK;
+}
+
+int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
+  if (!m || !out) return fail(IEM_E_ARG, "null argument");
+  if (m->sharded) return fail(IEM_E_ARG, "iem_kkt_create: a sharded handle holds one rank's window; the chain solver wants the whole model");
+  DevGuard dg_(m->device);
+  std::unique_ptr<iem_kkt> k(new iem_kkt);
+  k->m = m;
+  try {
+    const iem::Model &M = m->model;
+    std::vector<int64_t> jr((size_t)M.nnzj), jc((size_t)M.nnzj), hr((size_t)M.nnzh), hc((size_t)M.nnzh);
+    jac_structure_host(M, jr.data(), jc.data(), 0);
+    if (m->opt.hess_merge) return fail(IEM_E_ARG, "iem_kkt_create: the merged Hessian layout is not supported here");
+    hess_structure_host(M, hr.data(), hc.data(), 0);
+    k->L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 64, 48);
+    if (!kkt_fits(k->L.nb, k->L.ne, k->L.nc)) return fail(IEM_E_ARG, "chain KKT: the tiles of a block do not fit the LDS of a CU");
+    iem::KktPlan P = iem::kkt_plan(k->L, hr, hc, jr, jc);
+    k->n_dest = (int64_t)P.dest.size(); k->n_h = P.n_h; k->n_j = P.n_j;
+    int rc = kkt_module(m, k->L.nb, k->L.ne, k->L.nc, &k->km);
+    if (rc) return rc;
+    const iem::KktLayout &L = k->L;
+    std::vector<long long> dest(P.dest.begin(), P.dest.end()), on, pos, border, bloc;
+    for (int64_t u = 0; u < L.nvar + L.ncon; ++u) {
+      if (L.blk[(size_t)u] >= 0) { on.push_back(u); pos.push_back(L.blk[(size_t)u] * L.nb + L.loc[(size_t)u]); }
+      else { border.push_back(u); bloc.push_back(L.loc[(size_t)u]); }
+    }
+    k->n_on = (int64_t)on.size();
+    if ((rc = kkt_upload(&k->d_dest, dest)) || (rc = kkt_upload(&k->d_seg, P.seg)) || (rc = kkt_upload(&k->d_perm, P.perm)) || (rc = kkt_upload(&k->d_on, on)) ||
+        (rc = kkt_upload(&k->d_pos, pos)) || (rc = kkt_upload(&k->d_border, border)) || (rc = kkt_upload(&k->d_bloc, bloc)) ||
+        (rc = kkt_upload(&k->d_rows, L.rowsR)) || (rc = kkt_upload(&k->d_cols, L.colsC)))
+      return rc;
+    const int64_t S = L.S, nb = L.nb, ne = L.ne, nc = L.nc;
+    HIP_TRY(hipMalloc((void **)&k->d_flat, (size_t)L.total() * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_BR, (size_t)std::max<int64_t>(S * nc * nc, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_Z, (size_t)std::max<int64_t>(S * nb * ne, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_Gp, (size_t)std::max<int64_t>(S * ne * ne, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_r, (size_t)(S * nb) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_z, (size_t)(S * nb) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_rBp, (size_t)std::max<int64_t>(S * ne, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_xB, (size_t)std::max<int64_t>(ne, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_part, (size_t)std::max<int64_t>(((S + 255) / 256) * std::max<int64_t>(ne * ne, 1), 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_info, 32));
+  } catch (const std::exception &e) {
+    return fail(IEM_E_ARG, e.what());
+  }
+  *out = k.release();
+  return IEM_OK;
+}
+
+int iem_kkt_destroy(iem_kkt *k) {
+  if (!k) return IEM_OK;
+  DevGuard dg_(k->m->device);
+  for (void *p : {(void *)k->d_flat, (void *)k->d_BR, (void *)k->d_Z, (void *)k->d_Gp, (void *)k->d_r, (void *)k->d_z, (void *)k->d_rBp, (void *)k->d_xB, (void *)k->d_part,
+                  (void *)k->d_rows, (void *)k->d_cols, (void *)k->d_dest, (void *)k->d_on, (void *)k->d_pos, (void *)k->d_border, (void *)k->d_bloc, (void *)k->d_info,
+                  (void *)k->d_seg, (void *)k->d_perm})
+    if (p) hipFree(p);
+  delete k;
+  return IEM_OK;
+}
+
+int iem_kkt_info(const iem_kkt *k, iem_kkt_info_t *out) {
+  if (!k || !out) return fail(IEM_E_ARG, "null argument");
+  const iem::KktLayout &L = k->L;
+  out->S = L.S; out->n = L.nvar + L.ncon; out->n_border = L.n_border; out->nb = L.nb; out->ne = L.ne; out->nc = L.nc;
+  out->reach = L.reach; out->group = L.group; out->phase = L.phase; out->block_doubles = L.total();
+  return IEM_OK;
+}
+
+int iem_kkt_layout(const iem_kkt *k, int64_t *h_blk, int64_t *h_loc, int32_t *h_rows, int32_t *h_cols) {
+  if (!k) return fail(IEM_E_ARG, "null argument");
+  const iem::KktLayout &L = k->L;
+  if (h_blk) std::copy(L.blk.begin(), L.blk.end(), h_blk);
+  if (h_loc) std::copy(L.loc.begin(), L.loc.end(), h_loc);
+  if (h_rows) std::copy(L.rowsR.begin(), L.rowsR.end(), h_rows);
+  if (h_cols) std::copy(L.colsC.begin(), L.colsC.end(), h_cols);
+  return IEM_OK;
+}
+
+int iem_kkt_assemble(iem_kkt *k, const double *d_hess, const double *d_jac, const double *d_sigma, double delta_w, double delta_c) {
+  if (!k || (!d_hess && k->n_h) || (!d_jac && k->n_j)) return fail(IEM_E_ARG, "null argument");
+  iem_model *m = k->m;
+  DevGuard dg_(m->device);
+  const iem::KktLayout &L = k->L;
+  HIP_TRY(hipMemsetAsync(k->d_flat, 0, (size_t)L.total() * 8, m->stream));
+  struct { double *flat; const long long *dest; const unsigned *seg, *perm; const double *hess, *jac, *sigma; double dw, dc; long long n_dest, n_h, n_j, n_var, n_con; } A{
+      k->d_flat, k->d_dest, k->d_seg, k->d_perm, d_hess, d_jac, d_sigma, delta_w, delta_c, (long long)k->n_dest, (long long)k->n_h, (long long)k->n_j,
+      (long long)L.nvar, (long long)L.ncon};
+  k->factored = false;
+  return kkt_launch_raw(m, k->km->gather, &A, sizeof A, (k->n_dest + 255) / 256, 256);
+}
+
+int iem_kkt_factor(iem_kkt *k, int64_t *out_inertia) {
+  if (!k) return fail(IEM_E_ARG, "null argument");
+  iem_model *m = k->m;
+  DevGuard dg_(m->device);
+  const iem::KktLayout &L = k->L;
+  const bool chained = L.reach > 0;
+  double *D = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB(), *E = k->d_flat + L.oE();
+  int rc = iem_kkt_chain_factor(m, L.S, L.nb, L.ne, L.nc, D, chained ? Bt : nullptr, chained ? k->d_BR : nullptr, chained ? k->d_rows : nullptr,
+                                chained ? k->d_cols : nullptr, E, k->d_Z, k->d_Gp, (int64_t *)k->d_info, 1e-30);
+  if (rc) return rc;
+  int64_t neg = 0, doubtful = 0;
+  if (L.ne > 0) {      // the border: G - sum_k Gp[k] on the host (ne <= 64)
+    std::vector<double> gp, G((size_t)(L.ne * L.ne));
+    if ((rc = kkt_colsum_host(k, k->d_Gp, L.S, (int64_t)L.ne * L.ne, gp))) return rc;
+    HIP_TRY(hipMemcpy(G.data(), k->d_flat + L.oG(), G.size() * 8, hipMemcpyDeviceToHost));
+    k->Gs.resize(G.size());
+    for (size_t i = 0; i < G.size(); ++i) k->Gs[i] = G[i] - gp[i];
+    std::vector<double> ev;
+    iem::sym_eigenvalues(k->Gs, L.ne, ev);
+    for (double e : ev) if (e < 0.0) ++neg;
+  }
+  long long info[3] = {0, 0, 0};
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipMemcpy(info, k->d_info, 24, hipMemcpyDeviceToHost));
+  neg += info[0]; doubtful += info[1];
+  k->factored = true;
+  if (out_inertia) { out_inertia[0] = L.nvar + L.ncon - neg; out_inertia[1] = neg; out_inertia[2] = doubtful; }
+  return IEM_OK;
+}
+
+int iem_kkt_solve(iem_kkt *k, const double *d_rhs, double *d_sol) {
+  if (!k || !d_rhs || !d_sol) return fail(IEM_E_ARG, "null argument");
+  if (!k->factored) return fail(IEM_E_ARG, "iem_kkt_solve: no factorisation (iem_kkt_assemble + iem_kkt_factor first)");
+  iem_model *m = k->m;
+  DevGuard dg_(m->device);
+  const iem::KktLayout &L = k->L;
+  const bool chained = L.reach > 0;
+  const double *Dinv = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB();
+  HIP_TRY(hipMemsetAsync(k->d_r, 0, (size_t)(L.S * L.nb) * 8, m->stream));
+  struct Mv { double *dst; const double *src; const long long *di, *si; long long n; };
+  int rc;
+  { Mv A{k->d_r, d_rhs, k->d_pos, k->d_on, (long long)k->n_on}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (k->n_on + 255) / 256, 256))) return rc; }
+  if ((rc = iem_kkt_chain_solve(m, L.S, L.nb, L.ne, L.nc, Dinv, chained ? Bt : nullptr, chained ? k->d_BR : nullptr, chained ? k->d_rows : nullptr,
+                                chained ? k->d_cols : nullptr, k->d_Z, k->d_r, chained ? k->d_z : nullptr, k->d_rBp, nullptr, 0)))
+    return rc;
+  if (L.ne > 0) {      // border system on the host: Gs xB = rB - sum_k rBp[k]
+    std::vector<double> rbp, rB((size_t)L.ne, 0.0);
+    if ((rc = kkt_colsum_host(k, k->d_rBp, L.S, L.ne, rbp))) return rc;
+    std::vector<double> rhs_b((size_t)L.n_border);
+    std::vector<long long> border((size_t)L.n_border);
+    if (L.n_border) {   // (a handful of entries: gathered through a staging vector on the device)
+      Mv A{k->d_xB, d_rhs, k->d_bloc, k->d_border, (long long)L.n_border};
+      if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (L.n_border + 255) / 256, 256))) return rc;
+      HIP_TRY(hipStreamSynchronize(m->stream));
+      HIP_TRY(hipMemcpy(rB.data(), k->d_xB, (size_t)L.n_border * 8, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < L.ne; ++i) rB[(size_t)i] = (i < L.n_border ? rB[(size_t)i] : 0.0) - rbp[(size_t)i];
+    if (!iem::dense_solve(k->Gs, L.ne, rB)) return fail(IEM_E_ARG, "iem_kkt_solve: the border's Schur complement is singular");
+    HIP_TRY(hipMemcpyAsync(k->d_xB, rB.data(), (size_t)L.ne * 8, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));      // (rB is a host temporary)
+  }
+  if ((rc = iem_kkt_chain_solve(m, L.S, L.nb, L.ne, L.nc, Dinv, chained ? Bt : nullptr, chained ? k->d_BR : nullptr, chained ? k->d_rows : nullptr,
+                                chained ? k->d_cols : nullptr, k->d_Z, k->d_r, chained ? k->d_z : nullptr, k->d_rBp, L.ne > 0 ? k->d_xB : nullptr, 1)))
+    return rc;
+  { Mv A{d_sol, k->d_r, k->d_on, k->d_pos, (long long)k->n_on}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (k->n_on + 255) / 256, 256))) return rc; }
+  if (L.n_border) { Mv A{d_sol, k->d_xB, k->d_border, k->d_bloc, (long long)L.n_border}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (L.n_border + 255) / 256, 256))) return rc; }
   return IEM_OK;
 }
 

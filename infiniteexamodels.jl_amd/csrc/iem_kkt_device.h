@@ -602,4 +602,48 @@ extern "C" __global__ __launch_bounds__(64) void kkt_backward(const KktSolveArgs
   }
 }
 
+// ---- the solver-facing entry points (iem_kkt_assemble / _solve): blocks from the COO values, right-hand sides in and out ----
+// flat[dest[i]] = sum over k in [seg[i], seg[i + 1]) of the source perm[k] — an index into the virtual array
+//   hess values | jac values | (sigma + delta_w) per variable | -delta_c per row | 1.0 (the padding's unit diagonal)
+struct KktGatherArgs {
+  double *flat;
+  const long long *dest;
+  const unsigned *seg, *perm;
+  const double *hess, *jac, *sigma;
+  double dw, dc;
+  long long n_dest, n_h, n_j, n_var, n_con;
+};
+extern "C" __global__ __launch_bounds__(256) void kkt_gather(const KktGatherArgs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.n_dest) return;
+  double acc = 0.0;
+  for (unsigned k = A.seg[i]; k < A.seg[i + 1]; ++k) {
+    long long s = A.perm[k];
+    double v;
+    if (s < A.n_h) v = A.hess[s];
+    else if ((s -= A.n_h) < A.n_j) v = A.jac[s];
+    else if ((s -= A.n_j) < A.n_var) v = (A.sigma ? A.sigma[s] : 0.0) + A.dw;
+    else if ((s -= A.n_var) < A.n_con) v = -A.dc;
+    else v = 1.0;
+    acc += v;
+  }
+  A.flat[A.dest[i]] = acc;
+}
+// r[pos[i]] = rhs[idx[i]]  (into the chain / the border)   and back:  sol[idx[i]] = r[pos[i]]
+struct KktMoveArgs { double *dst; const double *src; const long long *di, *si; long long n; };
+extern "C" __global__ __launch_bounds__(256) void kkt_move(const KktMoveArgs A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < A.n) A.dst[A.di[i]] = A.src[A.si[i]];
+}
+// column sums of an S x w matrix (per-block border terms): partial[b][c] over rows b R .. , then one more pass over the partials
+struct KktSumArgs { const double *in; double *out; long long rows, w, rows_per_wg; };
+extern "C" __global__ __launch_bounds__(256) void kkt_colsum(const KktSumArgs A) {
+  const long long r0 = (long long)blockIdx.x * A.rows_per_wg, r1 = r0 + A.rows_per_wg < A.rows ? r0 + A.rows_per_wg : A.rows;
+  for (long long c = threadIdx.x; c < A.w; c += 256) {
+    double acc = 0.0;
+    for (long long r = r0; r < r1; ++r) acc += A.in[r * A.w + c];
+    A.out[(long long)blockIdx.x * A.w + c] = acc;
+  }
+}
+
 #endif  // IEM_KKT_DEVICE_H

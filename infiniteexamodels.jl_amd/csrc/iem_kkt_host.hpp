@@ -1,0 +1,271 @@
+// iem_kkt_host.hpp — host side of the chain KKT solver behind the C-ABI (iem_kkt_create / _assemble / _factor / _solve):
+// the grouping of the augmented system's unknowns into chain blocks + border, the narrow coupling, and the gather plan
+// that fills the blocks straight from the hess_coord! / jac_coord! value arrays.
+//
+// The same analysis exists in Python (infiniteexamodels.jl_amd/kkt_chain.py: ChainLayout — where it was developed, and what
+// tests/test_kkt_cabi.py compares this file with, field for field): unknown u < nvar is variable u, u >= nvar the
+// multiplier of row u - nvar; a support of the chain's parameter group owns its variables and the rows whose LAST touched
+// support it is; blocks are `reach` supports long and start where that gives the narrowest coupling; inside a block every
+// unknown sits at a FIXED place (variables before rows, by the support's position in the block, then by index; a short
+// block leaves holes, filled with a unit diagonal); unknowns off the chain form the border.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <cmath>
+#include <set>
+#include <stdexcept>
+#include <tuple>
+#include <string>
+#include <vector>
+
+#include "iem_model.hpp"
+
+namespace iem {
+
+struct KktLayout {
+  int64_t nvar = 0, ncon = 0, S = 0, n_border = 0;
+  int nb = 0, ne = 0, nc = 4, reach = 0, group = 0, phase = 0;
+  std::vector<int64_t> blk, loc;        // per unknown: block (-1: border) and place in the block / the border
+  std::vector<int64_t> counts;          // real unknowns per block
+  std::vector<int32_t> rowsR, colsC;    // local rows (of block k) / columns (of block k - 1) of the coupling, padded with -1 to nc
+  // flat buffer D | Bt | E | G
+  int64_t oD() const { return 0; }
+  int64_t oB() const { return S * (int64_t)nb * nb; }
+  int64_t oE() const { return oB() + S * (int64_t)nc * nc; }
+  int64_t oG() const { return oE() + S * (int64_t)nb * ne; }
+  int64_t total() const { return oG() + (int64_t)ne * ne; }
+};
+
+inline int64_t ceil4(int64_t n) { return (n + 3) / 4 * 4; }
+
+// gather plan: flat[dest[i]] = sum over k in [seg[i], seg[i+1]) of source(perm[k]); sources are indices into the virtual array
+// hess values | jac values | (sigma + delta_w) per variable | -delta_c per row | 1.0 (the padding's unit diagonal)
+struct KktPlan {
+  std::vector<int64_t> dest;
+  std::vector<uint32_t> seg, perm;
+  int64_t n_h = 0, n_j = 0;
+};
+
+// (hr, hc: the Hessian's structure — an entry across two supports would widen the coupling; none of the reference's models has one)
+inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, const std::vector<int64_t> &jc, const std::vector<int64_t> &hr,
+                            const std::vector<int64_t> &hc, int want_group, int max_nb, int max_ne, int max_nc) {
+  KktLayout L;
+  L.nvar = m.nvar; L.ncon = m.ncon;
+  const int64_t nvar = m.nvar, ncon = m.ncon, n = nvar + ncon, nj = (int64_t)jr.size();
+  std::set<int> groups;
+  for (const Slab &s : m.slabs) for (int a = 0; a < s.nd; ++a) if (s.group[a] > 0) groups.insert(s.group[a]);
+  if (groups.empty()) throw std::runtime_error("chain KKT: the model has no infinite-parameter slab table (nothing to chain along)");
+  auto coords = [&](int g, std::vector<int64_t> &vc) {
+    vc.assign((size_t)nvar, -1);
+    for (const Slab &s : m.slabs)
+      for (int a = 0; a < s.nd; ++a) {
+        if (s.group[a] != g) continue;
+        int64_t stride = 1;
+        for (int d = 0; d < a; ++d) stride *= s.dims[d];
+        const int64_t len = s.length();
+        for (int64_t i = 0; i < len; ++i) vc[(size_t)(s.off + i)] = (i / stride) % s.dims[a];
+        break;
+      }
+  };
+  auto row_span = [&](const std::vector<int64_t> &vc, std::vector<int64_t> &hi, std::vector<int64_t> &lo) {
+    hi.assign((size_t)ncon, -1); lo.assign((size_t)ncon, INT64_MAX);
+    for (int64_t k = 0; k < nj; ++k) {
+      const int64_t v = vc[(size_t)jc[k]];
+      hi[(size_t)jr[k]] = std::max(hi[(size_t)jr[k]], v);
+      if (v >= 0) lo[(size_t)jr[k]] = std::min(lo[(size_t)jr[k]], v);
+    }
+    for (int64_t r = 0; r < ncon; ++r) if (lo[(size_t)r] == INT64_MAX) lo[(size_t)r] = hi[(size_t)r];
+  };
+  std::vector<int64_t> vc, hi, lo;
+  int group = want_group;
+  if (group <= 0) {
+    bool have = false;
+    std::pair<bool, int64_t> best_key;
+    for (int g : groups) {
+      std::vector<int64_t> v, h, l;
+      coords(g, v); row_span(v, h, l);
+      int64_t reach = 0, top = -1;
+      for (int64_t r = 0; r < ncon; ++r) reach = std::max(reach, h[(size_t)r] - l[(size_t)r]);
+      for (int64_t x : v) top = std::max(top, x);
+      const std::pair<bool, int64_t> key{reach > 0, top + 1};
+      if (!have || key > best_key) { have = true; best_key = key; group = g; vc.swap(v); hi.swap(h); lo.swap(l); }
+    }
+  } else {
+    coords(group, vc); row_span(vc, hi, lo);
+  }
+  L.group = group;
+  for (int64_t r = 0; r < ncon; ++r) L.reach = (int)std::max<int64_t>(L.reach, hi[(size_t)r] - lo[(size_t)r]);
+  const int64_t R = std::max(L.reach, 1);
+  std::vector<int64_t> chain((size_t)n);
+  for (int64_t i = 0; i < nvar; ++i) chain[(size_t)i] = vc[(size_t)i];
+  for (int64_t r = 0; r < ncon; ++r) chain[(size_t)(nvar + r)] = hi[(size_t)r];     // a row sits with the LAST support it touches
+  std::vector<int64_t> ids, border;
+  for (int64_t u = 0; u < n; ++u) (chain[(size_t)u] >= 0 ? ids : border).push_back(u);
+  struct Cand { std::vector<int64_t> blk, loc, counts; int nb = 0; std::vector<int64_t> rows, cols; int64_t S = 0; };
+  auto arrange = [&](int64_t phase) {
+    Cand c;
+    c.blk.assign((size_t)n, -1); c.loc.assign((size_t)n, -1);
+    std::vector<int64_t> off((size_t)n, 0);
+    for (int64_t u : ids) { c.blk[(size_t)u] = (chain[(size_t)u] + phase) / R; off[(size_t)u] = (chain[(size_t)u] + phase) % R; c.S = std::max(c.S, c.blk[(size_t)u] + 1); }
+    auto gkey = [&](int64_t u) { return (c.blk[(size_t)u] * 2 + (u >= nvar ? 1 : 0)) * R + off[(size_t)u]; };
+    std::vector<int64_t> order(ids);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return gkey(a) < gkey(b); });
+    std::vector<int64_t> ordinal(order.size(), 0), size((size_t)(2 * R), 0);
+    for (size_t i = 0; i < order.size(); ++i) {
+      if (i && gkey(order[i]) == gkey(order[i - 1])) ordinal[i] = ordinal[i - 1] + 1;
+      const int64_t u = order[i], ko = (u >= nvar ? 1 : 0) * R + off[(size_t)u];
+      size[(size_t)ko] = std::max(size[(size_t)ko], ordinal[i] + 1);
+    }
+    std::vector<int64_t> base((size_t)(2 * R), 0);
+    int64_t run = 0;
+    for (int64_t ko = 0; ko < 2 * R; ++ko) { base[(size_t)ko] = run; run += size[(size_t)ko]; }   // variables by position, then rows by position
+    for (size_t i = 0; i < order.size(); ++i) {
+      const int64_t u = order[i], ko = (u >= nvar ? 1 : 0) * R + off[(size_t)u];
+      c.loc[(size_t)u] = base[(size_t)ko] + ordinal[i];
+    }
+    for (size_t i = 0; i < border.size(); ++i) c.loc[(size_t)border[i]] = (int64_t)i;
+    c.counts.assign((size_t)c.S, 0);
+    for (int64_t u : ids) ++c.counts[(size_t)c.blk[(size_t)u]];
+    c.nb = (int)ceil4(run);
+    std::set<int64_t> rs, cs;
+    for (int64_t k = 0; k < nj; ++k) {
+      const int64_t ur = nvar + jr[k], uc = jc[k], kr = c.blk[(size_t)ur], kc = c.blk[(size_t)uc];
+      if (kr < 0 || kc < 0) continue;
+      if (kr == kc + 1) { rs.insert(c.loc[(size_t)ur]); cs.insert(c.loc[(size_t)uc]); }
+      else if (kc == kr + 1) { rs.insert(c.loc[(size_t)uc]); cs.insert(c.loc[(size_t)ur]); }
+    }
+    for (size_t k = 0; k < hr.size(); ++k) {
+      const int64_t ur = hr[k], uc = hc[k], kr = c.blk[(size_t)ur], kc = c.blk[(size_t)uc];
+      if (kr < 0 || kc < 0 || kr == kc) continue;
+      if (kr == kc + 1) { rs.insert(c.loc[(size_t)ur]); cs.insert(c.loc[(size_t)uc]); }
+      else if (kc == kr + 1) { rs.insert(c.loc[(size_t)uc]); cs.insert(c.loc[(size_t)ur]); }
+    }
+    c.rows.assign(rs.begin(), rs.end()); c.cols.assign(cs.begin(), cs.end());
+    return c;
+  };
+  bool have = false;
+  std::tuple<int64_t, int, int64_t> best_key;
+  Cand best;
+  for (int64_t phase = 0; phase < R; ++phase) {
+    Cand c = arrange(phase);
+    const std::tuple<int64_t, int, int64_t> key{(int64_t)std::max(c.rows.size(), c.cols.size()), c.nb, phase};
+    if (!have || key < best_key) { have = true; best_key = key; best = std::move(c); L.phase = (int)phase; }
+  }
+  if (best.S < 1) throw std::runtime_error("chain KKT: no unknown lies on the chain");
+  L.S = best.S; L.blk.swap(best.blk); L.loc.swap(best.loc); L.counts.swap(best.counts);
+  L.n_border = (int64_t)border.size();
+  L.nb = best.nb; L.ne = (int)ceil4((int64_t)border.size());
+  if (L.nb > max_nb || L.ne > max_ne)
+    throw std::runtime_error("chain KKT: blocks of " + std::to_string(*std::max_element(L.counts.begin(), L.counts.end())) + " unknowns / a border of " +
+                             std::to_string(border.size()) + " exceed the dense-block solver's limits (" + std::to_string(max_nb) + " / " + std::to_string(max_ne) + ")");
+  L.nc = (int)std::max<int64_t>(ceil4((int64_t)std::max(best.rows.size(), best.cols.size())), 4);
+  if (L.reach > 0 && (L.nc > max_nc || L.nc > L.nb))
+    throw std::runtime_error("chain KKT: the coupling between neighbouring blocks spans " + std::to_string(best.rows.size()) + " rows / " +
+                             std::to_string(best.cols.size()) + " columns (limit " + std::to_string(max_nc) + ")");
+  L.rowsR.assign((size_t)L.nc, -1); L.colsC.assign((size_t)L.nc, -1);
+  for (size_t i = 0; i < best.rows.size(); ++i) L.rowsR[i] = (int32_t)best.rows[i];
+  for (size_t i = 0; i < best.cols.size(); ++i) L.colsC[i] = (int32_t)best.cols[i];
+  return L;
+}
+
+// where the entry (ur, uc) of K goes in the flat buffer (-1: dropped — the upper coupling blocks and the border's row block, by symmetry)
+inline int64_t kkt_dest(const KktLayout &L, const std::vector<int32_t> &ridx, const std::vector<int32_t> &cidx, int64_t ur, int64_t uc) {
+  const int64_t kr = L.blk[(size_t)ur], kc = L.blk[(size_t)uc], lr = L.loc[(size_t)ur], lc = L.loc[(size_t)uc];
+  if (kr >= 0 && kc >= 0) {
+    if (kr == kc) return L.oD() + (kr * L.nb + lr) * L.nb + lc;
+    if (kr == kc + 1) {
+      const int32_t ri = ridx[(size_t)lr], ci = cidx[(size_t)lc];
+      if (ri < 0 || ci < 0) throw std::runtime_error("chain KKT: an entry of the Hessian couples neighbouring blocks outside the rows / columns the Jacobian couples them on");
+      return L.oB() + (kr * L.nc + ri) * L.nc + ci;
+    }
+    if (kc == kr + 1) return -1;
+    throw std::runtime_error("chain KKT: an entry couples blocks that are not neighbours (the chain grouping does not fit this model)");
+  }
+  if (kr >= 0 && kc < 0) return L.oE() + (kr * L.nb + lr) * L.ne + lc;
+  if (kr < 0 && kc < 0) return L.oG() + lr * L.ne + lc;
+  return -1;
+}
+
+inline KktPlan kkt_plan(const KktLayout &L, const std::vector<int64_t> &hr, const std::vector<int64_t> &hc, const std::vector<int64_t> &jr,
+                        const std::vector<int64_t> &jc) {
+  KktPlan P;
+  const int64_t nvar = L.nvar, ncon = L.ncon, nh = (int64_t)hr.size(), nj = (int64_t)jr.size();
+  P.n_h = nh; P.n_j = nj;
+  if (nh + nj + nvar + ncon + 1 >= (int64_t)UINT32_MAX) throw std::runtime_error("chain KKT: too many entries for the 32-bit gather plan");
+  std::vector<int32_t> ridx((size_t)L.nb, -1), cidx((size_t)L.nb, -1);
+  for (int i = 0; i < L.nc; ++i) { if (L.rowsR[(size_t)i] >= 0) ridx[(size_t)L.rowsR[(size_t)i]] = i; if (L.colsC[(size_t)i] >= 0) cidx[(size_t)L.colsC[(size_t)i]] = i; }
+  std::vector<std::pair<int64_t, uint32_t>> pairs;
+  pairs.reserve((size_t)(2 * nh + 2 * nj + nvar + ncon));
+  auto put = [&](int64_t ur, int64_t uc, int64_t src) {
+    const int64_t d = kkt_dest(L, ridx, cidx, ur, uc);
+    if (d >= 0) pairs.emplace_back(d, (uint32_t)src);
+  };
+  for (int64_t k = 0; k < nh; ++k) {
+    put(hr[(size_t)k], hc[(size_t)k], k);
+    if (hr[(size_t)k] != hc[(size_t)k]) put(hc[(size_t)k], hr[(size_t)k], k);
+  }
+  for (int64_t k = 0; k < nj; ++k) { put(nvar + jr[(size_t)k], jc[(size_t)k], nh + k); put(jc[(size_t)k], nvar + jr[(size_t)k], nh + k); }
+  for (int64_t i = 0; i < nvar; ++i) put(i, i, nh + nj + i);
+  for (int64_t r = 0; r < ncon; ++r) put(nvar + r, nvar + r, nh + nj + nvar + r);
+  // the padding's unit diagonal: the places of a block no unknown occupies, the border's tail
+  const uint32_t one = (uint32_t)(nh + nj + nvar + ncon);
+  {
+    std::vector<char> used((size_t)(L.S * L.nb), 0);
+    for (int64_t u = 0; u < nvar + ncon; ++u) if (L.blk[(size_t)u] >= 0) used[(size_t)(L.blk[(size_t)u] * L.nb + L.loc[(size_t)u])] = 1;
+    for (int64_t s = 0; s < L.S * L.nb; ++s) if (!used[(size_t)s]) { const int64_t k = s / L.nb, l = s % L.nb; pairs.emplace_back(L.oD() + (k * L.nb + l) * L.nb + l, one); }
+    for (int64_t l = L.n_border; l < L.ne; ++l) pairs.emplace_back(L.oG() + l * L.ne + l, one);
+  }
+  std::stable_sort(pairs.begin(), pairs.end(), [](const std::pair<int64_t, uint32_t> &a, const std::pair<int64_t, uint32_t> &b) { return a.first < b.first; });
+  P.perm.reserve(pairs.size());
+  for (size_t k = 0; k < pairs.size(); ++k) {
+    if (k == 0 || pairs[k].first != pairs[k - 1].first) { P.dest.push_back(pairs[k].first); P.seg.push_back((uint32_t)k); }
+    P.perm.push_back(pairs[k].second);
+  }
+  P.seg.push_back((uint32_t)pairs.size());
+  return P;
+}
+
+// eigenvalues of a small symmetric matrix (cyclic Jacobi): the inertia of the border's Schur complement
+inline void sym_eigenvalues(std::vector<double> a, int n, std::vector<double> &ev) {
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double offd = 0.0;
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) offd += a[(size_t)(i * n + j)] * a[(size_t)(i * n + j)];
+    if (offd < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[(size_t)(p * n + q)];
+        if (apq == 0.0) continue;
+        const double th = (a[(size_t)(q * n + q)] - a[(size_t)(p * n + p)]) / (2.0 * apq);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) { const double akp = a[(size_t)(k * n + p)], akq = a[(size_t)(k * n + q)]; a[(size_t)(k * n + p)] = c * akp - s * akq; a[(size_t)(k * n + q)] = s * akp + c * akq; }
+        for (int k = 0; k < n; ++k) { const double apk = a[(size_t)(p * n + k)], aqk = a[(size_t)(q * n + k)]; a[(size_t)(p * n + k)] = c * apk - s * aqk; a[(size_t)(q * n + k)] = s * apk + c * aqk; }
+      }
+  }
+  ev.resize((size_t)n);
+  for (int i = 0; i < n; ++i) ev[(size_t)i] = a[(size_t)(i * n + i)];
+}
+
+// A x = b for a small dense matrix, partial pivoting (in place on copies); false when singular
+inline bool dense_solve(std::vector<double> a, int n, std::vector<double> &b) {
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    for (int i = k + 1; i < n; ++i) if (std::fabs(a[(size_t)(i * n + k)]) > std::fabs(a[(size_t)(p * n + k)])) p = i;
+    if (a[(size_t)(p * n + k)] == 0.0) return false;
+    if (p != k) { for (int j = 0; j < n; ++j) std::swap(a[(size_t)(p * n + j)], a[(size_t)(k * n + j)]); std::swap(b[(size_t)p], b[(size_t)k]); }
+    for (int i = k + 1; i < n; ++i) {
+      const double f = a[(size_t)(i * n + k)] / a[(size_t)(k * n + k)];
+      if (f == 0.0) continue;
+      for (int j = k; j < n; ++j) a[(size_t)(i * n + j)] -= f * a[(size_t)(k * n + j)];
+      b[(size_t)i] -= f * b[(size_t)k];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[(size_t)i];
+    for (int j = i + 1; j < n; ++j) s -= a[(size_t)(i * n + j)] * b[(size_t)j];
+    b[(size_t)i] = s / a[(size_t)(i * n + i)];
+  }
+  return true;
+}
+
+}  // namespace iem

@@ -69,6 +69,11 @@ class ShardTemplate(C.Structure):
 COMM_HANDLE_BYTES = 128
 
 
+class KktInfo(C.Structure):
+    _fields_ = [("S", C.c_int64), ("n", C.c_int64), ("n_border", C.c_int64), ("block_doubles", C.c_int64),
+                ("nb", C.c_int32), ("ne", C.c_int32), ("nc", C.c_int32), ("reach", C.c_int32), ("group", C.c_int32), ("phase", C.c_int32)]
+
+
 class KernelInfo(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("kind", C.c_int32), ("jit", C.c_int32), ("grid", C.c_int64 * 3),
                 ("lds_bytes", C.c_int64), ("alg_bytes_read", C.c_int64), ("alg_bytes_written", C.c_int64)]
@@ -80,7 +85,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_obj_begin", "iem_obj_end", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jac_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_csr_spmv", "iem_kkt_chain_factor", "iem_kkt_chain_solve", "iem_kkt_source", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_csr_spmv", "iem_kkt_chain_factor", "iem_kkt_chain_solve", "iem_kkt_source", "iem_kkt_create", "iem_kkt_destroy", "iem_kkt_info", "iem_kkt_layout", "iem_kkt_analyse_blob", "iem_kkt_assemble", "iem_kkt_factor", "iem_kkt_solve", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
 
@@ -160,6 +165,14 @@ def lib():
     L.iem_kkt_chain_factor.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, dbl]
     L.iem_kkt_chain_solve.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     L.iem_kkt_source.argtypes = [i32, i32, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.iem_kkt_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.iem_kkt_destroy.argtypes = [vp]
+    L.iem_kkt_info.argtypes = [vp, C.POINTER(KktInfo)]
+    L.iem_kkt_layout.argtypes = [vp, vp, vp, vp, vp]
+    L.iem_kkt_analyse_blob.argtypes = [vp, C.c_size_t, i32, C.POINTER(KktInfo)] + [C.POINTER(vp)] * 7 + [C.POINTER(i64), C.POINTER(i64)]
+    L.iem_kkt_assemble.argtypes = [vp, vp, vp, vp, dbl, dbl]
+    L.iem_kkt_factor.argtypes = [vp, vp]
+    L.iem_kkt_solve.argtypes = [vp, vp, vp]
     L.iem_emit_source.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     L.iem_emit_source.restype = i32
     L.iem_free.argtypes = [vp]
@@ -232,6 +245,27 @@ def emit_source(blob: bytes):
     finally:
         L.iem_free(p)
     return src, int(key.value)
+
+
+def kkt_analyse_blob(blob: bytes, group: int = 0):
+    """Host analysis of the chain KKT solver behind ``iem_kkt_create`` (no device): ``(info dict, blk, loc, rows, cols, dest, seg,
+    perm)`` as numpy arrays."""
+    import numpy as np
+    L = lib()
+    info = KktInfo()
+    ptrs = [C.c_void_p() for _ in range(7)]
+    nd, npm = C.c_int64(), C.c_int64()
+    check(L.iem_kkt_analyse_blob(blob, len(blob), int(group), C.byref(info), *[C.byref(p) for p in ptrs], C.byref(nd), C.byref(npm)))
+    n = int(info.n)
+    shapes = [(n, np.int64), (n, np.int64), (int(info.nc), np.int32), (int(info.nc), np.int32), (nd.value, np.int64), (nd.value + 1, np.uint32), (npm.value, np.uint32)]
+    out = []
+    try:
+        for p, (cnt, dt) in zip(ptrs, shapes):
+            out.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64 if dt == np.int64 else C.c_int32 if dt == np.int32 else C.c_uint32)), shape=(max(cnt, 1),))[:cnt].copy())
+    finally:
+        for p in ptrs:
+            L.iem_free(p)
+    return ({k: int(getattr(info, k)) for k, _ in KktInfo._fields_}, *out)
 
 
 def kkt_source(nb: int, ne: int, nc: int = 12):
