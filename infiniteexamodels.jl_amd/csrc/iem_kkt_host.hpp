@@ -216,7 +216,29 @@ inline KktPlan kkt_plan(const KktLayout &L, const std::vector<int64_t> &hr, cons
     for (int64_t s = 0; s < L.S * L.nb; ++s) if (!used[(size_t)s]) { const int64_t k = s / L.nb, l = s % L.nb; pairs.emplace_back(L.oD() + (k * L.nb + l) * L.nb + l, one); }
     for (int64_t l = L.n_border; l < L.ne; ++l) pairs.emplace_back(L.oG() + l * L.ne + l, one);
   }
-  std::stable_sort(pairs.begin(), pairs.end(), [](const std::pair<int64_t, uint32_t> &a, const std::pair<int64_t, uint32_t> &b) { return a.first < b.first; });
+  // by destination, sources of one destination in the order above: the regions D | Bt | E are block-major, so a counting
+  // sort over (region, block) followed by a sort inside each bucket (a few hundred entries) is the global order
+  {
+    const int64_t S = L.S, wD = (int64_t)L.nb * L.nb, wB = (int64_t)L.nc * L.nc, wE = (int64_t)L.nb * L.ne;
+    auto bucket = [&](int64_t d) -> int64_t {
+      if (d < L.oB()) return (d - L.oD()) / wD;
+      if (d < L.oE()) return S + (d - L.oB()) / wB;
+      if (d < L.oG()) return 2 * S + (d - L.oE()) / wE;
+      return 3 * S;
+    };
+    std::vector<int64_t> start((size_t)(3 * S + 2), 0);
+    for (const auto &pr : pairs) ++start[(size_t)(bucket(pr.first) + 1)];
+    for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+    std::vector<std::pair<int64_t, uint32_t>> sorted(pairs.size());
+    {
+      std::vector<int64_t> at(start.begin(), start.end() - 1);
+      for (const auto &pr : pairs) sorted[(size_t)at[(size_t)bucket(pr.first)]++] = pr;
+    }
+    for (int64_t b = 0; b + 1 < (int64_t)start.size(); ++b)
+      std::stable_sort(sorted.begin() + start[(size_t)b], sorted.begin() + start[(size_t)(b + 1)],
+                       [](const std::pair<int64_t, uint32_t> &a, const std::pair<int64_t, uint32_t> &c) { return a.first < c.first; });
+    pairs.swap(sorted);
+  }
   P.perm.reserve(pairs.size());
   for (size_t k = 0; k < pairs.size(); ++k) {
     if (k == 0 || pairs[k].first != pairs[k - 1].first) { P.dest.push_back(pairs[k].first); P.seg.push_back((uint32_t)k); }
