@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="quadrotor")
 ap.add_argument("--supports", type=int, default=100_000)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--cabi", type=int, default=1, help="also time the iem_kkt_* object")
 args = ap.parse_args()
 mk = {"quadrotor": lambda: workloads.quadrotor(args.supports), "quadrotor_oc3": lambda: workloads.quadrotor(args.supports, collocation=3),
       "farmer": lambda: workloads.farmer(args.supports), "opf": lambda: workloads.opf(args.supports), "hovercraft": lambda: workloads.hovercraft(args.supports),
@@ -55,9 +56,30 @@ sol = ck.solve(rhs, refine=1)
 res = float((ck._matvec(sol) - rhs).abs().max().item() / max(1.0, float(rhs.abs().max().item())))
 res0 = float((ck._matvec(ck.solve(rhs, refine=0)) - rhs).abs().max().item())
 pos, neg, doubtful = ck.inertia()
+# the same solver as ONE C-ABI object (iem_kkt_*): analysis in C++, blocks filled straight from the COO value buffers
+import ctypes as C
+from infiniteexamodels.jl_amd import lib as iemlib
+cabi = {}
+if args.cabi:
+    k = C.c_void_p()
+    t3 = time.perf_counter()
+    iemlib.check(gm._L.iem_kkt_create(gm._h, 0, C.byref(k)))
+    cabi["create_s"] = time.perf_counter() - t3
+    p = lambda t: C.c_void_p(t.data_ptr())
+    inertia = (C.c_int64 * 3)()
+    out = torch.empty_like(rhs)
+    gm._sync_stream()
+    asm = lambda: iemlib.check(gm._L.iem_kkt_assemble(k, p(hv), p(jv), p(sigma), 1e-2, 1e-6))
+    cabi["assemble_ms"] = timed(asm)
+    cabi["assemble_factor_ms"] = timed(lambda: (asm(), iemlib.check(gm._L.iem_kkt_factor(k, inertia))))
+    cabi["solve_ms"] = timed(lambda: iemlib.check(gm._L.iem_kkt_solve(k, p(rhs), p(out))))
+    torch.cuda.synchronize()
+    cabi["inertia"] = [int(v) for v in inertia]
+    cabi["abs_residual_without_refinement"] = float((ck._matvec(out) - rhs).abs().max().item())
+    iemlib.check(gm._L.iem_kkt_destroy(k))
 flops = L.S * (2.0 * L.nb ** 3 * (1 + 2 + 3) + 2.0 * L.nb * L.nb * L.ne * 4)      # inverse + X, Y + three update products (+ border terms)
 print(json.dumps({"workload": args.workload, "supports": args.supports, "n": n, "nnz_K": kkt.nnz, "chain": {"S": L.S, "nb": L.nb, "ne": L.ne, "nc": L.nc, "reach": L.reach, "group": L.group, "phase": L.phase},
                   "setup_s": {"model_and_csr_plan": t1 - t0, "chain_layout_and_plan": t2 - t1}, "ms": ms,
                   "factor_GFLOP_dense": flops / 1e9, "factor_TFLOPs": flops / (ms["factor"] * 1e-3) / 1e12,
                   "block_bytes": int(ck.flat.numel() * 8 + (ck.BR.numel() + ck.Z.numel()) * 8),
-                  "rel_residual_after_refinement": res, "abs_residual_without": res0, "inertia": [pos, neg, doubtful], "ncon": gm.meta.ncon}))
+                  "rel_residual_after_refinement": res, "abs_residual_without": res0, "inertia": [pos, neg, doubtful], "ncon": gm.meta.ncon, "c_abi_object": cabi}))
