@@ -287,7 +287,9 @@ int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const d
  *                                     doubtful} pivots of K (a correctly regularised system has ncon negative ones); synchronises
  *   iem_kkt_solve(k, d_rhs, d_sol)    K sol = rhs (nvar + ncon doubles each; no refinement — K x for a residual is
  *                                     iem_hprod + iem_jtprod / iem_jprod + the diagonal terms)
- * Models whose blocks / border / coupling exceed the solver's limits (96 / 64 / 48) are refused by iem_kkt_create. */
+ * d_rhs and d_sol may be the same array.  The object borrows the model handle (its stream, device and kernel cache): destroy
+ * it before iem_destroy(m).  Models whose blocks / border / coupling exceed the solver's limits (96 / 64 / 48) are refused by
+ * iem_kkt_create. */
 typedef struct iem_kkt iem_kkt;
 typedef struct {
   int64_t S, n, n_border, block_doubles;   /* blocks, unknowns, border unknowns, doubles of the block buffer D | Bt | E | G */

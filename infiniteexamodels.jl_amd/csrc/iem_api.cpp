@@ -1942,7 +1942,8 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
   if (!m || !out) return fail(IEM_E_ARG, "null argument");
   if (m->sharded) return fail(IEM_E_ARG, "iem_kkt_create: a sharded handle holds one rank's window; the chain solver wants the whole model");
   DevGuard dg_(m->device);
-  std::unique_ptr<iem_kkt> k(new iem_kkt);
+  struct Drop { void operator()(iem_kkt *p) const { iem_kkt_destroy(p); } };     // (a failed create frees what it had uploaded)
+  std::unique_ptr<iem_kkt, Drop> k(new iem_kkt);
   k->m = m;
   try {
     const iem::Model &M = m->model;
