@@ -1752,12 +1752,29 @@ int iem_comm_status(iem_model *m, int64_t *out_status) {
 
 /* ---- chain KKT solver ------------------------------------------------------------------------------ */
 namespace {
+// Shape of a kkt_eliminate workgroup: waves (KKT_WMAX of csrc/iem_kkt_device.h; a wave owns every KKT_WMAX-th 16-row tile row)
+// and the register budget as waves per SIMD (KKT_WPE).  The block inverse is a chain of dependent panel steps, each of which
+// reads the whole row panel from LDS IN EVERY WAVE: few waves with many tiles each — and many workgroups per CU to hide the
+// chain's latency — beat one wave per tile row (quadrotor_oc3, 84 x 84 blocks: 11.6 ms with four waves, 10.3 with six, 5.8
+// with two; 40 x 40: 2.60 -> 2.40 with one).  With a border the products Z = D^-1 E and E' Z dominate and want the waves
+// (OPF, 60 + 52: 3.6 ms with four, 4.6 with two, 7.0 with one).  profiles/r03_kkt_shape_ab.txt
+void kkt_shape(int nb, int ne, int *wmax, int *wpe) {
+  const int R = (nb + 15) / 16;
+  if (ne > 0 || R <= 2) { *wmax = 4; *wpe = nb <= 48 ? 4 : 0; }
+  else if (R == 3) { *wmax = 1; *wpe = 3; }
+  else if (R == 4) { *wmax = 2; *wpe = 3; }
+  else { *wmax = 2; *wpe = 2; }
+  if (const char *e = getenv("IEM_KKT_WMAX")) { const int v = atoi(e); if (v >= 1 && v <= 6) *wmax = v; }
+  if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) *wpe = v; }
+}
 std::string kkt_source(int nb, int ne, int nc) {
   std::string s = "// iem-flags: -O3 -ffp-contract=off -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
-  // blocks of up to three 16-row tiles: kkt_eliminate is bound by latency x occupancy — a register budget for four waves per
-  // SIMD (5 spilled registers) factors 10 % faster than the 2 - 3 waves the compiler settles for (profiles/r03_kkt_chain.json)
-  if (nb <= 48) s += "#define KKT_WPE 4\n";
+  int wmax, wpe;
+  kkt_shape(nb, ne, &wmax, &wpe);
+  if (wpe > 0) s += "#define KKT_WPE " + std::to_string(wpe) + "\n";
+  if (wmax != 4) s += "#define KKT_WMAX " + std::to_string(wmax) + "\n";
+  if (const char *e = getenv("IEM_KKT_DEFS")) s += std::string(e) + "\n";     // (experiments: extra #define lines)
   s += kKktSource;
   return s;
 }
@@ -1816,7 +1833,9 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double
   int rc = kkt_module(m, nb, ne, nc, &km);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(d_info, 0, 24, m->stream));
-  const unsigned wg = 64u * (unsigned)std::min((nb + 15) / 16, 4);   // KKT_T of csrc/iem_kkt_device.h: one wave per 16-row tile row, at most four
+  int wmax, wpe_;
+  kkt_shape(nb, ne, &wmax, &wpe_);
+  const unsigned wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);   // KKT_T of csrc/iem_kkt_device.h
   KktArgsH A{d_D, d_Bt, d_BR, d_E, d_Z, d_Gp, d_rows, d_cols, (long long *)d_info, (long long)S, 1, 0, tiny};
   if (!chained) {   // one launch: every block against the border
     A.final_block = 2;

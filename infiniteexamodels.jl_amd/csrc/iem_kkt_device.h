@@ -47,12 +47,16 @@
 // the vector FMA — and a quarter of the operand traffic of a 4 x 4 register tiling, whose LDS reads bound the first form of
 // these kernels: tools/probes/mfma_f64_probe.hip, profiles/r03_kkt_chain.json).  An NB x NB matrix is cut into R x R tiles of
 // 16 x 16 (R = ceil(NB / 16), the rim padded with zeros); wave w of the workgroup owns the tile rows w, w + W, ...
-// (W = min(R, 4) waves).  Within a tile lane l holds, in register r of its accumulator, the element
+// (W = min(R, KKT_WMAX) waves; the host picks KKT_WMAX per shape — kkt_shape in csrc/iem_api.cpp: one or two waves holding
+// many tiles each for blocks without a border).  Within a tile lane l holds, in register r of its accumulator, the element
 //        row = (l >> 4) + 4 r ,  col = l & 15            (the instruction's C/D layout),
 // and feeds A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15] per step of four of the inner dimension.
 #define KKT_R ((KKT_NB + 15) / 16)
 #define KKT_RE ((KKT_NE + 15) / 16)
-#define KKT_W (KKT_R < 4 ? KKT_R : 4)
+#ifndef KKT_WMAX
+#define KKT_WMAX 4
+#endif
+#define KKT_W (KKT_R < KKT_WMAX ? KKT_R : KKT_WMAX)
 #define KKT_T (64 * KKT_W)        // threads per workgroup
 #define KKT_TRW ((KKT_R + KKT_W - 1) / KKT_W)   // tile rows per wave
 #define KKT_LD (KKT_NB + 1)       // LDS row stride of an NB-wide matrix (odd: rows of a fragment fall into different banks)
@@ -252,6 +256,8 @@ __device__ __forceinline__ void kkt_gj_panel(kkt_d4 (&m)[KKT_TRW][KKT_R], double
   // B operand = entry j of the normalised pivot row lk at the time of ITS step: a combination of the row panel's column j
   // with row lk of the lower triangle of `snap` (the steps before it, already folded).  The panel's own columns enter as
   // unit vectors (the in-place algorithm keeps the inverse where the identity of [A | I] would sit).
+  // (also in a one-wave workgroup: keeping `snap` in registers across the panel instead costs more than the LDS round trip —
+  // 2.52 against 2.37 ms at 1e5 quadrotor supports)
   double sl[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) sl[b] = Gj[16 + 4 * lk + b];

@@ -19,7 +19,8 @@ ap.add_argument("--cabi", type=int, default=1, help="also time the iem_kkt_* obj
 args = ap.parse_args()
 mk = {"quadrotor": lambda: workloads.quadrotor(args.supports), "quadrotor_oc3": lambda: workloads.quadrotor(args.supports, collocation=3),
       "farmer": lambda: workloads.farmer(args.supports), "opf": lambda: workloads.opf(args.supports), "hovercraft": lambda: workloads.hovercraft(args.supports),
-      "kinetic": lambda: workloads.kinetic_control(args.supports)}[args.workload]
+      "kinetic": lambda: workloads.kinetic_control(args.supports), "pandemic3": lambda: workloads.pandemic(args.supports, 3),
+      "pandemic5": lambda: workloads.pandemic(args.supports, 5)}[args.workload]
 t0 = time.perf_counter()
 core = transcribe.exa_core(mk())
 gm = ExaModel(core, device=0)
@@ -30,7 +31,7 @@ t2 = time.perf_counter()
 L = ck.layout
 n = gm.meta.nvar + gm.meta.ncon
 rng = np.random.default_rng(0)
-x = torch.tensor(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar) if args.workload not in ("farmer",) else np.abs(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)) + 0.05, device="cuda")
+x = torch.tensor(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar) if args.workload not in ("farmer", "pandemic3", "pandemic5") else np.abs(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)) + 0.05, device="cuda")
 y = torch.tensor(0.1 * np.random.default_rng(1).standard_normal(gm.meta.ncon), device="cuda")
 sigma = torch.tensor(0.5 + rng.random(gm.meta.nvar), device="cuda")
 rhs = torch.tensor(rng.standard_normal(n), device="cuda")

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/kkt_suite; rm -rf $O; mkdir -p $O
 cd $R
-for spec in "farmer 100000" "opf 20000" "quadrotor 100000" "hovercraft 100000" "quadrotor 1000000" "quadrotor_oc3 50000" "kinetic 100000"; do
+for spec in "farmer 100000" "opf 20000" "quadrotor 100000" "hovercraft 100000" "quadrotor 1000000" "quadrotor_oc3 50000" "kinetic 100000" "pandemic3 100000" "pandemic5 50000"; do
   set -- $spec
   timeout -k 10 400 python3 tools/kkt_chain_bench.py --workload $1 --supports $2 > $O/bench_$1_$2.log 2>&1 || { echo "FAILED $spec"; tail -5 $O/bench_$1_$2.log; exit 1; }
   grep -h '^{' $O/bench_$1_$2.log | cut -c1-700
