@@ -8,6 +8,7 @@ O=$R/gpurun_out/r03_final; mkdir -p $O
 cd $R
 bash tools/profile_gpu.sh > $O/profile.log 2>&1 || { tail -5 $O/profile.log; exit 1; }
 echo "profile ok"
+cp $R/gpurun_out/prof/summary.json $R/profiles/pmc_quadrotor_1e6.json    # (the box's copy of the tree: the bench lines below cite THIS profile; tools/collect_final.sh makes the same copy at home)
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard_stats -- python3 $R/bench.py --emulate-shard 3/8 --steps 200 --warmup 20 --no-cpu-baseline --no-cold > $O/shard_bench.json 2> $O/shard_bench.err ) || exit 1
 echo "shard stats ok"
 for i in 1 2 3 4 5 6 7 8 9 10; do
