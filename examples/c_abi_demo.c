@@ -8,8 +8,8 @@
  * Reads a blob (include/iem_blob.h — e.g. written by ExaCore.to_blob() or by the Julia writer),
  * an evaluation point x and multipliers y (raw little-endian doubles), runs the five NLPModels
  * calls the reference's solvers make every iteration (ext/InfiniteExaModelsIpopt.jl:48-60) on
- * device arrays it owns, and prints one line per call: name, length, sum, sum of squares —
- * tests/test_c_abi_demo.py compares them with the oracle.                                      */
+ * device arrays it owns, then one KKT solve with the chain solver (iem_kkt_*), and prints one line per call: name, length,
+ * sum, sum of squares — tests/test_c_abi_demo.py compares them with the oracle (the solve: with SciPy's sparse LU).   */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -79,6 +79,26 @@ int main(int argc, char **argv) {
   IEM(iem_synchronize(m));
   printf("obj2 1 %.17g %.17g\n", f2, f2 * f2);
   if (report("jac2", jv2, meta.nnzj) || report("hess2", hv2, meta.nnzh)) return 1;
+  /* the linear solve of a solver iteration (where the reference plugs CUDSS, README.md:36-37): the KKT matrix of this
+   * point, K = [H + 0.01 I, J'; J, -1e-6 I], assembled from the two value buffers above, factorised, and K s = (grad; cons)
+   * solved — skipped (printed as such) when the model's blocks are beyond the chain solver */
+  iem_kkt *k = NULL;
+  if (iem_kkt_create(m, 0, &k) == 0) {
+    int64_t inertia[3];
+    double *rhs;
+    HIP(hipMalloc((void **)&rhs, nx + ny + 8));
+    HIP(hipMemcpy(rhs, g, nx, hipMemcpyDeviceToDevice));
+    HIP(hipMemcpy((char *)rhs + nx, c, ny, hipMemcpyDeviceToDevice));
+    IEM(iem_kkt_assemble(k, hv, jv, NULL, 1e-2, 1e-6));
+    IEM(iem_kkt_factor(k, inertia));
+    IEM(iem_kkt_solve(k, rhs, rhs));
+    IEM(iem_synchronize(m));
+    printf("kkt_inertia %lld %lld %lld\n", (long long)inertia[0], (long long)inertia[1], (long long)inertia[2]);
+    if (report("kkt_solution", rhs, meta.nvar + meta.ncon)) return 1;
+    IEM(iem_kkt_destroy(k));
+  } else {
+    printf("kkt_refused %s\n", iem_last_error());
+  }
   IEM(iem_destroy(m));
   return 0;
 }

@@ -51,3 +51,21 @@ def test_c_demo_matches_oracle(name, built, tmp_path):
     assert [int(v) for v in got["jac_structure"]] == [om.nnzj, int(jr.sum()), int(jc.sum())]
     # the deferred objective and the one-launch jac + hess pair give the very same numbers as the five plain calls
     assert got["obj2"] == got["obj"] and got["jac2"] == got["jac"] and got["hess2"] == got["hess"]
+    # the KKT solve from C (iem_kkt_*): K = [H + 0.01 I, J'; J, -1e-6 I] at this point, right-hand side (grad; cons)
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import spsolve
+    hr, hc = om.hess_structure(base=0)
+    jr0, jc0 = om.jac_structure(base=0)
+    hv, jv = om.hess_coord(x, y, 1.0), om.jac_coord(x)
+    n, m = om.nvar, om.ncon
+    off = hr != hc
+    H = sp.coo_matrix((np.concatenate([hv, hv[off]]), (np.concatenate([hr, hc[off]]), np.concatenate([hc, hr[off]]))), shape=(n, n))
+    J = sp.coo_matrix((jv, (jr0, jc0)), shape=(m, n))
+    K = sp.bmat([[H + 1e-2 * sp.identity(n), J.T], [J, -1e-6 * sp.identity(m)]]).tocsc()
+    want = spsolve(K, np.concatenate([om.grad(x), om.cons(x)]))
+    neg = int((np.linalg.eigvalsh(K.toarray()) < 0).sum())     # (a random point: the Hessian block need not be positive definite)
+    assert [int(v) for v in got["kkt_inertia"]] == [n + m - neg, neg, 0]
+    cnt, s, q = int(got["kkt_solution"][0]), float(got["kkt_solution"][1]), float(got["kkt_solution"][2])
+    assert cnt == n + m
+    assert abs(s - want.sum()) <= 1e-6 * max(1.0, float(np.abs(want).sum()))
+    assert abs(q - (want * want).sum()) <= 1e-6 * max(1.0, float((want * want).sum()))
