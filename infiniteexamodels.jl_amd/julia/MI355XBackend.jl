@@ -180,6 +180,35 @@ halo_fold!(m::MI355XModel, v::ROCVector{Float64}) =
 allreduce_obj_grad!(m::MI355XModel, f::ROCVector{Float64}, g::ROCVector{Float64}) =
     (check(ccall((:iem_allreduce_obj_grad, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), m.handle, dptr(f), dptr(g))); (f, g))
 
+# ---- the linear solver behind MadNLP's AbstractLinearSolver slot (where README.md:36-37 picks CUDSSSolver) ----------
+# UNEXECUTED, like the rest of this file; [EXT]: MadNLP's linear-solver interface (factorize!, solve!, is_inertia, inertia)
+# from memory of MadNLP 0.8.  One object holds the analysis (grouping by support, coupling rows / columns, gather plan from
+# the hess_coord! / jac_coord! value buffers) and the device blocks: include/iem.h, iem_kkt_*.  `hess`, `jac`, `sigma` are the
+# solver's own value buffers (MadNLP's sparse KKT system keeps them); delta_w / delta_c its current regularisation.
+mutable struct ChainKKTSolver <: Any      # <: MadNLP.AbstractLinearSolver{Float64} once MadNLP is loaded next to this file
+    k::Ptr{Cvoid}
+    hess::ROCVector{Float64}; jac::ROCVector{Float64}; sigma::ROCVector{Float64}
+    delta_w::Float64; delta_c::Float64
+    inertia::Vector{Int64}
+end
+function ChainKKTSolver(m::MI355XModel, hess, jac, sigma)
+    k = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:iem_kkt_create, LIBIEM), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), m.handle, 0, k))   # refuses what it cannot hold
+    s = ChainKKTSolver(k[], hess, jac, sigma, 0.0, 0.0, zeros(Int64, 3))
+    finalizer(s -> ccall((:iem_kkt_destroy, LIBIEM), Cint, (Ptr{Cvoid},), s.k), s)      # before the model's own finalizer
+    return s
+end
+function factorize!(s::ChainKKTSolver)
+    check(ccall((:iem_kkt_assemble, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble),
+                s.k, dptr(s.hess), dptr(s.jac), dptr(s.sigma), s.delta_w, s.delta_c))
+    check(ccall((:iem_kkt_factor, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.k, s.inertia))
+    return s
+end
+solve!(s::ChainKKTSolver, x::ROCVector{Float64}) =       # in place: the right-hand side is read before the solution is written
+    (check(ccall((:iem_kkt_solve, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), s.k, dptr(x), dptr(x))); x)
+is_inertia(::ChainKKTSolver) = true
+inertia(s::ChainKKTSolver) = (s.inertia[1], s.inertia[3], s.inertia[2])      # (positive, zero, negative)
+
 # ---- blob writer ----------------------------------------------------------------------------
 # Serialises a host ExaCore into the wire format of include/iem_blob.h.  [EXT]: the field and
 # type names of ExaModels' internal structs (Objective/Constraint linked lists, SIMDFunction,
