@@ -441,3 +441,61 @@ class InfiniteModel:
         self.backend = backend
         backend._attach(self)
         self._ready = False
+
+    # The user-facing calls of the reference's tests (test/solve.jl): each one is the InfiniteOpt / JuMP function of the
+    # same name, forwarded to the transformation backend (src/infiniteopt_backend.jl).
+    def transformation_backend_ready(self) -> bool:
+        return bool(self._ready)
+
+    def optimize(self):
+        """``optimize!(model)``: (re)build the backend when the model changed, then ``JuMP.optimize!(backend)``."""
+        if not self._ready:
+            self.backend.build_transformation_backend(self)
+        return self.backend.optimize()
+
+    def set_parameter_value(self, pref, value) -> None:
+        """``set_parameter_value``: θ is updated in place when the backend can (finite parameters, parameter functions:
+        ``src/infiniteopt_backend.jl:511-550``); anything else leaves the backend to be rebuilt."""
+        ready = self._ready
+        if isinstance(pref, FiniteParameterRef):
+            pref.value = float(value)
+        elif isinstance(pref, ParameterFunctionRef):
+            pref.func = value
+        else:
+            raise TypeError("set_parameter_value takes a finite parameter or a parameter function")
+        self._ready = bool(ready and self.backend is not None and self.backend.update_parameter_value(pref, value))
+
+    def set_start_value(self, vref, value) -> None:
+        """``set_start_value``: written into ``core.x0`` when the backend is built (``:553-592``)."""
+        ready = self._ready
+        vref.info.start = value
+        self._ready = bool(ready and self.backend is not None and self.backend.update_start_value(vref, value))
+
+    def value(self, ref, label: str = "public"):
+        return self.backend.map_value(ref, label)
+
+    def dual(self, cref, label: str = "public"):
+        return self.backend.map_dual(cref, label)
+
+    def supports(self, ref, label: str = "public"):
+        if isinstance(ref, ConstraintObject):
+            return self.backend.constraint_supports(ref, label)
+        return self.backend.variable_supports(ref, label)
+
+    def objective_value(self) -> float:
+        return self.backend.objective_value()
+
+    def termination_status(self) -> str:
+        return self.backend.termination_status()
+
+    def primal_status(self) -> str:
+        return self.backend.primal_status()
+
+    def solve_time(self) -> float:
+        return self.backend.solve_time_sec()
+
+    def set_silent(self, value: bool = True) -> None:
+        self.backend.set_silent(value)
+
+    def set_time_limit_sec(self, value) -> None:
+        self.backend.set_time_limit_sec(value)

@@ -134,6 +134,16 @@ def test_lagrange_newton_solver_in_the_backend_slot(built):
     assert np.abs(om.cons(x) - om.lcon).max() <= 1e-8
     assert np.abs(om.grad(x) + om.jtprod(x, y)).max() <= 1e-7
     assert abs(res.objective - om.obj(x)) <= 1e-9 * max(1.0, abs(om.obj(x)))
+    # the result side of the plug point, as the reference's tests read it (test/solve.jl:15-18): statuses, objective,
+    # value(x) over the supports, duals of the ODE rows in JuMP's sign
+    assert im.termination_status() == "LOCALLY_SOLVED" and im.primal_status() == "FEASIBLE_POINT"
+    assert im.objective_value() == res.objective and im.solve_time() > 0.0
+    x1 = im.infinite_variables[0]
+    v = im.value(x1)
+    assert v.shape == (200,) and np.array_equal(v, x[:200]) and im.supports(x1).shape == (200, 1)
+    c0 = im.constraints[0]
+    con = im.backend.transformation_constraint(c0)
+    assert np.array_equal(im.dual(c0), -y[con.offset:con.offset + con.length])
     # a model without a chain (finite parameters only) goes through the dense fallback ... if it is equality-constrained;
     # rosenbrock has inequality rows: refused
     m, _ = cases.rosenbrock()
