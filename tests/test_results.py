@@ -216,3 +216,94 @@ def test_attributes_and_status_tables():
     madnlp = type("S", (), dict(termination_statuses=R.MADNLP_TERMINATION, result_statuses=R.MADNLP_RESULT))()
     assert R.translate_termination_status(madnlp, "INFEASIBLE_PROBLEM_DETECTED") == "LOCALLY_INFEASIBLE"
     assert R.translate_result_status(madnlp, "SOLVE_SUCCEEDED") == "FEASIBLE_POINT"
+
+
+def _prev(be):
+    return dict(be.prev_options)
+
+
+@pytest.mark.parametrize("conv, SILENT, DEFAULT, USER, WALL", [("ipopt", 0, 5, 3, 1.0e20), ("madnlp", "ERROR", "INFO", "WARN", 1.0e6)])
+def test_option_updates_replayed_from_the_reference(built, conv, SILENT, DEFAULT, USER, WALL):
+    """/root/reference/test/ipopt.jl:2-158 and test/madnlp.jl:2-165 ("option updates 1 / 2"): the dictionaries the
+    reference asserts for ``prev_options`` after every solve, with SLSQP on the oracle standing in for the solver (its
+    optimum: ``test/ipopt.jl:18``) under that solver's option conventions."""
+    # --- option updates 1 (:2-55)
+    m = cases.ode_5x5()
+    be = attach(m)
+    be.solver.option_convention = conv
+    m.set_silent()
+    m.set_time_limit_sec(120.0)
+    assert be.silent is True and be.time_limit == 120.0
+    m.optimize()
+    assert abs(m.objective_value() - (-12.784599900757165)) < 2e-6
+    assert be.options == {} and _prev(be) == {"print_level": SILENT, "max_wall_time": 120.0}
+    m.set_silent(False)                                   # unset_silent
+    m.set_time_limit_sec(200.0)
+    for k, v in (("max_iter", 50), ("mu_init", 1e-2), ("tol", 1e-6)):
+        be.set_attribute(k, v)                            # set_optimizer_attribute
+    assert be.results is not None                         # changing options does not wipe the results
+    m.optimize()
+    assert be.options == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6}
+    assert _prev(be) == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6, "print_level": DEFAULT, "max_wall_time": 200.0}
+    assert [k for k, _ in be.solver.calls] == ["initial", "resolve"]
+    assert be.solver.calls[1][1] == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6, "print_level": DEFAULT, "max_wall_time": 200.0}
+    # --- option updates 2 (:57-158)
+    m = cases.ode_5x5()
+    be = attach(m)
+    be.solver.option_convention = conv
+    m.set_time_limit_sec(120.0)
+    for k, v in (("max_iter", 50), ("mu_init", 1e-2), ("tol", 1e-6)):
+        be.set_attribute(k, v)
+    m.optimize()
+    assert _prev(be) == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6, "max_wall_time": 120.0}
+    be.set_attribute("print_level", USER)
+    m.set_time_limit_sec(None)                            # unset_time_limit_sec
+    assert np.isnan(be.time_limit)
+    m.optimize()
+    assert _prev(be) == {"print_level": USER, "max_wall_time": WALL, "tol": 1e-6, "mu_init": 1e-2, "max_iter": 50}
+    assert be.options == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6, "print_level": USER}
+    m.set_silent()
+    m.set_time_limit_sec(150.0)
+    m.optimize()
+    assert be.options == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6, "print_level": USER}
+    assert _prev(be) == {"max_iter": 50, "mu_init": 1e-2, "tol": 1e-6, "max_wall_time": 150.0, "print_level": SILENT}
+    m.set_silent(False)                                   # the print level set before comes back
+    m.optimize()
+    assert _prev(be) == {"print_level": USER, "max_wall_time": 150.0, "tol": 1e-6, "mu_init": 1e-2, "max_iter": 50}
+    assert be.solver.calls[-1][1] == {"print_level": USER}
+
+
+def test_warm_start_and_rebuild_keep_the_settings(built):
+    """/root/reference/test/ipopt.jl:159-203 (warm start) and :205-221 (a rebuild re-sends the silent setting, #26)"""
+    m = cases.ode_5x5()
+    be = attach(m)
+    with pytest.warns(UserWarning, match="No previous solution values found"):
+        be.warmstart_backend_start_values()
+    m.optimize()
+    expected = np.zeros(51)
+    expected[0] = 10.0
+    assert np.array_equal(be.core.x0, expected)                                   # :183-185
+    be.warmstart_backend_start_values()
+    assert np.array_equal(be.core.x0, be.results.solution)                        # :190-191
+    seen = []
+    inner = be.solver._solve
+    be.solver._solve = lambda x0: (seen.append(np.array(x0)), inner(x0))[1]
+    m.optimize()
+    assert np.array_equal(seen[-1], be.results.solution) or np.allclose(seen[-1], be.results.solution, atol=1e-6)   # started from the solution
+    assert abs(m.objective_value() - (-12.784599900757165)) < 2e-6
+    # a rebuild: prev_options are emptied with the backend, so the silent setting travels again
+    m2 = InfiniteModel()
+    t = m2.infinite_parameter("t", 0, 1, num_supports=5)
+    y = m2.variable("y", t, lb=0, start=1.0)
+    z = m2.finite_parameter("z", 10.0)
+    m2.objective("min", m2.integral(y ** 2 + 2 * z, t))
+    m2.constraint(y + z <= 42 + t)
+    be2 = attach(m2)
+    m2.set_silent()
+    m2.optimize()
+    assert be2.solver.calls[-1] == ("initial", {"print_level": 0})
+    m2.variable("w", t)                                   # a change the backend cannot take in place
+    assert not m2.transformation_backend_ready()
+    m2.objective("min", m2.integral(y ** 2 + 2 * z, t))
+    m2.optimize()
+    assert be2.solver.calls[-1] == ("initial", {"print_level": 0})                # still silent, and a fresh solver state
