@@ -307,3 +307,30 @@ def test_warm_start_and_rebuild_keep_the_settings(built):
     m2.objective("min", m2.integral(y ** 2 + 2 * z, t))
     m2.optimize()
     assert be2.solver.calls[-1] == ("initial", {"print_level": 0})                # still silent, and a fresh solver state
+
+
+@pytest.mark.parametrize("maker, nt", [(cases.test_problem_1, 5), (cases.test_problem_1_oc3, 9)])
+def test_values_of_variables_derivatives_and_restricted_rows(built, maker, nt):
+    """/root/reference/test/solve.jl:2-44: ``value(y)``, ``value(z)``, ``value(∂(y, t))`` after a solve — the reference
+    compares them with InfiniteOpt's own transcription; here they are checked against what the transcription promises:
+    shapes over the (public) supports, the derivative values satisfying the ODE row they appear in, the restricted row
+    holding on the supports it admits."""
+    m = maker()
+    attach(m)
+    m.optimize()
+    y = next(v for v in m.infinite_variables if v.name == "y")
+    z = m.finite_variables[0]
+    dy = m.derivatives[0]
+    Y, Z, DY = m.value(y), m.value(z), m.value(dy)
+    assert Y.shape == (5, 5) and DY.shape == (5, 5) and np.isscalar(Z)             # public supports only
+    assert m.value(y, "all").shape == (nt, 5) and m.supports(y, "all").shape == (nt, 5, 2)
+    assert np.allclose(DY, np.sin(Y) + Z + 1.2, atol=1e-6)                          # dy/dt == sin(y) + z + 1.2
+    assert (Y >= -1e-9).all()
+    c_ode, c_restricted = m.constraints[0], m.constraints[1]
+    assert m.dual(c_ode, "all").shape == (nt * 5,) or m.dual(c_ode, "all").shape == (nt, 5)
+    supp = m.supports(c_restricted, "all")
+    assert supp.shape[1] == 2 and ((supp[:, 0] >= 0) & (supp[:, 0] <= 0.5)).all()
+    assert m.dual(c_restricted, "all").shape == (supp.shape[0],)
+    ts = m.supports(y)[:, 0, 0]
+    early = ts <= 0.5
+    assert (Y[early] + Z <= 42 + ts[early][:, None] + 1e-7).all()
