@@ -29,7 +29,7 @@ class NewtonResult:
     multipliers: Any              # y:  ∇f(x) + J(x)'y = 0
     objective: float
     iterations: int
-    status: str                   # "first_order" | "max_iter" | "small_step"
+    status: str                   # JSO names: "first_order" | "max_iter" | "small_step" | "max_time"
     kkt_residual: float
     elapsed_s: float
     history: List[Dict[str, Any]] = field(default_factory=list)
@@ -67,13 +67,16 @@ class _Dense:
 
 
 class LagrangeNewtonSolver:
-    """``solver(model, x0, y0, **options) -> NewtonResult`` — the callable ``ExaTranscriptionBackend`` expects."""
+    """``solver(model, x0, y0, **options) -> NewtonResult`` — the callable ``ExaTranscriptionBackend`` expects.  The
+    backend's ``silent`` / time-limit settings reach it as ``print_level`` (0: quiet, 5: a line per iteration) and
+    ``max_wall_time`` — Ipopt's names and defaults (``ext/InfiniteExaModelsIpopt.jl:5-7``)."""
+    option_convention = "ipopt"
 
     def __init__(self, tol: float = 1e-8, max_iter: int = 50, delta_w: float = 1e-8, delta_c: float = 1e-10, refine="auto",
-                 linear_rtol: float = 1e-7, dense_limit: int = 3000, log=None):
+                 linear_rtol: float = 1e-7, dense_limit: int = 3000, log=None, print_level: int = 0, max_wall_time: float = 1.0e20):
         # (refine = "auto": a linear solve is refined only while its residual exceeds linear_rtol * |rhs| — an inexact Newton step)
         self.opt = dict(tol=tol, max_iter=max_iter, delta_w=delta_w, delta_c=delta_c, refine=refine, linear_rtol=linear_rtol,
-                        dense_limit=dense_limit, log=log)
+                        dense_limit=dense_limit, log=log, print_level=print_level, max_wall_time=max_wall_time)
 
     def __call__(self, model, x0=None, y0=None, **options) -> NewtonResult:
         import torch
@@ -118,10 +121,15 @@ class LagrangeNewtonSolver:
             hist.append(dict(iter=it, kkt_residual=rn, obj=model.obj(x)))
             if o["log"]:
                 o["log"](hist[-1])
+            elif int(o["print_level"]) >= 5:
+                print(f"iter {it:3d}  objective {hist[-1]['obj']: .8e}  kkt residual {rn:.3e}", flush=True)
             if rn <= o["tol"]:
                 status = "first_order"
                 break
             if it == int(o["max_iter"]):
+                break
+            if time.perf_counter() - t_start > float(o["max_wall_time"]):
+                status = "max_time"
                 break
             t0 = time.perf_counter()
             model.jac_hess_coord(x, y, jv, hv, obj_weight=1.0)

@@ -123,7 +123,7 @@ def test_lagrange_newton_solver_in_the_backend_slot(built):
     from infiniteexamodels.jl_amd.model import ExaModel, MI355XBackend
     from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
     im = workloads.quadrotor(200, backend=ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8, max_iter=40), backend=MI355XBackend()))
-    res = im.backend.optimize()
+    res = im.optimize()
     assert res.status == "first_order" and res.kkt_residual <= 1e-8 and res.iterations <= 25, res.history
     pos, neg, doubtful = res.history[-2]["inertia"]
     assert (pos, neg, doubtful) == (im.backend.model.meta.nvar, im.backend.model.meta.ncon, 0)      # a minimiser
@@ -144,6 +144,15 @@ def test_lagrange_newton_solver_in_the_backend_slot(built):
     c0 = im.constraints[0]
     con = im.backend.transformation_constraint(c0)
     assert np.array_equal(im.dual(c0), -y[con.offset:con.offset + con.length])
+    # the backend's settings reach the solver under Ipopt's option names: a time limit of nothing ends the re-solve at once
+    assert im.backend.prev_options == {} or "print_level" not in im.backend.prev_options      # not silent: the default level is not re-sent
+    im.set_time_limit_sec(0.0)
+    res2 = im.optimize()
+    assert im.backend.prev_options["max_wall_time"] == 0.0 and res2.status == "max_time" and im.termination_status() == "TIME_LIMIT"
+    im.set_time_limit_sec(None)
+    im.set_silent()
+    res3 = im.optimize()
+    assert im.backend.prev_options == {"max_wall_time": 1.0e20, "print_level": 0} and res3.status == "first_order"
     # a model without a chain (finite parameters only) goes through the dense fallback ... if it is equality-constrained;
     # rosenbrock has inequality rows: refused
     m, _ = cases.rosenbrock()
