@@ -267,6 +267,10 @@ int jit_compile(iem_model *m, const std::string &src, const std::string &dir, co
     return fail(IEM_E_COMPILE, "hiprtcCreateProgram failed");
   std::string archopt = "--offload-arch=" + arch;
   std::string cflag = contract_flag(m->opt);
+  if (src.rfind("// iem-flags:", 0) == 0) {      // the source's own flag line decides (the offline build reads the same line)
+    const size_t eol = src.find('\n'), p = src.find("-ffp-contract=");
+    if (p != std::string::npos && p < eol) cflag = src.substr(p, src.find_first_of(" \n", p) - p);
+  }
   const char *opts[] = {archopt.c_str(), "-O3", cflag.c_str(), "-std=c++17"};
   hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
   if (r != HIPRTC_SUCCESS) {
@@ -1768,7 +1772,12 @@ void kkt_shape(int nb, int ne, int *wmax, int *wpe) {
   if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) *wpe = v; }
 }
 std::string kkt_source(int nb, int ne, int nc) {
-  std::string s = "// iem-flags: -O3 -ffp-contract=off -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+  // (fused multiply-adds would be allowed here — nothing compares these kernels bit for bit — and take 1 000 of the 2 350 FP64
+  // instructions out of a 40 x 40 kkt_eliminate, but the factorisation does not get faster for it: 2.52 against 2.45 ms at 1e5
+  // quadrotor supports, 3.22 against 3.54 for the bordered OPF blocks, solves 9 % slower — the panel steps wait on their
+  // dependency chain, not on issue slots.  IEM_KKT_CONTRACT=fast switches them on; profiles/r03_kkt_shape_ab.txt)
+  const char *contract = getenv("IEM_KKT_CONTRACT");
+  std::string s = std::string("// iem-flags: -O3 -ffp-contract=") + (contract ? contract : "off") + " -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
   int wmax, wpe;
   kkt_shape(nb, ne, &wmax, &wpe);
