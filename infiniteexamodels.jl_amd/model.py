@@ -108,6 +108,9 @@ class ExaModel:
 
     # ---- lifecycle -----------------------------------------------------------
     def close(self):
+        cached = self.__dict__.pop("_newton_linear", None)     # what a solver keeps on the model between solves (newton.py)
+        if cached is not None:
+            cached[0].close()
         if getattr(self, "_h", None):
             self._L.iem_destroy(self._h)
             self._h = None

@@ -91,14 +91,22 @@ class LagrangeNewtonSolver:
             raise _lib.IemError("LagrangeNewtonSolver: the model has variable bounds or inequality rows; this solver takes equality-constrained "
                                 "models only (an interior-point method is not part of this package)")
         dev = model.device
-        kkt = KKTSystem(model)
-        try:
-            lin = ChainKKT(kkt)
-        except _lib.IemError:
-            if kkt.n > int(o["dense_limit"]):
-                kkt.close()
-                raise
-            lin = _Dense(kkt)
+        # The KKT structure of a model never changes (set_parameter! moves values only): the CSR plan, the chain layout and
+        # their device buffers are kept ON the model between solves — a re-solve (src/infiniteopt_backend.jl:511-615) starts
+        # iterating at once instead of repeating seconds of set-up.  model.close() releases them.
+        cached = getattr(model, "_newton_linear", None)
+        if cached is None:
+            kkt = KKTSystem(model)
+            try:
+                lin = ChainKKT(kkt)
+            except _lib.IemError:
+                if kkt.n > int(o["dense_limit"]):
+                    kkt.close()
+                    raise
+                lin = _Dense(kkt)
+            model._newton_linear = (kkt, lin)
+        else:
+            kkt, lin = cached
         T = lambda a: a.to(dev, torch.float64).clone() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev).clone()
         x = T(meta.x0 if x0 is None else x0)
         y = torch.zeros(m, dtype=torch.float64, device=dev) if y0 is None else T(y0)
@@ -162,6 +170,5 @@ class LagrangeNewtonSolver:
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
             hist[-1].update(step=step, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw, factorisations=tries)
-        kkt.close()
         return NewtonResult(solution=x, multipliers=y, objective=float(hist[-1]["obj"]), iterations=it, status=status, kkt_residual=rn,
                             elapsed_s=time.perf_counter() - t_start, history=hist)

@@ -8,3 +8,7 @@ im = workloads.quadrotor(100_000, backend=ExaTranscriptionBackend(LagrangeNewton
 im.set_silent()
 im.optimize()
 print(im.termination_status(), im.objective_value(), im.value(im.infinite_variables[0]).shape, im.dual(im.constraints[0]).shape, "solve_time", im.solve_time(), "total", time.time() - t0)
+# a re-solve (start values moved, as an MPC loop would): the KKT set-up is kept on the model
+im.set_start_value(im.infinite_variables[0], 0.1)
+im.optimize()
+print("re-solve:", im.termination_status(), "solve_time", im.solve_time(), "iterations", im.backend.results.iterations)
