@@ -54,6 +54,36 @@ def test_host_analysis_matches_the_python_layout(name, built):
     assert np.allclose(flat[oG:total].reshape(L.ne, L.ne), G, rtol=0, atol=1e-12 * max(1.0, np.abs(G).max() if G.size else 1.0))
 
 
+def test_host_analysis_agrees_on_every_small_case(built):
+    """grouping, coupling width, block phase — or the refusal — for every model of tests/cases.py"""
+    import warnings
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.kkt_chain import ChainLayout
+    for name in cases.small_cases():
+        if name in ("quadrotor_1000", "farmer_1000", "opf_600", "pandemic_300x7", "quadrotor_oc3_700"):
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            core = cases.build_core(name)
+        blob = core.to_blob()
+        om = OracleModel(blob)
+        jr, jc = om.jac_structure()
+        try:
+            L = ChainLayout(core.slabs, om.nvar, om.ncon, jr, jc)
+            py = (L.S, L.nb, L.ne, L.nc, L.reach, L.group, L.phase, L.n_border)
+        except iemlib.IemError as e:
+            py = str(e).split(":", 1)[1][:50]
+        try:
+            info = iemlib.kkt_analyse_blob(blob)[0]
+            cc = tuple(info[k] for k in ("S", "nb", "ne", "nc", "reach", "group", "phase", "n_border"))
+        except iemlib.IemError as e:
+            cc = str(e).split("chain KKT:", 1)[1][:50] if "chain KKT:" in str(e) else str(e)
+        if isinstance(py, str):
+            assert isinstance(cc, str) and py.split("(")[0].strip()[:24] in cc, (name, py, cc)      # both refuse, for the same reason
+        else:
+            assert py == cc, (name, py, cc)
+
+
 def test_analysis_refuses_what_the_solver_cannot_hold(built):
     from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
     big = transcribe.exa_core(workloads.pandemic(10, 40)).to_blob()     # 40 scenarios x 17 unknowns per time support
