@@ -115,9 +115,14 @@ class LagrangeNewtonSolver:
         jv = torch.empty(meta.nnzj, dtype=torch.float64, device=dev)
         hv = torch.empty(meta.nnzh, dtype=torch.float64, device=dev)
 
+        # a maximisation problem (meta.minimize false: ExaCore(minimize = false), src/transform.jl:814-815) is the minimisation
+        # of -f: the iteration runs on sgn * f — the inertia test asks for a minimiser of that — and the multipliers are
+        # handed back for f itself (grad f + J'y = 0)
+        sgn = 1.0 if bool(getattr(meta, "minimize", True)) else -1.0
+
         def residual(xx, yy):
             model.grad(xx, g); model.cons(xx, c); model.jtprod(xx, yy, jtv)
-            return torch.cat([g + jtv, c - ceq])
+            return torch.cat([sgn * g + jtv, c - ceq])
 
         hist: List[Dict[str, Any]] = []
         status, stalled = "max_iter", 0
@@ -140,7 +145,7 @@ class LagrangeNewtonSolver:
                 status = "max_time"
                 break
             t0 = time.perf_counter()
-            model.jac_hess_coord(x, y, jv, hv, obj_weight=1.0)
+            model.jac_hess_coord(x, y, jv, hv, obj_weight=sgn)
             # inertia correction as in Ipopt / MadNLP: the factorisation reports the pivot signs; while they are not
             # (nvar, ncon, 0) the Hessian block is shifted by a growing delta_w and the system factorised again
             dw, tries = float(o["delta_w"]), 0
@@ -170,5 +175,5 @@ class LagrangeNewtonSolver:
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
             hist[-1].update(step=step, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw, factorisations=tries)
-        return NewtonResult(solution=x, multipliers=y, objective=float(hist[-1]["obj"]), iterations=it, status=status, kkt_residual=rn,
+        return NewtonResult(solution=x, multipliers=sgn * y, objective=float(hist[-1]["obj"]), iterations=it, status=status, kkt_residual=rn,
                             elapsed_s=time.perf_counter() - t_start, history=hist)

@@ -160,3 +160,32 @@ def test_lagrange_newton_solver_in_the_backend_slot(built):
     with pytest.raises(iemlib.IemError, match="equality-constrained"):
         LagrangeNewtonSolver()(gm)
     gm.close()
+
+
+def test_lagrange_newton_solver_on_a_maximisation(built):
+    """``@objective(m, Max, -f)`` ends at the minimiser of ``f`` with the objective negated and multipliers that make
+    ``grad(objective) + J'y`` vanish for the objective as stated."""
+    from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
+    from infiniteexamodels.jl_amd.infinite import InfiniteModel
+    from infiniteexamodels.jl_amd.model import MI355XBackend
+    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    from pyoracle import OracleModel
+
+    def build(sense):
+        m = InfiniteModel(ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-10), backend=MI355XBackend()))
+        t = m.infinite_parameter("t", 0, 1, num_supports=70)
+        x, u = m.variable("x", t), m.variable("u", t)
+        m.constraint(m.deriv(x, t) == u - x ** 2)
+        m.constraint(x(0) == 1.0)
+        f = m.integral(x ** 2 + 0.1 * u ** 2 + 0.5 * u, t)
+        m.objective(sense, f if sense == "min" else -1.0 * f)
+        return m, x
+
+    (mn, xn), (mx, xx) = build("min"), build("max")
+    rn, rx = mn.optimize(), mx.optimize()
+    assert rn.status == "first_order" and rx.status == "first_order"
+    assert abs(mn.objective_value() + mx.objective_value()) <= 1e-9 and np.allclose(mn.value(xn), mx.value(xx), atol=1e-8)
+    om = OracleModel(mx.backend.core.to_blob())
+    xs, ys = rx.solution.cpu().numpy(), rx.multipliers.cpu().numpy()
+    assert not om.minimize and np.abs(om.grad(xs) + om.jtprod(xs, ys)).max() <= 1e-8
+    assert np.allclose(mn.dual(mn.constraints[0]), -mx.dual(mx.constraints[0]), atol=1e-7)
