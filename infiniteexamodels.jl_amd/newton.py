@@ -5,8 +5,9 @@ The reference hands its ``ExaModel`` to MadNLP (+ CUDSS) or Ipopt (``/root/refer
 and factorises the augmented system once.  For EQUALITY-constrained models without variable bounds — the quadrotor and
 hovercraft tracking problems of the reference's examples — that iteration is all there is to the method: Newton on the KKT
 conditions ``∇f + J'y = 0, c(x) = c_E`` with the regularised system ``[H + δw I, J'; J, −δc I]``, the inertia correction
-interior-point codes use (δw grows until the factorisation reports ``ncon`` negative pivots) and backtracking on the KKT
-residual.  Everything stays on the device: the five evaluation calls, the CSR assembly (``kkt.KKTSystem``), the chain KKT
+interior-point codes use (δw grows until the factorisation reports ``ncon`` negative pivots) and backtracking on the ℓ1
+merit function (with that inertia the step is a descent direction for it), a second-order correction against the Maratos
+effect.  Everything stays on the device: the five evaluation calls, the CSR assembly (``kkt.KKTSystem``), the chain KKT
 factorisation and solve (``kkt_chain.ChainKKT``); the host sees a few scalars per iteration.
 
 Models with bounds or inequality rows are REFUSED (an interior-point method is a different project — DESIGN.md §9); models
@@ -125,17 +126,18 @@ class LagrangeNewtonSolver:
             return torch.cat([sgn * g + jtv, c - ceq])
 
         hist: List[Dict[str, Any]] = []
-        status, stalled = "max_iter", 0
-        r = residual(x, y)
+        status, nu = "max_iter", 1.0
+        r = residual(x, y)                      # (leaves grad f(x) in g and c(x) in c)
+        f = model.obj(x)
         rn = float(r.abs().max().item())
         it = 0
         for it in range(int(o["max_iter"]) + 1):
             rn = float(r.abs().max().item())
-            hist.append(dict(iter=it, kkt_residual=rn, obj=model.obj(x)))
+            hist.append(dict(iter=it, kkt_residual=rn, obj=f))
             if o["log"]:
                 o["log"](hist[-1])
             elif int(o["print_level"]) >= 5:
-                print(f"iter {it:3d}  objective {hist[-1]['obj']: .8e}  kkt residual {rn:.3e}", flush=True)
+                print(f"iter {it:3d}  objective {f: .8e}  kkt residual {rn:.3e}", flush=True)
             if rn <= o["tol"]:
                 status = "first_order"
                 break
@@ -146,34 +148,69 @@ class LagrangeNewtonSolver:
                 break
             t0 = time.perf_counter()
             model.jac_hess_coord(x, y, jv, hv, obj_weight=sgn)
-            # inertia correction as in Ipopt / MadNLP: the factorisation reports the pivot signs; while they are not
-            # (nvar, ncon, 0) the Hessian block is shifted by a growing delta_w and the system factorised again
-            dw, tries = float(o["delta_w"]), 0
-            while True:
-                kkt.assemble(hv, jv, None, dw, float(o["delta_c"]))
-                lin.load().factor()
-                pos, neg, doubtful = lin.inertia()
-                tries += 1
-                if (neg == m and doubtful == 0) or tries >= 12:
-                    break
-                dw = max(1e-4, dw * 10.0)
-            d = lin.solve(-r, refine=o["refine"], rtol=float(o["linear_rtol"]))
-            dx, dy = d[:n], d[n:]
-            step, rt = 1.0, None
-            for _ in range(24):                               # backtracking on the KKT residual
-                rt = residual(x + step * dx, y + step * dy)
-                if float(rt.abs().max().item()) < rn:
-                    stalled = 0
-                    break
-                step *= 0.5
-            else:                                             # no decrease down to 1e-7 of the step: take it (the next
-                stalled += 1                                  # linearisation differs), give up after three in a row
-                if stalled >= 3:
-                    status = "small_step"
-                    break
-            x, y, r = x + step * dx, y + step * dy, rt
+            gdx_base = (sgn * g).clone()        # grad of the minimised objective at x (g is overwritten by trial points)
+            viol = float((c - ceq).abs().sum().item())
+            # Inertia correction as in Ipopt / MadNLP: the factorisation reports the pivot signs; while they are not
+            # (nvar, ncon, 0) the Hessian block is shifted by a growing delta_w and the system factorised again.  With that
+            # inertia the step is a descent direction of the l1 merit function  phi = f + nu |c - c_E|_1  (nu above the new
+            # multipliers), which the line search below backtracks on (Armijo); a full step is also taken when it reduces
+            # the KKT residual (no Maratos stall next to the solution).  A search that fails down to 2^-20 does not end in a
+            # zero step: the shift is raised tenfold — towards a gradient step — and the direction computed again.
+            dw, tries, accepted, step, searches = float(o["delta_w"]), 0, False, 0.0, 0
+            while not accepted and searches < 6:
+                searches += 1
+                while True:
+                    kkt.assemble(hv, jv, None, dw, float(o["delta_c"]))
+                    lin.load().factor()
+                    pos, neg, doubtful = lin.inertia()
+                    tries += 1
+                    if (neg == m and doubtful == 0) or tries >= 16:
+                        break
+                    dw = max(1e-4, dw * 10.0)
+                d = lin.solve(-r, refine=o["refine"], rtol=float(o["linear_rtol"]))
+                dx, dy = d[:n], d[n:]
+                # the weight follows the multipliers of THIS step — up at once, down by halves (the wild multipliers of the
+                # first iterations would otherwise price every later step by its second-order constraint violation)
+                target = 1.1 * float((y + dy).abs().max().item()) + 1e-8
+                nu = target if target >= nu else max(target, 0.5 * nu)
+                slope = float((gdx_base @ dx).item()) - nu * viol
+                phi0 = sgn * f + nu * viol
+                step = 1.0
+                for k in range(21):
+                    xt = x + step * dx
+                    ft = model.obj(xt)
+                    model.cons(xt, c)
+                    phit = sgn * ft + nu * float((c - ceq).abs().sum().item())
+                    if slope < 0.0 and phit <= phi0 + 1e-4 * step * slope:
+                        accepted = True
+                    elif k == 0 or slope >= 0.0:
+                        # the full step refused by the merit function: the watchdog judges it by the KKT residual, then a
+                        # second-order correction (the same factors, right-hand side (0; c(x + dx) - c_E)) is tried — the
+                        # Maratos effect is exactly a good step whose constraint curvature the l1 term overprices
+                        rt = residual(xt, y + step * dy)
+                        accepted = float(rt.abs().max().item()) < (1.0 - 1e-4 * step) * rn
+                        if not accepted and k == 0 and slope < 0.0:
+                            model.cons(xt, c)
+                            soc = lin.solve(-torch.cat([torch.zeros_like(x), c - ceq]), refine=o["refine"], rtol=float(o["linear_rtol"]))
+                            xs = xt + soc[:n]
+                            fs = model.obj(xs)
+                            model.cons(xs, c)
+                            if sgn * fs + nu * float((c - ceq).abs().sum().item()) <= phi0 + 1e-4 * slope:
+                                dx, dy, accepted = dx + soc[:n], dy + soc[n:], True
+                    if accepted:
+                        break
+                    step *= 0.5
+                if not accepted:
+                    dw = max(1e-4, dw * 10.0)
+            if not accepted:
+                status = "small_step"
+                break
+            x, y = x + step * dx, y + step * dy
+            r = residual(x, y)
+            f = model.obj(x)
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
-            hist[-1].update(step=step, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw, factorisations=tries)
+            hist[-1].update(step=step, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw, factorisations=tries,
+                            merit_weight=nu)
         return NewtonResult(solution=x, multipliers=sgn * y, objective=float(hist[-1]["obj"]), iterations=it, status=status, kkt_residual=rn,
                             elapsed_s=time.perf_counter() - t_start, history=hist)
