@@ -189,3 +189,28 @@ def test_lagrange_newton_solver_on_a_maximisation(built):
     xs, ys = rx.solution.cpu().numpy(), rx.multipliers.cpu().numpy()
     assert not om.minimize and np.abs(om.grad(xs) + om.jtprod(xs, ys)).max() <= 1e-8
     assert np.allclose(mn.dual(mn.constraints[0]), -mx.dual(mx.constraints[0]), atol=1e-7)
+
+
+@pytest.mark.parametrize("build, max_iterations", [
+    (lambda be: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).quadrotor(2000, backend=be), 10),   # stalled under a residual-only line search
+    (lambda be: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).quadrotor(700, collocation=3, backend=be), 10),
+    (lambda be: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).hovercraft(backend=be), 4),
+    (lambda be: __import__("infiniteexamodels.jl_amd.workloads", fromlist=["x"]).hovercraft(21, collocation=4, backend=be), 4),
+])
+def test_lagrange_newton_solver_on_the_equality_constrained_examples(built, build, max_iterations):
+    """the reference's examples without bounds or inequality rows (examples/quadrotor.jl, quadrotor_example.jl,
+    hovercraft_example.jl), from their own start values: a KKT point in a handful of iterations, feasibility and
+    stationarity re-checked through the oracle"""
+    from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
+    from infiniteexamodels.jl_amd.model import MI355XBackend
+    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    from pyoracle import OracleModel
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        im = build(ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8, max_iter=40), backend=MI355XBackend()))
+        res = im.optimize()
+    assert im.termination_status() == "LOCALLY_SOLVED" and res.iterations <= max_iterations, res.history
+    om = OracleModel(im.backend.core.to_blob())
+    x, y = res.solution.cpu().numpy(), res.multipliers.cpu().numpy()
+    assert np.abs(om.cons(x) - om.lcon).max() <= 1e-7 and np.abs(om.grad(x) + om.jtprod(x, y)).max() <= 1e-6
