@@ -10,7 +10,7 @@ merit function (with that inertia the step is a descent direction for it), a sec
 effect.  Everything stays on the device: the five evaluation calls, the CSR assembly (``kkt.KKTSystem``), the chain KKT
 factorisation and solve (``kkt_chain.ChainKKT``); the host sees a few scalars per iteration.
 
-Models with bounds or inequality rows are REFUSED (an interior-point method is a different project — DESIGN.md §9); models
+Models with bounds or inequality rows are REFUSED here (``ipm.InteriorPointSolver`` takes them); models
 whose supports do not form a chain fall back to a dense factorisation when small, and are refused otherwise.
 
     backend = ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8), backend=MI355XBackend())
@@ -90,7 +90,7 @@ class LagrangeNewtonSolver:
         n, m = meta.nvar, meta.ncon
         if np.isfinite(meta.lvar).any() or np.isfinite(meta.uvar).any() or not np.array_equal(meta.lcon, meta.ucon):
             raise _lib.IemError("LagrangeNewtonSolver: the model has variable bounds or inequality rows; this solver takes equality-constrained "
-                                "models only (an interior-point method is not part of this package)")
+                                "models only (ipm.InteriorPointSolver takes bounds and inequality rows)")
         dev = model.device
         # The KKT structure of a model never changes (set_parameter! moves values only): the CSR plan, the chain layout and
         # their device buffers are kept ON the model between solves — a re-solve (src/infiniteopt_backend.jl:511-615) starts

@@ -214,3 +214,47 @@ def test_lagrange_newton_solver_on_the_equality_constrained_examples(built, buil
     om = OracleModel(im.backend.core.to_blob())
     x, y = res.solution.cpu().numpy(), res.multipliers.cpu().numpy()
     assert np.abs(om.cons(x) - om.lcon).max() <= 1e-7 and np.abs(om.grad(x) + om.jtprod(x, y)).max() <= 1e-6
+
+
+def test_interior_point_solver_reaches_the_references_constants_on_the_device(built):
+    """``ExaTranscriptionBackend(InteriorPointSolver(), backend = MI355XBackend())``: evaluation calls, KKT assembly with the
+    barrier terms, chain factorisation (inertia) and solves on the device — the constants the reference's tests assert
+    (test/solve.jl:146,154,187,206, test/ipopt.jl:180-181) at their tolerance, Ipopt's iteration count on the warm-start
+    problem, and the two-stage LP of examples/2stage_example.jl."""
+    from infiniteexamodels.jl_amd import workloads
+    from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
+    from infiniteexamodels.jl_amd.ipm import InteriorPointSolver
+    from infiniteexamodels.jl_amd.model import MI355XBackend
+    from pyoracle import OracleModel
+    mk = lambda **kw: ExaTranscriptionBackend(InteriorPointSolver(**kw), backend=MI355XBackend())
+    m, (P1, P2) = cases.rosenbrock()
+    m.set_transformation_backend(mk())
+    m.optimize()
+    assert m.termination_status() == "LOCALLY_SOLVED" and abs(m.objective_value() - 306.4999755050365) < 1e-6
+    m.set_parameter_value(P1, 90.0)
+    m.set_parameter_value(P2, 1.3)
+    m.optimize()
+    assert abs(m.objective_value() - 276.26497794903645) < 1e-6
+    m, (pf1, pf2) = cases.pfun()
+    m.set_transformation_backend(mk())
+    m.optimize()
+    assert abs(m.objective_value() - 0.48292223509341475) < 1e-6
+    m.set_parameter_value(pf1, np.cos)
+    m.set_parameter_value(pf2, lambda t, s: np.sin(t) * s + 0.8)
+    m.optimize()
+    assert abs(m.objective_value() - 0.8155916466182952) < 1e-6
+    m = cases.ode_5x5()
+    m.set_transformation_backend(mk())
+    r = m.optimize()
+    assert abs(m.objective_value() - (-12.784599900757165)) < 1e-6 and r.iterations == 8
+    m.backend.warmstart_backend_start_values()
+    assert m.optimize().iterations < 8
+    im = workloads.farmer(2000, backend=mk(mu_from_start=True))
+    r = im.optimize()
+    assert im.termination_status() == "LOCALLY_SOLVED", (r.status, r.iterations, r.kkt_residual)
+    om = OracleModel(im.backend.core.to_blob())
+    x, y, zL, zU = (a.cpu().numpy() for a in (r.solution, r.multipliers, r.multipliers_L, r.multipliers_U))
+    c = om.cons(x)
+    tol = lambda b: 1e-7 * np.maximum(1.0, np.abs(np.where(np.isfinite(b), b, 0.0)))      # (bounds are relaxed by 1e-8 relative, as Ipopt does)
+    assert (x >= om.lvar - tol(om.lvar)).all() and (c <= om.ucon + tol(om.ucon)).all() and (c >= om.lcon - tol(om.lcon)).all()
+    assert np.abs(om.grad(x) + om.jtprod(x, y) - zL + zU).max() <= 1e-6 * max(1.0, np.abs(y).max(), np.abs(zL).max())
