@@ -45,7 +45,7 @@ class InteriorPointSolver:
 
     def __init__(self, linear: Optional[Callable] = None, **options):
         self.linear_factory = linear          # model -> linear-system object (tests inject a host one); None: the device's
-        self.opt = dict(tol=1e-8, acceptable_tol=1e-6, max_iter=300, mu_init=0.1, mu_min=1e-11, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5,
+        self.opt = dict(tol=1e-8, acceptable_tol=1e-6, acceptable_iter=15, max_iter=300, mu_init=0.1, mu_min=1e-11, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5,
                         tau_min=0.99, bound_push=1e-2, bound_frac=1e-2, bound_relax_factor=1e-8, delta_w=0.0, delta_c=1e-10,
                         refine="auto", linear_rtol=1e-8, dense_limit=3000, print_level=0, max_wall_time=1.0e20, log=None, mu_from_start=False)
         self.opt.update(options)
@@ -140,7 +140,7 @@ class InteriorPointSolver:
             return max(ed, ep, ec), ed, ep, ec
 
         hist: List[Dict[str, Any]] = []
-        status, nu, it = "max_iter", 1.0, 0
+        status, nu, it, acceptable_run = "max_iter", 1.0, 0, 0
         f = evaluate(x, y)
         e0 = errors(0.0)[0]
         for it in range(int(o["max_iter"]) + 1):
@@ -152,6 +152,10 @@ class InteriorPointSolver:
                 print(f"iter {it:3d}  objective {f: .8e}  inf_pr {ep:.2e}  inf_du {ed:.2e}  compl {ec:.2e}  mu {mu:.1e}", flush=True)
             if e0 <= float(o["tol"]):
                 status = "first_order"
+                break
+            acceptable_run = acceptable_run + 1 if e0 <= float(o["acceptable_tol"]) else 0
+            if acceptable_run >= int(o["acceptable_iter"]):      # Ipopt's acceptable termination: 15 iterations in a row below acceptable_tol
+                status = "acceptable"
                 break
             if it == int(o["max_iter"]):
                 status = "acceptable" if e0 <= float(o["acceptable_tol"]) else "max_iter"
@@ -295,10 +299,14 @@ class _DeviceLinear:
         self.lin.load()
 
     def factor(self):
-        self.lin.factor()
+        self._singular = False
+        try:
+            self.lin.factor()
+        except RuntimeError:      # the border's Schur complement did not factorise (an exactly singular system): report it as
+            self._singular = True   # doubtful pivots, the caller shifts and factorises again
 
     def inertia(self):
-        return self.lin.inertia()
+        return (0, 0, 1) if self._singular else self.lin.inertia()
 
     def solve(self, rhs, refine="auto", rtol=1e-8):
         return self.lin.solve(rhs, refine=refine, rtol=rtol)
