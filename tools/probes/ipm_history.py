@@ -11,5 +11,5 @@ im = {"pandemic": lambda: workloads.pandemic(20, 3, backend=mk()), "farmer": lam
       "kinetic": lambda: workloads.kinetic_control(20, backend=mk()), "opf": lambda: workloads.opf(7, backend=mk())}[name]()
 r = im.optimize()
 hs = r.history
-for h in hs[:12] + hs[-8:]:
-    print({k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in h.items() if k not in ("iteration_ms", "merit_weight")})
+for h in hs:
+    print(" ".join(f"{k}={(f'{v:.3g}' if isinstance(v, float) else v)}" for k, v in h.items() if k in ("iter", "obj", "dual_inf", "primal_inf", "compl", "mu", "step", "step_dual", "delta_w", "factorisations")))
