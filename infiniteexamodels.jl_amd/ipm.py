@@ -47,7 +47,8 @@ class InteriorPointSolver:
         self.linear_factory = linear          # model -> linear-system object (tests inject a host one); None: the device's
         self.opt = dict(tol=1e-8, acceptable_tol=1e-6, acceptable_iter=15, max_iter=300, mu_init=0.1, mu_min=1e-11, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5,
                         tau_min=0.99, bound_push=1e-2, bound_frac=1e-2, bound_relax_factor=1e-8, delta_w=0.0, delta_c=1e-10,
-                        refine="auto", linear_rtol=1e-8, dense_limit=3000, print_level=0, max_wall_time=1.0e20, log=None, mu_from_start=False)
+                        refine="auto", linear_rtol=1e-8, dense_limit=3000, print_level=0, max_wall_time=1.0e20, log=None, mu_from_start=False,
+                        line_search="merit")
         self.opt.update(options)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -141,6 +142,9 @@ class InteriorPointSolver:
 
         hist: List[Dict[str, Any]] = []
         status, nu, it, acceptable_run = "max_iter", 1.0, 0, 0
+        use_filter = str(o["line_search"]) == "filter"
+        filt: List[Any] = []          # (theta, phi) pairs no later iterate of this barrier problem may be dominated by
+        theta_ref = None
         f = evaluate(x, y)
         e0 = errors(0.0)[0]
         for it in range(int(o["max_iter"]) + 1):
@@ -167,6 +171,7 @@ class InteriorPointSolver:
             mu_floor = max(float(o["mu_min"]), float(o["tol"]) / 10.0)
             while mu > mu_floor and errors(mu)[0] <= float(o["kappa_eps"]) * mu:
                 mu = max(mu_floor, min(float(o["kappa_mu"]) * mu, mu ** float(o["theta_mu"])))
+                filt = []              # a new barrier problem: the filter starts again
             tau = max(float(o["tau_min"]), 1.0 - mu)
             t0 = time.perf_counter()
             model.jac_hess_coord(x, y, jv, hv, obj_weight=sgn)
@@ -230,10 +235,26 @@ class InteriorPointSolver:
                     ft = model.obj(xt)
                     model.cons(xt, c)
                     vt = float(infeasibility(c, st).abs().sum().item())
-                    phit = sgn * ft - mu * barrier(xt, st) + nu * vt
-                    if np.isfinite(phit) and phit <= phi0 + 1e-8 * step * slope + 10.0 * np.finfo(float).eps * abs(phi0):
+                    phibt = sgn * ft - mu * barrier(xt, st)
+                    phit = phibt + nu * vt
+                    if use_filter:
+                        # Ipopt's filter (Waechter & Biegler 2006, section 2.3) on (theta = |infeasibility|_1, phi = barrier objective):
+                        # an f-type step (switching condition) has to pass Armijo on phi, any other one has to improve theta or
+                        # phi over the current point; nothing dominated by a filter entry is taken
+                        if theta_ref is None:
+                            theta_ref = max(1.0, viol)
+                        slope_b = slope + nu * viol
+                        ok = np.isfinite(phibt) and vt <= 1e4 * theta_ref and not any(vt >= th and phibt >= ph for th, ph in filt)
+                        ftype = slope_b < 0.0 and viol <= 1e-4 * theta_ref and step * (-slope_b) ** 2.3 > viol ** 1.1
+                        if ok and ftype:
+                            accepted = phibt <= phi_f + 1e-8 * step * slope_b + 10.0 * np.finfo(float).eps * abs(phi_f)
+                        elif ok:
+                            accepted = vt <= (1.0 - 1e-5) * viol or phibt <= phi_f - 1e-5 * viol
+                            if accepted:
+                                filt.append(((1.0 - 1e-5) * viol, phi_f - 1e-5 * viol))
+                    elif np.isfinite(phit) and phit <= phi0 + 1e-8 * step * slope + 10.0 * np.finfo(float).eps * abs(phi0):
                         accepted = True
-                    elif k == 0 and slope < 0.0 and np.isfinite(phit):
+                    if not accepted and not use_filter and k == 0 and slope < 0.0 and np.isfinite(phit):
                         # second-order correction (the factors of this iteration, right-hand side (0; infeasibility at the trial point))
                         rpt = infeasibility(c, st)
                         soc = lin.solve(-torch.cat([torch.zeros_like(x), rpt]), refine=o["refine"], rtol=float(o["linear_rtol"]))

@@ -108,3 +108,15 @@ def test_time_limit_and_iteration_limit_statuses(built):
     hm = HostModel(cases.build_core("ode_5x5").to_blob())
     assert InteriorPointSolver(linear=HostLinear, max_iter=2)(hm).status == "max_iter"
     assert InteriorPointSolver(linear=HostLinear, max_wall_time=0.0)(hm).status == "max_time"
+
+
+@pytest.mark.parametrize("name", ["ode_5x5", "test_problem_2_obj4", "irregular"])
+def test_filter_line_search_option(built, name):
+    """``line_search = "filter"``: Ipopt's acceptance rule instead of the l1 merit function — the fifth objective form of
+    test/solve.jl:46-90 (non-convex in z) needs it"""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hm = HostModel(cases.build_core(name).to_blob())
+    r = InteriorPointSolver(linear=HostLinear, line_search="filter")(hm)
+    assert r.status == "first_order" and r.iterations <= 40, (r.status, r.iterations, r.kkt_residual)
