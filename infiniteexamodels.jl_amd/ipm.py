@@ -3,8 +3,9 @@ variable bounds and inequality rows (``newton.LagrangeNewtonSolver`` takes the e
 
 The reference hands its ``ExaModel`` to MadNLP / Ipopt (``/root/reference/README.md:36-37``, ``ext/*.jl``); this is the same
 class of method, restated compactly from the published algorithm of Ipopt (Wächter & Biegler 2006: monotone barrier update,
-fraction-to-the-boundary rule, inertia-corrected reduced KKT systems) with the ℓ1 merit function of ``newton.py`` on the
-barrier problem in place of the filter.  Per iteration: the five evaluation calls of the hot path, one assembly of
+fraction-to-the-boundary rule, inertia-corrected reduced KKT systems, the filter line search — and, there being no
+restoration phase, the ℓ1 merit function of ``newton.py`` on the barrier problem whenever the filter finds no step;
+``line_search = "merit"`` uses that one alone).  Per iteration: the five evaluation calls of the hot path, one assembly of
 
         [ H + Σx + δw I     J'   ] [dx]     [ ∇f + J'y − μ/(x − l) + μ/(u − x)        ]
         [       J          −D    ] [dy] = − [ c − c_E   |   c − s + Σs⁻¹ r_s           ]
@@ -48,7 +49,7 @@ class InteriorPointSolver:
         self.opt = dict(tol=1e-8, acceptable_tol=1e-6, acceptable_iter=15, max_iter=300, mu_init=0.1, mu_min=1e-11, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5,
                         tau_min=0.99, bound_push=1e-2, bound_frac=1e-2, bound_relax_factor=1e-8, delta_w=0.0, delta_c=1e-10,
                         refine="auto", linear_rtol=1e-8, dense_limit=3000, print_level=0, max_wall_time=1.0e20, log=None, mu_from_start=False,
-                        line_search="merit")
+                        line_search="filter")
         self.opt.update(options)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -142,7 +143,7 @@ class InteriorPointSolver:
 
         hist: List[Dict[str, Any]] = []
         status, nu, it, acceptable_run = "max_iter", 1.0, 0, 0
-        use_filter = str(o["line_search"]) == "filter"
+        filter_mode = str(o["line_search"]) == "filter"
         filt: List[Any] = []          # (theta, phi) pairs no later iterate of this barrier problem may be dominated by
         theta_ref = None
         f = evaluate(x, y)
@@ -229,47 +230,52 @@ class InteriorPointSolver:
                 nu = target if target >= nu else max(target, 0.5 * nu)
                 slope = float((gx @ dx).item()) + (float((gs @ ds).item()) if mI else 0.0) - nu * viol
                 phi0 = phi_f + nu * viol
-                step = a_max
-                for k in range(30):
-                    xt, st = x + step * dx, s + step * ds
-                    ft = model.obj(xt)
-                    model.cons(xt, c)
-                    vt = float(infeasibility(c, st).abs().sum().item())
-                    phibt = sgn * ft - mu * barrier(xt, st)
-                    phit = phibt + nu * vt
-                    if use_filter:
-                        # Ipopt's filter (Waechter & Biegler 2006, section 2.3) on (theta = |infeasibility|_1, phi = barrier objective):
-                        # an f-type step (switching condition) has to pass Armijo on phi, any other one has to improve theta or
-                        # phi over the current point; nothing dominated by a filter entry is taken
-                        if theta_ref is None:
-                            theta_ref = max(1.0, viol)
-                        slope_b = slope + nu * viol
-                        ok = np.isfinite(phibt) and vt <= 1e4 * theta_ref and not any(vt >= th and phibt >= ph for th, ph in filt)
-                        ftype = slope_b < 0.0 and viol <= 1e-4 * theta_ref and step * (-slope_b) ** 2.3 > viol ** 1.1
-                        if ok and ftype:
-                            accepted = phibt <= phi_f + 1e-8 * step * slope_b + 10.0 * np.finfo(float).eps * abs(phi_f)
-                        elif ok:
-                            accepted = vt <= (1.0 - 1e-5) * viol or phibt <= phi_f - 1e-5 * viol
-                            if accepted:
-                                filt.append(((1.0 - 1e-5) * viol, phi_f - 1e-5 * viol))
-                    elif np.isfinite(phit) and phit <= phi0 + 1e-8 * step * slope + 10.0 * np.finfo(float).eps * abs(phi0):
-                        accepted = True
-                    if not accepted and not use_filter and k == 0 and slope < 0.0 and np.isfinite(phit):
-                        # second-order correction (the factors of this iteration, right-hand side (0; infeasibility at the trial point))
-                        rpt = infeasibility(c, st)
-                        soc = lin.solve(-torch.cat([torch.zeros_like(x), rpt]), refine=o["refine"], rtol=float(o["linear_rtol"]))
-                        dx2 = dx * step + soc[:n]
-                        ds2 = ds * step + (soc[n:][ine_idx] / torch.clamp(sig_s, min=1e-300) if mI else ds * 0)
-                        a2 = min(ftb(x, dx2, dL, dU), ftb(s, ds2, eL, eU) if mI else 1.0)
-                        xs_, ss_ = x + a2 * dx2, s + a2 * ds2
-                        fs = model.obj(xs_)
-                        model.cons(xs_, c)
-                        phis = sgn * fs - mu * barrier(xs_, ss_) + nu * float(infeasibility(c, ss_).abs().sum().item())
-                        if np.isfinite(phis) and phis <= phi0 + 1e-8 * a2 * slope:
-                            dx, ds, dy, step, accepted = dx2, ds2, dy * step + soc[n:], a2, True
+                # (a filter search that finds no step falls back to the merit function for this iteration — there is no
+                # restoration phase to send it to)
+                for use_filter in ((True, False) if filter_mode else (False,)):
                     if accepted:
                         break
-                    step *= 0.5
+                    step = a_max
+                    for k in range(30):
+                        xt, st = x + step * dx, s + step * ds
+                        ft = model.obj(xt)
+                        model.cons(xt, c)
+                        vt = float(infeasibility(c, st).abs().sum().item())
+                        phibt = sgn * ft - mu * barrier(xt, st)
+                        phit = phibt + nu * vt
+                        if use_filter:
+                            # Ipopt's filter (Waechter & Biegler 2006, section 2.3) on (theta = |infeasibility|_1, phi = barrier objective):
+                            # an f-type step (switching condition) has to pass Armijo on phi, any other one has to improve theta or
+                            # phi over the current point; nothing dominated by a filter entry is taken
+                            if theta_ref is None:
+                                theta_ref = max(1.0, viol)
+                            slope_b = slope + nu * viol
+                            ok = np.isfinite(phibt) and vt <= 1e4 * theta_ref and not any(vt >= th and phibt >= ph for th, ph in filt)
+                            ftype = slope_b < 0.0 and viol <= 1e-4 * theta_ref and step * (-slope_b) ** 2.3 > viol ** 1.1
+                            if ok and ftype:
+                                accepted = phibt <= phi_f + 1e-8 * step * slope_b + 10.0 * np.finfo(float).eps * abs(phi_f)
+                            elif ok:
+                                accepted = vt <= (1.0 - 1e-5) * viol or phibt <= phi_f - 1e-5 * viol
+                                if accepted:
+                                    filt.append(((1.0 - 1e-5) * viol, phi_f - 1e-5 * viol))
+                        elif np.isfinite(phit) and phit <= phi0 + 1e-8 * step * slope + 10.0 * np.finfo(float).eps * abs(phi0):
+                            accepted = True
+                        if not accepted and not use_filter and k == 0 and slope < 0.0 and np.isfinite(phit):
+                            # second-order correction (the factors of this iteration, right-hand side (0; infeasibility at the trial point))
+                            rpt = infeasibility(c, st)
+                            soc = lin.solve(-torch.cat([torch.zeros_like(x), rpt]), refine=o["refine"], rtol=float(o["linear_rtol"]))
+                            dx2 = dx * step + soc[:n]
+                            ds2 = ds * step + (soc[n:][ine_idx] / torch.clamp(sig_s, min=1e-300) if mI else ds * 0)
+                            a2 = min(ftb(x, dx2, dL, dU), ftb(s, ds2, eL, eU) if mI else 1.0)
+                            xs_, ss_ = x + a2 * dx2, s + a2 * ds2
+                            fs = model.obj(xs_)
+                            model.cons(xs_, c)
+                            phis = sgn * fs - mu * barrier(xs_, ss_) + nu * float(infeasibility(c, ss_).abs().sum().item())
+                            if np.isfinite(phis) and phis <= phi0 + 1e-8 * a2 * slope:
+                                dx, ds, dy, step, accepted = dx2, ds2, dy * step + soc[n:], a2, True
+                        if accepted:
+                            break
+                        step *= 0.5
                 if not accepted:
                     dw = 1e-4 if dw == 0.0 else dw * 10.0
             if not accepted:

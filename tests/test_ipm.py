@@ -111,12 +111,14 @@ def test_time_limit_and_iteration_limit_statuses(built):
 
 
 @pytest.mark.parametrize("name", ["ode_5x5", "test_problem_2_obj4", "irregular"])
-def test_filter_line_search_option(built, name):
-    """``line_search = "filter"``: Ipopt's acceptance rule instead of the l1 merit function — the fifth objective form of
-    test/solve.jl:46-90 (non-convex in z) needs it"""
+def test_filter_line_search(built, name):
+    """the default acceptance rule (Ipopt's filter, the l1 merit function as its fallback): the fifth objective form of
+    test/solve.jl:46-90 (non-convex in z) needs it; ``line_search = "merit"`` remains as an option"""
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         hm = HostModel(cases.build_core(name).to_blob())
-    r = InteriorPointSolver(linear=HostLinear, line_search="filter")(hm)
+    r = InteriorPointSolver(linear=HostLinear)(hm)
     assert r.status == "first_order" and r.iterations <= 40, (r.status, r.iterations, r.kkt_residual)
+    if name == "ode_5x5":
+        assert InteriorPointSolver(linear=HostLinear, line_search="merit")(hm).status == "first_order"
