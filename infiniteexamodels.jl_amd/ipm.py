@@ -49,7 +49,7 @@ class InteriorPointSolver:
         self.opt = dict(tol=1e-8, acceptable_tol=1e-6, acceptable_iter=15, max_iter=300, mu_init=0.1, mu_min=1e-11, kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5,
                         tau_min=0.99, bound_push=1e-2, bound_frac=1e-2, bound_relax_factor=1e-8, delta_w=0.0, delta_c=1e-10,
                         refine="auto", linear_rtol=1e-8, dense_limit=3000, print_level=0, max_wall_time=1.0e20, log=None, mu_from_start=False,
-                        line_search="filter")
+                        line_search="filter", nlp_scaling_max_gradient=100.0)
         self.opt.update(options)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -64,6 +64,11 @@ class InteriorPointSolver:
         f64 = torch.float64
         T = lambda a: a.to(dev, f64).clone() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev).clone()
         sgn = 1.0 if bool(getattr(meta, "minimize", True)) else -1.0
+        lin = self.linear_factory(model) if self.linear_factory is not None else _device_linear(model, int(o["dense_limit"]))
+        scaled = None
+        if float(o["nlp_scaling_max_gradient"]) > 0.0 and n:
+            scaled = model = _Scaled(model, T(meta.x0 if x0 is None else x0), float(o["nlp_scaling_max_gradient"]))
+            meta = model.meta
         lvar, uvar, lcon, ucon = (np.asarray(a, dtype=np.float64) for a in (meta.lvar, meta.uvar, meta.lcon, meta.ucon))
         relax = float(o["bound_relax_factor"])      # (a fixed variable, lvar == uvar, becomes an interval of twice this width)
         rl = lambda b: b - relax * np.maximum(1.0, np.abs(b))      # Ipopt relaxes every finite bound a little (bound_relax_factor)
@@ -77,7 +82,6 @@ class InteriorPointSolver:
         ceq = T(np.where(eq, lcon, 0.0))
         ine_idx = torch.as_tensor(np.nonzero(ine)[0], device=dev, dtype=torch.int64)
         eq_mask = torch.as_tensor(eq, device=dev)
-        lin = self.linear_factory(model) if self.linear_factory is not None else _device_linear(model, int(o["dense_limit"]))
 
         def push(v, lo, hi, has_lo, has_hi):      # the start point strictly inside (Ipopt: bound_push / bound_frac)
             k1, k2 = float(o["bound_push"]), float(o["bound_frac"])
@@ -94,6 +98,8 @@ class InteriorPointSolver:
         model.cons(x, c)
         s = push(c[ine_idx].clone(), sl, su, Ls, Us)
         y = torch.zeros(m, dtype=f64, device=dev) if y0 is None else sgn * T(y0)
+        if scaled is not None and y0 is not None:
+            y = y * scaled.df / scaled.dc
         zL, zU = torch.where(Lx, torch.ones_like(x), torch.zeros_like(x)), torch.where(Ux, torch.ones_like(x), torch.zeros_like(x))
         vL, vU = torch.where(Ls, torch.ones_like(s), torch.zeros_like(s)), torch.where(Us, torch.ones_like(s), torch.zeros_like(s))
         mu = float(o["mu_init"])
@@ -150,11 +156,11 @@ class InteriorPointSolver:
         e0 = errors(0.0)[0]
         for it in range(int(o["max_iter"]) + 1):
             e0, ed, ep, ec = errors(0.0)
-            hist.append(dict(iter=it, obj=f, kkt_residual=e0, dual_inf=ed, primal_inf=ep, compl=ec, mu=mu))
+            hist.append(dict(iter=it, obj=f / (scaled.df if scaled is not None else 1.0), kkt_residual=e0, dual_inf=ed, primal_inf=ep, compl=ec, mu=mu))
             if o["log"]:
                 o["log"](hist[-1])
             elif int(o["print_level"]) >= 5:
-                print(f"iter {it:3d}  objective {f: .8e}  inf_pr {ep:.2e}  inf_du {ed:.2e}  compl {ec:.2e}  mu {mu:.1e}", flush=True)
+                print(f"iter {it:3d}  objective {hist[-1]['obj']: .8e}  inf_pr {ep:.2e}  inf_du {ed:.2e}  compl {ec:.2e}  mu {mu:.1e}", flush=True)
             if e0 <= float(o["tol"]):
                 status = "first_order"
                 break
@@ -295,8 +301,62 @@ class InteriorPointSolver:
                 torch.cuda.synchronize(dev)
             hist[-1].update(step=step, step_dual=a_z, iteration_ms=(time.perf_counter() - t0) * 1e3, inertia=(pos, neg, doubtful), delta_w=dw,
                             factorisations=tries, merit_weight=nu)
+        if scaled is not None:
+            y, zL, zU = scaled.unscale(y, zL, zU)
+            f = f / scaled.df
         return IPMResult(solution=x, multipliers=sgn * y, multipliers_L=sgn * zL, multipliers_U=sgn * zU,
                          objective=float(f), iterations=it, status=status, kkt_residual=float(e0), elapsed_s=time.perf_counter() - t_start, history=hist)
+
+
+class _Scaled:
+    """Gradient-based scaling (Ipopt's ``nlp_scaling_method = gradient-based``): the objective and every constraint row are
+    multiplied by ``min(1, max_gradient / largest entry of its gradient at the start point)`` — a population of 1e5 people or a
+    rate constant of 1e12 otherwise decide the step lengths.  The solver iterates on the scaled functions; ``unscale`` turns
+    its multipliers into those of the model as stated."""
+
+    def __init__(self, model, x0, max_gradient: float):
+        import torch
+        self.inner, self.device = model, model.device
+        meta = model.meta
+        g = model.grad(x0)
+        gmax = float(g.abs().max().item()) if g.numel() else 0.0
+        self.df = min(1.0, max_gradient / gmax) if gmax > 0.0 else 1.0
+        m = int(meta.ncon)
+        self.dc = torch.ones(m, dtype=torch.float64, device=self.device)
+        if m and int(meta.nnzj):
+            rows = model.jac_structure_device(0)[0]
+            jv = torch.empty(int(meta.nnzj), dtype=torch.float64, device=self.device)
+            hv = torch.empty(int(meta.nnzh), dtype=torch.float64, device=self.device)
+            model.jac_hess_coord(x0, torch.zeros(m, dtype=torch.float64, device=self.device), jv, hv, obj_weight=0.0)
+            rowmax = torch.zeros(m, dtype=torch.float64, device=self.device).scatter_reduce(0, rows, jv.abs(), reduce="amax")
+            self.dc = torch.where(rowmax > max_gradient, max_gradient / rowmax, torch.ones_like(rowmax))
+            self.rows = rows
+        dcn = self.dc.cpu().numpy()
+        self.meta = type("ScaledMeta", (), dict(nvar=meta.nvar, ncon=meta.ncon, nnzj=meta.nnzj, nnzh=meta.nnzh, x0=meta.x0, lvar=meta.lvar,
+                                                uvar=meta.uvar, lcon=np.asarray(meta.lcon) * dcn, ucon=np.asarray(meta.ucon) * dcn,
+                                                minimize=getattr(meta, "minimize", True)))()
+
+    def obj(self, x):
+        return self.df * self.inner.obj(x)
+
+    def grad(self, x, g=None):
+        g = self.inner.grad(x, g)
+        return g.mul_(self.df)
+
+    def cons(self, x, c=None):
+        c = self.inner.cons(x, c)
+        return c.mul_(self.dc)
+
+    def jtprod(self, x, v, out=None):
+        return self.inner.jtprod(x, v * self.dc, out)
+
+    def jac_hess_coord(self, x, y, jac=None, hess=None, obj_weight: float = 1.0):
+        self.inner.jac_hess_coord(x, y * self.dc, jac, hess, obj_weight=obj_weight * self.df)
+        jac.mul_(self.dc[self.rows])
+        return jac, hess
+
+    def unscale(self, y, zL, zU):
+        return y * self.dc / self.df, zL / self.df, zU / self.df
 
 
 class _DeviceLinear:

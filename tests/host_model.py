@@ -35,6 +35,9 @@ class HostModel:
         w = torch.from_numpy(np.ascontiguousarray(self.om.jtprod(self._np(x), self._np(v))))
         return w if out is None else out.copy_(w)
 
+    def jac_structure_device(self, base=0):
+        return torch.from_numpy(self.jr + base), torch.from_numpy(self.jc + base)
+
     def jac_hess_coord(self, x, y, jac=None, hess=None, obj_weight=1.0):
         jac.copy_(torch.from_numpy(self.om.jac_coord(self._np(x))))
         hess.copy_(torch.from_numpy(self.om.hess_coord(self._np(x), self._np(y), float(obj_weight))))

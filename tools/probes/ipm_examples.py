@@ -12,7 +12,7 @@ from infiniteexamodels.jl_amd.ipm import InteriorPointSolver
 from infiniteexamodels.jl_amd.model import MI355XBackend
 
 MU = bool(int(os.environ.get("IPM_MU_FROM_START", "0")))
-mk = lambda **kw: ExaTranscriptionBackend(InteriorPointSolver(tol=1e-8, mu_from_start=MU, line_search=os.environ.get("IPM_LINE_SEARCH", "merit"), **kw), backend=MI355XBackend())
+mk = lambda **kw: ExaTranscriptionBackend(InteriorPointSolver(tol=1e-8, mu_from_start=MU, line_search=os.environ.get("IPM_LINE_SEARCH", "filter"), **kw), backend=MI355XBackend())
 def from_case(fn):
     def build():
         m = fn()
