@@ -249,6 +249,9 @@ def test_interior_point_solver_reaches_the_references_constants_on_the_device(bu
     assert abs(m.objective_value() - (-12.784599900757165)) < 1e-6 and r.iterations == 8
     m.backend.warmstart_backend_start_values()
     assert m.optimize().iterations < 8
+    om7 = workloads.opf(7, backend=mk())                       # ESCAPE34/opf.jl: bounds, inequality rows, a fixed reference angle
+    r7 = om7.optimize()
+    assert om7.termination_status() == "LOCALLY_SOLVED" and r7.iterations <= 60, (r7.status, r7.iterations, r7.kkt_residual)
     im = workloads.farmer(2000, backend=mk(mu_from_start=True))
     r = im.optimize()
     assert im.termination_status() == "LOCALLY_SOLVED", (r.status, r.iterations, r.kkt_residual)

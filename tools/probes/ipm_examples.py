@@ -26,6 +26,7 @@ table = {"rosenbrock": from_case(cases.rosenbrock), "pfun": from_case(cases.pfun
          "test_problem_2_obj0": from_case(lambda: cases.test_problem_2(0)), "test_problem_2_obj2": from_case(lambda: cases.test_problem_2(2)),
          "farmer 100": lambda: workloads.farmer(100, backend=mk()), "farmer 10000": lambda: workloads.farmer(10000, backend=mk()),
          "opf 7": lambda: workloads.opf(7, backend=mk()), "opf 1000": lambda: workloads.opf(1000, backend=mk()),
+         "opf 10000": lambda: workloads.opf(10000, backend=mk()), "farmer 100000": lambda: workloads.farmer(100000, backend=mk()),
          "pandemic 20 x 3": lambda: workloads.pandemic(20, 3, backend=mk()), "pandemic 500 x 3": lambda: workloads.pandemic(500, 3, backend=mk()),
          "kinetic 20": lambda: workloads.kinetic_control(20, backend=mk()), "kinetic 2000": lambda: workloads.kinetic_control(2000, backend=mk()),
          "3-node 50": lambda: workloads.three_node_design(50, backend=mk()), "3-node 5000": lambda: workloads.three_node_design(5000, backend=mk()),
