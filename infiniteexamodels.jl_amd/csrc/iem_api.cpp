@@ -1923,16 +1923,20 @@ int kkt_upload_bytes(void **d, const void *h, size_t bytes) {
 #define kkt_upload(dptr, vec) kkt_upload_bytes((void **)(dptr), (vec).data(), (vec).size() * sizeof((vec)[0]))
 // column sums of a device S x w matrix, to the host
 int kkt_colsum_host(iem_kkt *k, const double *d_in, int64_t rows, int64_t w, std::vector<double> &out) {
+  // two launches: up to 512 row chunks x column chunks of 256 (every CU busy: the border terms of 1e4 OPF scenarios are 216 MB),
+  // then the partials into one row; w doubles come home
   iem_model *m = k->m;
-  const int64_t per = 256, nwg = (rows + per - 1) / per;
-  struct { const double *in; double *out; long long rows, w, rows_per_wg; } A{d_in, k->d_part, (long long)rows, (long long)w, (long long)per};
-  int rc = kkt_launch_raw(m, k->km->colsum, &A, sizeof A, nwg, 256);
+  const int64_t ncc = (w + 255) / 256, per = (rows + 511) / 512, nrc = (rows + per - 1) / per;
+  struct Sum { const double *in; double *out; long long rows, w, rows_per_wg; };
+  Sum A{d_in, k->d_part, (long long)rows, (long long)w, (long long)per};
+  int rc = kkt_launch_raw(m, k->km->colsum, &A, sizeof A, nrc * ncc, 256);
   if (rc) return rc;
-  std::vector<double> part((size_t)(nwg * w));
-  HIP_TRY(hipStreamSynchronize(m->stream));
-  HIP_TRY(hipMemcpy(part.data(), k->d_part, part.size() * 8, hipMemcpyDeviceToHost));
+  double *d_row = k->d_part + 512 * w;
+  Sum B{k->d_part, d_row, (long long)nrc, (long long)w, (long long)nrc};
+  if ((rc = kkt_launch_raw(m, k->km->colsum, &B, sizeof B, ncc, 256))) return rc;
   out.assign((size_t)w, 0.0);
-  for (int64_t b = 0; b < nwg; ++b) for (int64_t c = 0; c < w; ++c) out[(size_t)c] += part[(size_t)(b * w + c)];
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipMemcpy(out.data(), d_row, (size_t)w * 8, hipMemcpyDeviceToHost));
   return IEM_OK;
 }
 }  // namespace
@@ -2005,7 +2009,7 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
     HIP_TRY(hipMalloc((void **)&k->d_z, (size_t)(S * nb) * 8));
     HIP_TRY(hipMalloc((void **)&k->d_rBp, (size_t)std::max<int64_t>(S * ne, 1) * 8));
     HIP_TRY(hipMalloc((void **)&k->d_xB, (size_t)std::max<int64_t>(ne, 1) * 8));
-    HIP_TRY(hipMalloc((void **)&k->d_part, (size_t)std::max<int64_t>(((S + 255) / 256) * std::max<int64_t>(ne * ne, 1), 1) * 8));
+    HIP_TRY(hipMalloc((void **)&k->d_part, (size_t)(513 * std::max<int64_t>(ne * ne, 1)) * 8));      // kkt_colsum_host: 512 partial rows + the result
     HIP_TRY(hipMalloc((void **)&k->d_info, 32));
   } catch (const std::exception &e) {
     return fail(IEM_E_ARG, e.what());

@@ -641,15 +641,17 @@ extern "C" __global__ __launch_bounds__(256) void kkt_move(const KktMoveArgs A) 
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < A.n) A.dst[A.di[i]] = A.src[A.si[i]];
 }
-// column sums of an S x w matrix (per-block border terms): partial[b][c] over rows b R .. , then one more pass over the partials
+// column sums of a rows x w matrix (per-block border terms): workgroup b sums the rows of chunk b / ncc for the 256 columns of
+// chunk b % ncc (ncc = ceil(w / 256)) into out[chunk][column]; a second launch over the partials leaves one row
 struct KktSumArgs { const double *in; double *out; long long rows, w, rows_per_wg; };
 extern "C" __global__ __launch_bounds__(256) void kkt_colsum(const KktSumArgs A) {
-  const long long r0 = (long long)blockIdx.x * A.rows_per_wg, r1 = r0 + A.rows_per_wg < A.rows ? r0 + A.rows_per_wg : A.rows;
-  for (long long c = threadIdx.x; c < A.w; c += 256) {
-    double acc = 0.0;
-    for (long long r = r0; r < r1; ++r) acc += A.in[r * A.w + c];
-    A.out[(long long)blockIdx.x * A.w + c] = acc;
-  }
+  const long long ncc = (A.w + 255) / 256, rc = (long long)blockIdx.x / ncc, cc = (long long)blockIdx.x % ncc;
+  const long long c = cc * 256 + threadIdx.x;
+  if (c >= A.w) return;
+  const long long r0 = rc * A.rows_per_wg, r1 = r0 + A.rows_per_wg < A.rows ? r0 + A.rows_per_wg : A.rows;
+  double acc = 0.0;
+  for (long long r = r0; r < r1; ++r) acc += A.in[r * A.w + c];
+  A.out[rc * A.w + c] = acc;
 }
 
 #endif  // IEM_KKT_DEVICE_H

@@ -251,9 +251,12 @@ inline KktPlan kkt_plan(const KktLayout &L, const std::vector<int64_t> &hr, cons
 // eigenvalues of a small symmetric matrix (cyclic Jacobi): the inertia of the border's Schur complement
 inline void sym_eigenvalues(std::vector<double> a, int n, std::vector<double> &ev) {
   for (int sweep = 0; sweep < 60; ++sweep) {
-    double offd = 0.0;
-    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) offd += a[(size_t)(i * n + j)] * a[(size_t)(i * n + j)];
-    if (offd < 1e-300) break;
+    double offd = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i) {
+      diag += a[(size_t)(i * n + i)] * a[(size_t)(i * n + i)];
+      for (int j = i + 1; j < n; ++j) offd += a[(size_t)(i * n + j)] * a[(size_t)(i * n + j)];
+    }
+    if (offd <= 1e-30 * diag || offd < 1e-300) break;      // (relative: a converged sweep leaves rounding, not zero)
     for (int p = 0; p < n; ++p)
       for (int q = p + 1; q < n; ++q) {
         const double apq = a[(size_t)(p * n + q)];
