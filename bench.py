@@ -6,9 +6,10 @@ same run.
 
   python bench.py --gpus N --steps K --warmup W [--supports S] [--scaling strong|weak]
 
-A "step" is one jac_coord! + one hess_coord! over the resident model (inputs already in HBM) — by default through
-iem_jac_hess_coord, the C-ABI's one-launch form of the pair (identical bytes; `--separate` times the two calls, and the
-form that is not the timed one is always reported beside it: "separate_calls" / "fused_pair").  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the time
+A "step" is one jac_coord! + one hess_coord! over the resident model (inputs already in HBM): the metric's own call pair,
+iem_jac_coord + iem_hess_coord — what an NLPModels solver makes (ext/InfiniteExaModelsIpopt.jl:48-49,
+ext/InfiniteExaModelsMadNLP.jl:49-50).  The C-ABI's one-launch form of the pair (iem_jac_hess_coord, identical bytes) is
+reported beside it as "fused_pair" (`--fused` makes IT the timed step; then "separate_calls" is the one beside).  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the time
 axis is sharded into contiguous support blocks (halo of one support for the
 finite-difference rows); jac_coord!/hess_coord! need no collective, so ranks only meet
 at the barriers that bracket the timed region.
@@ -243,7 +244,7 @@ def comm_isolated(args, dist, rank, world, local_rank, barrier):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--comm-child", "--gpus", str(world), "--dist-backend", "gloo", "--supports", str(args.supports),
            "--scaling", args.scaling, "--steps", str(min(args.steps, 200)), "--warmup", "3", "--store-mode", str(args.store_mode),
-           "--hess-layout", args.hess_layout, "--no-cold"] + (["--same-device"] if args.same_device else []) + (["--separate"] if args.separate else []) + [a for kv in args.opt for a in ("--opt", kv)]
+           "--hess-layout", args.hess_layout, "--no-cold"] + (["--same-device"] if args.same_device else []) + (["--fused"] if args.fused else []) + [a for kv in args.opt for a in ("--opt", kv)]
     out, rc = "", -1
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -290,9 +291,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the jac+hess pair from a captured HIP graph instead of eager launches")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the (untimed) check of the halo exchange / objective all-reduce")
     ap.add_argument("--comm-child", action="store_true", help=argparse.SUPPRESS)   # internal: run ONLY the comm section (see comm_isolated)
-    ap.add_argument("--separate", action="store_true", help="the timed step is iem_jac_coord + iem_hess_coord (two launches) instead of "
-                    "iem_jac_hess_coord (one launch, the default); the other form is always reported beside it")
-    ap.add_argument("--fused", action="store_true", help=argparse.SUPPRESS)   # (the default; kept so older command lines still parse)
+    ap.add_argument("--fused", action="store_true", help="the timed step is iem_jac_hess_coord (one launch) instead of the metric's own call pair "
+                    "iem_jac_coord + iem_hess_coord (two launches, the default); the other form is always reported beside it")
+    ap.add_argument("--separate", action="store_true", help=argparse.SUPPRESS)   # (the default; kept so older command lines still parse)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-input measurement (K rotating x / y sets)")
     ap.add_argument("--rotate-inputs", type=int, default=0, metavar="K",
                     help="cold-input measurement (roofline.frac_cold_inputs): K distinct (x, y) sets cycled per call; 0 = as many as "
@@ -303,7 +304,6 @@ def main():
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU, no evaluation, NOT a measurement: spawn / rendezvous / reduce only (CPU test of the N>1 launch path)")
     args = ap.parse_args()
-    args.fused = not args.separate
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -450,12 +450,16 @@ def main():
                     pass
         barrier()
         torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events over the timed region, on the launch stream
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(steps):
             step()
+        ev1.record()
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+        halo_state["loop_event_ms"] = ev0.elapsed_time(ev1) / steps
         if halo_state["in_loop"]:
             halo_state["status"] = gm.comm_status()     # 0: every exchange of the timed loop completed
         if use_dist:
@@ -515,17 +519,22 @@ def main():
     pair_ms = np.array([a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])])
 
     has_pair = any(k["kind"] == "pair" for k in gm.kernels())
-    # average duration of the fused kernel: an event pair around every launch, launches back to back (what rocprofv3
-    # --kernel-trace --stats reports as the kernel's average)
-    pair_kernel_ms = None
-    if has_pair:
-        pe = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(100)]
+
+    def block_ms(fn, n=100):
+        """average launch duration of ONE kernel: n launches back to back between ONE pair of HIP events on the launch stream
+        (an event pair around every launch adds ~3 us to each; rocprofv3 --kernel-trace --stats of this command reports the same average)"""
         for _ in range(5):
-            gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0)
-        for a, b in pe:
-            a.record(); gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0); b.record()
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
         torch.cuda.synchronize()
-        pair_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in pe]))
+        return a.elapsed_time(b) / n
+    ms_jac_blk = block_ms(lambda: gm.jac_coord(xd, jac))
+    ms_hess_blk = block_ms(lambda: gm.hess_coord(xd, yd, hess, obj_weight=1.0))
+    pair_kernel_ms = block_ms(lambda: gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0)) if has_pair else None
     # the same pair with COLD inputs: K distinct (x, y) sets, > 256 MiB in total, cycled per call — per-kernel events
     cold = None
     if world == 1 and not args.no_cold and not args.graph:
@@ -534,24 +543,23 @@ def main():
         xs = [xd] + [xd + 1e-3 * (i + 1) for i in range(K - 1)]
         ys = [yd] + [yd * (1.0 + 1e-3 * (i + 1)) for i in range(K - 1)]
         nc = 20 * K if gm.meta.nvar < 5_000_000 else 4 * K
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nc)]
-        for i in range(K):
-            gm.jac_coord(xs[i], jac); gm.hess_coord(xs[i], ys[i], hess, obj_weight=1.0)
-        torch.cuda.synchronize()
-        for i in range(nc):
-            evs[i][0].record(); gm.jac_coord(xs[i % K], jac)
-            evs[i][1].record(); gm.hess_coord(xs[i % K], ys[i % K], hess, obj_weight=1.0)
-            evs[i][2].record()
-        torch.cuda.synchronize()
-        cold = {"sets": K, "input_bytes_total": int(8 * K * (gm.meta.nvar + gm.meta.ncon)),
-                "jac_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
-                "hess_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))}
-        if has_pair:
+
+        def rot_ms(fn):      # nc calls, inputs cycled per call, between ONE event pair
+            for i in range(K):
+                fn(i)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
             for i in range(nc):
-                evs[i][0].record(); gm.jac_hess_coord(xs[i % K], ys[i % K], jac, hess, obj_weight=1.0)
-                evs[i][1].record()
+                fn(i % K)
+            b.record()
             torch.cuda.synchronize()
-            cold["pair_kernel_ms"] = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+            return a.elapsed_time(b) / nc
+        cold = {"sets": K, "input_bytes_total": int(8 * K * (gm.meta.nvar + gm.meta.ncon)),
+                "jac_ms": rot_ms(lambda i: gm.jac_coord(xs[i], jac)),
+                "hess_ms": rot_ms(lambda i: gm.hess_coord(xs[i], ys[i], hess, obj_weight=1.0)),
+                "two_calls_ms": rot_ms(lambda i: (gm.jac_coord(xs[i], jac), gm.hess_coord(xs[i], ys[i], hess, obj_weight=1.0)))}
+        if has_pair:
+            cold["pair_kernel_ms"] = rot_ms(lambda i: gm.jac_hess_coord(xs[i], ys[i], jac, hess, obj_weight=1.0))
         del xs, ys
 
     reads_all = None
@@ -562,15 +570,18 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = supports_total / 1e6 * args.steps / dt
-        # roofline of the dominant kernel, timed live with HIP events on the launch stream
-        ms_jac, ms_hess = gm.time_kernels(xd, yd, jac, hess, iters=100)
+        # roofline of the dominant kernel: its algorithmic bytes / its average launch duration, the latter from blocks of
+        # back-to-back launches between ONE pair of HIP events on the launch stream (block_ms) — never per-launch event pairs
+        ms_jac, ms_hess = ms_jac_blk, ms_hess_blk
         ks = {k["kind"]: k for k in gm.kernels() if k["kind"] in ("jac", "hess") and k["grid"][0] > 1}
-        pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())
+        pair_alg = sum(k["alg_bytes_read"] + k["alg_bytes_written"] for k in ks.values())     # two calls: each reads its own inputs
+        fused_kd = dict([k for k in gm.kernels() if k["kind"] == "pair"][0]) if has_pair else None
+        fused_alg = (fused_kd["alg_bytes_read"] + fused_kd["alg_bytes_written"]) if has_pair else None   # ONE launch: inputs both bodies load counted once
         if args.fused and has_pair:
             # the timed step is ONE kernel (both calls' workgroups behind one dispatcher): it is the dominant kernel
             dom = "pair"
-            kd = dict([k for k in gm.kernels() if k["kind"] == "pair"][0])
-            alg, ms_dom = pair_alg, pair_kernel_ms     # (x7..x9, u1..u3 and h are loaded by both kinds' workgroups: counted per kind, as for the two calls)
+            kd = fused_kd
+            alg, ms_dom = fused_alg, pair_kernel_ms
         else:
             dom = "hess" if ms_hess >= ms_jac else "jac"
             kd = dict(ks[dom])
@@ -600,16 +611,22 @@ def main():
         roof = {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
                 "traffic_stale": stale, "traffic_source": traffic_src, "csrc_fingerprint": csrc_fingerprint(),
-                "alg_bytes": alg, "kernel_ms": ms_dom,
-                "jac_ms": ms_jac, "hess_ms": ms_hess, "pair_alg_bytes": pair_alg,
-                "pair_frac": pair_alg / ((ms_jac + ms_hess) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "alg_bytes": alg, "kernel_ms": ms_dom, "kernel_ms_from": "100 back-to-back launches between one pair of HIP events on the launch stream",
+                "jac_ms": ms_jac, "hess_ms": ms_hess,
+                "jac_frac": (ks["jac"]["alg_bytes_read"] + ks["jac"]["alg_bytes_written"]) / (ms_jac * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hess_frac": (ks["hess"]["alg_bytes_read"] + ks["hess"]["alg_bytes_written"]) / (ms_hess * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "pair_alg_bytes": fused_alg if (args.fused and has_pair) else pair_alg,
+                # the step's own fraction, from the HIP events that bracket the TIMED loop (all K steps between one event pair)
+                "step_event_ms": halo_state.get("loop_event_ms"),
+                "pair_frac": (fused_alg if (args.fused and has_pair) else pair_alg) / (halo_state["loop_event_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if pair_kernel_ms is not None:
             roof["pair_kernel_ms"] = pair_kernel_ms
-            roof["pair_kernel_frac"] = pair_alg / (pair_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["pair_kernel_alg_bytes"] = fused_alg
+            roof["pair_kernel_frac"] = fused_alg / (pair_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if cold:
             cms = cold.get("pair_kernel_ms") if dom == "pair" else cold["hess_ms"] if dom == "hess" else cold["jac_ms"]
             roof["frac_cold_inputs"] = alg / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            roof["pair_frac_cold_inputs"] = pair_alg / ((cold["jac_ms"] + cold["hess_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["pair_frac_cold_inputs"] = pair_alg / (cold["two_calls_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["cold_inputs"] = cold
         line = {
             "metric": "jac_coord!+hess_coord! evals/sec, quadrotor 1e6 supports; % HBM roofline",

@@ -163,7 +163,10 @@ int iem_halo_exchange(iem_model *m, double *d_x);
  * comes first, it gets the stand-alone exchange kernel in front of it — exactly iem_halo_exchange.  In solver order (obj,
  * grad!, cons!, jac_coord!, hess_coord! at a new point: ext/InfiniteExaModelsIpopt.jl:48-49) the exchange rides on obj and is
  * complete before cons! starts.  A call that neither touches nor can carry (grad!, the products) leaves it deferred;
- * iem_halo_wait, iem_synchronize, iem_halo_fold, iem_comm_status and a further exchange flush it (stand-alone kernel).
+ * iem_halo_wait, iem_synchronize, iem_halo_fold, iem_allreduce_obj_grad, iem_comm_status and a further exchange flush it
+ * (stand-alone kernel).  ORDERING RULE: every rank issues its mailbox kernels in the same order — whether an evaluation
+ * call carries or flushes a deferred exchange depends on the rank's own halo (rank 0 has none), so no collective
+ * (fold, all-reduce) ever overtakes a deferred exchange: each flushes it first.
  * Contract: between this call and the evaluation call that carries it (or iem_halo_wait) the caller enqueues nothing that
  * writes d_x or reads its halo entries.  Graph-capturable (the decision is taken at capture time; a replay repeats it).
  * iem_halo_reads: for kernel kind `kind` (iem_kernel_info_t.kind): can it touch a halo entry through x / through a

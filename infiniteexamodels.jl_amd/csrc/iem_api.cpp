@@ -834,6 +834,10 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   }
   if (std::strcmp(name, "pair_kernel") == 0) { o.pair_kernel = (int)value; return IEM_OK; }
   if (std::strcmp(name, "store_wait") == 0) { o.store_wait = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "carrier") == 0) { o.carrier = value != 0; return IEM_OK; }
+  if (std::strcmp(name, "jac_split") == 0) { if (value < 0 || value > 2) return fail(IEM_E_ARG, "jac_split must be 0, 1 or 2"); o.jac_split = (int)value; return IEM_OK; }
+  if (std::strcmp(name, "jac_split_min") == 0) { if (value < 0) return fail(IEM_E_ARG, "jac_split_min must be >= 0"); o.jac_split_min = value; return IEM_OK; }
+  if (std::strcmp(name, "pair_inter") == 0) { o.pair_inter = value != 0; return IEM_OK; }
   if (std::strcmp(name, "comm_timeout_ms") == 0) {
     if (value < 1 || value > 600000) return fail(IEM_E_ARG, "comm_timeout_ms must be in 1..600000");
     o.comm_timeout_ms = (int)value;
@@ -974,6 +978,7 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
     if (shard_group > 0) {   // cut this rank's window out of the global model (iem_shard.hpp)
       iem::shard_model(m->model, shard_group, rank, world, m->shard);
       m->sharded = true;
+      m->opt.carrier = 1;    // only a sharded handle's kernels carry the halo-exchange prologue (iem_halo_exchange_async)
       // continue from the shard's own blob — byte for byte what iem_shard_blob hands out — so that the
       // generated source (hence the code-object cache key) is the one an offline build of that blob gets,
       // and the global arrays nothing references any more (x0/lvar/uvar of the whole model) are released
@@ -1731,6 +1736,10 @@ int iem_allreduce_obj_grad(iem_model *m, double *d_obj, double *d_g) {
   if (!m->connected) return fail(IEM_E_ARG, "iem_allreduce_obj_grad: not connected (iem_comm_connect)");
   if (!d_g && m->n_shared) return fail(IEM_E_ARG, "null gradient but the model has replicated variables");
   DevGuard dg_(m->device);
+  // Every rank must issue its mailbox kernels in the SAME order.  Whether an evaluation call in between flushed a deferred
+  // exchange depends on the rank (rank 0 holds no halo copies: its reads_halo is false), so a collective never overtakes a
+  // deferred exchange: it goes first, as in iem_halo_fold / iem_comm_status / iem_synchronize.
+  { int rc = halo_flush(m); if (rc) return rc; }
   const iem::ShardInfo &si = m->shard;
   const long long G = (long long)reduce_chunks(1 + m->n_shared);
   struct { double *obj, *g; const long long *shared; unsigned long long *const *peers; long long NR, NH, W, rank, G; unsigned long long *hstatus; long long ticks; } A = {

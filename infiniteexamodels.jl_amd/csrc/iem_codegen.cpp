@@ -22,6 +22,7 @@
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -1273,6 +1274,19 @@ class KernelBuilder {
   const std::vector<ILoad> &iloads() const { return iloads_; }
   const std::vector<int> &ia_arrays() const { return iav_; }
   const Group &group() const { return g_; }
+  // after emit(): index ranges of every array the kernel's live loads touch (key: 0 x, 1 theta, 2 y, 4 v, 100 + slot item
+  // columns by MODEL array id) — generate() takes the union over the bodies of one launch, so that an input two bodies
+  // load is counted once in the launch's algorithmic bytes
+  std::map<int, std::vector<std::pair<int64_t, int64_t>>> read_ranges() const {
+    std::map<int, std::vector<std::pair<int64_t, int64_t>>> out;
+    for (auto &kv : ranges_) {
+      const int key = kv.first >= 100 ? 100 + fav_[kv.first - 100] : kv.first;   // local fa slot -> model array id
+      auto &dst = out[key];
+      dst.insert(dst.end(), kv.second.begin(), kv.second.end());
+    }
+    return out;
+  }
+  int64_t iload_elems() const { return iload_elems_; }
 
   // ---- emission -----------------------------------------------------------------
   std::string aff_str(const AffQ &a) {
@@ -1768,7 +1782,8 @@ class KernelBuilder {
         }
         elems += cur_hi - cur_lo + 1;
       }
-      kd.alg_bytes_read = 8 * (elems + (int64_t)iloads_.size() * g_.ext[0] * g_.ext[1] * g_.ext[2]);
+      iload_elems_ = (int64_t)iloads_.size() * g_.ext[0] * g_.ext[1] * g_.ext[2];
+      kd.alg_bytes_read = 8 * (elems + iload_elems_);
       if (kind_ == KK_GRAD || kind_ == KK_JTPROD || kind_ == KK_HPROD) {
         // scatter kinds: one write per item of every slot that is still its own (merge_scatter sums a lane's
         // addends into one slot; entries reduced by the last workgroup are a handful) plus the fused zero fill
@@ -1880,7 +1895,29 @@ class KernelBuilder {
   // kinds whose kernels can carry a pending halo exchange as an extra leading workgroup: the block-store kinds (their
   // bodies never look at gridDim.x); the objective's and the pair's wrappers add theirs in generate()
   bool carrier() const {
-    return kind_ == KK_CONS || kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_JPROD;
+    return opt_.carrier && (kind_ == KK_CONS || kind_ == KK_JAC || kind_ == KK_HESS || kind_ == KK_JPROD);
+  }
+  // templates of this builder whose output values are pure ITEM DATA: constants and item columns only — nothing of x, theta,
+  // y or v is loaded for them (the partials of a linear row).  generate() gives them a body of their own (Options::jac_split).
+  std::set<int> data_only_templates() const {
+    std::set<int> data, computed;
+    for (const Output &o : outs_) {
+      bool pure = true;
+      std::vector<int> st(o.vals.begin(), o.vals.end());
+      std::set<int> seen;
+      while (!st.empty() && pure) {
+        const int id = st.back(); st.pop_back();
+        if (id < 0 || !seen.insert(id).second) continue;
+        const VNode &n = v_[id];
+        if (n.op == VLD) { if (loads_[n.sub].arr != 3) pure = false; }
+        else if (n.op == VW) pure = false;
+        else if (n.op == VUN || n.op == VGUARD) st.push_back(n.a);
+        else if (n.op == VBIN || n.op == VSEL) { st.push_back(n.a); st.push_back(n.b); }
+      }
+      (pure ? data : computed).insert(o.tpl);
+    }
+    for (int t : computed) data.erase(t);
+    return data;
   }
   // values coordinate d takes over the launch domain (a folded group derives q1, q2 from q0)
   void coord_range(int d, int64_t &lo, int64_t &hi) const {
@@ -1932,7 +1969,7 @@ class KernelBuilder {
   std::vector<double> dpv_;
   std::map<int, int> fa_ids_, ia_ids_;
   std::vector<int> fav_, iav_;
-  int64_t alg_w_ = 0, alg_r_loads_ = 0;
+  int64_t alg_w_ = 0, alg_r_loads_ = 0, iload_elems_ = 0;
   std::vector<char> lazy_load_;   // per load: 0 in the head, 1 at first use (not yet emitted), 2 emitted
   std::vector<std::pair<int64_t, int64_t>> zero_fill_;  // [lo, hi) ranges of OUT this kernel zeroes itself
   SharedInfo shared_;
@@ -2267,6 +2304,69 @@ static Options kind_options(const Options &opt, const std::vector<Group> &groups
   return ko;
 }
 
+// algorithmic bytes READ by one launch of several bodies: every distinct input element once (the union of the bodies' ranges)
+template <class Builders>
+static int64_t union_read_bytes(const Builders &bs) {
+  std::map<int, std::vector<std::pair<int64_t, int64_t>>> all;
+  int64_t elems = 0;
+  for (const auto *b : bs) {
+    for (auto &kv : b->read_ranges()) { auto &d = all[kv.first]; d.insert(d.end(), kv.second.begin(), kv.second.end()); }
+    elems += b->iload_elems();
+  }
+  for (auto &kv : all) {
+    auto &v = kv.second;
+    if (v.empty()) continue;
+    std::sort(v.begin(), v.end());
+    int64_t lo = v[0].first, hi = v[0].second;
+    for (size_t i = 1; i < v.size(); ++i) {
+      if (v[i].first <= hi + 1) hi = std::max(hi, v[i].second);
+      else { elems += hi - lo + 1; lo = v[i].first; hi = v[i].second; }
+    }
+    elems += hi - lo + 1;
+  }
+  return 8 * elems;
+}
+
+// Workgroup-id dispatch over a few bodies (<= 4) of one launch: body j owns the workgroups [first_j, first_j + n_j) —
+// except a LEADING RUN of `run` bodies with one common grid, whose workgroups are interleaved so that all of them are
+// resident together (Options::jac_split / pair_inter).  mode 1: workgroup r of the run -> body r % run, tile r / run;
+// mode 2: in runs of 8 consecutive workgroups (hardware deals workgroups round-robin over the 8 XCDs: every XCD then
+// works on every body), the last n % 8 tiles of each body behind them.  `dec`: decode table {first, gx, gy, gz} per body.
+static void emit_dispatch_chain(std::ostream &src, size_t nb, size_t dec, size_t run, int mode, const std::vector<bool> &remap,
+                                const std::function<std::string(size_t, const std::string &)> &call,
+                                const std::function<std::string(size_t)> &extra) {
+  size_t j0 = 0;
+  if (run >= 2) {
+    const size_t e = dec;
+    src << "  ";
+    if (run < nb) src << "if (b < A.ip[" << (dec + 4 * run) << "]) ";
+    src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
+        << "    const long long n_ = gx * gy * gz, r_ = b - A.ip[" << e << "];\n    long long j_, lq_;\n";
+    if (mode == 1)
+      src << "    j_ = r_ % " << run << "; lq_ = r_ / " << run << ";\n";
+    else
+      src << "    { const long long f_ = (n_ >> 3) * " << (8 * run) << ";\n"
+          << "      if (r_ < f_) { j_ = (r_ >> 3) % " << run << "; lq_ = (r_ / " << (8 * run) << ") * 8 + (r_ & 7); }\n"
+          << "      else { const long long t_ = n_ & 7, q_ = r_ - f_; j_ = q_ / t_; lq_ = (n_ & ~7LL) + q_ % t_; } }\n";
+    src << "    const long long lb = " << (remap[0] ? "iem_xcd_remap(lq_, n_)" : "lq_") << ";\n";
+    for (size_t j = 0; j < run; ++j) {
+      src << "    " << (j ? "else " : "");
+      if (j + 1 < run) src << "if (j_ == " << j << ") ";
+      src << "{\n" << extra(j) << call(j, "      ") << "    }\n";
+    }
+    src << "  }\n";
+    j0 = run;
+  }
+  for (size_t j = j0; j < nb; ++j) {
+    const size_t e = dec + 4 * j;
+    src << "  " << (j ? "else " : "");
+    if (j + 1 < nb) src << "if (b < A.ip[" << (e + 4) << "]) ";
+    src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
+        << "    const long long lb = " << (remap[j] ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
+        << extra(j) << call(j, "    ") << "  }\n";
+  }
+}
+
 Program generate(const Model &m, const Options &opt_in) {
   validate_indices(m);
   Options opt = opt_in;
@@ -2313,6 +2413,9 @@ Program generate(const Model &m, const Options &opt_in) {
   std::vector<std::unique_ptr<KernelBuilder>> builders;
   std::vector<KernelDesc> descs;
   std::vector<Options> kopts;   // the options each builder was made with (kind_options)
+  std::deque<Group> sub_groups;  // Options::jac_split: the two halves of a support grid's templates (builders keep references)
+  std::map<size_t, std::pair<const Group *, std::string>> whole_of;   // desc index of a split body's FIRST half -> (the whole grid, its kernel name)
+  std::set<size_t> second_half;
 
   auto is_scatter = [](int kind) { return kind == KK_GRAD || kind == KK_JTPROD || kind == KK_HPROD; };
   // a handle's second code object (the tuner's large store batch) carries a tag in its kernel names, so that a
@@ -2329,6 +2432,34 @@ Program generate(const Model &m, const Options &opt_in) {
       const Options ko = kind_options(opt, pass ? groups_fused : groups, kind);
       auto kb = std::make_unique<KernelBuilder>(m, g, kind, ko, name);
       if (!kb->build(nullptr)) continue;
+      if (kind == KK_JAC && opt.jac_split > 0 && !opt.no_fuse && ko.store_mode == 2 && g.grid_id > 0) {
+        // a large grid: the templates whose partials are item data get a body of their own (Options::jac_split)
+        KernelDesc probe;
+        launch_grid(g, kb->qstep(), probe);
+        const std::set<int> data = kb->data_only_templates();
+        int n_data = 0, n_comp = 0;   // lane templates on either side (scalars follow their class, but never make a body)
+        for (int ti : g.tpls) if (kb->relevant(m.tpl[ti])) (data.count(ti) ? n_data : n_comp)++;
+        if (probe.n_blocks > opt.jac_split_min && n_data > 0 && n_comp > 0) {
+          for (int half = 0; half < 2; ++half) {
+            sub_groups.push_back(g);
+            Group &sg = sub_groups.back();
+            sg.tpls.clear(); sg.scalars.clear();
+            for (int ti : g.tpls) if ((data.count(ti) != 0) == (half == 0)) sg.tpls.push_back(ti);
+            for (int ti : g.scalars) if ((data.count(ti) != 0 || !kb->relevant(m.tpl[ti])) == (half == 0)) sg.scalars.push_back(ti);
+            const std::string hname = name + (half ? "b" : "a");
+            auto hb = std::make_unique<KernelBuilder>(m, sg, kind, ko, hname);
+            if (!hb->build(nullptr)) throw std::runtime_error("internal: empty half of a split jac_coord! body");
+            KernelDesc hd;
+            hd.name = hname; hd.kind = kind; hd.block = ko.block; hd.lds_slots = ko.lds_slots; hd.inter = (int)gi;
+            launch_grid(sg, hb->qstep(), hd);
+            if (half == 0) whole_of[descs.size()] = {&g, name}; else second_half.insert(descs.size());
+            builders.push_back(std::move(hb));
+            descs.push_back(hd);
+            kopts.push_back(ko);
+          }
+          continue;
+        }
+      }
       if (kind == KK_HESS && opt.hess_merge) kb->merge_hess(P.nnzh_merged, P.hess_classes);
       KernelDesc kd;
       kd.name = name;
@@ -2708,6 +2839,11 @@ Program generate(const Model &m, const Options &opt_in) {
       F.lds_slots = std::max(F.lds_slots, d.lds_slots);
     }
     if (F.grid[0] > 2147483647LL) throw std::runtime_error("support grids too large for one launch");
+    {
+      std::vector<const KernelBuilder *> bs;
+      for (size_t k : ks) bs.push_back(builders[k].get());
+      F.alg_bytes_read = union_read_bytes(bs);
+    }
     const int64_t n_tiles = F.grid[0];
     // workgroup decode table: per body {first workgroup, gx, gy, gz} (launch-size dependent -> arguments)
     const size_t dec = F.ip.size();
@@ -2768,9 +2904,11 @@ Program generate(const Model &m, const Options &opt_in) {
     if (is_obj) {
       // every lane adds the terms of its tiles b, b + gridDim.x, ... in that order; the body index only grows
       // (a pending halo exchange rides on this launch as one extra leading workgroup; the walkers are the others)
+      if (opt.carrier)
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
           << "  const long long bx_ = (long long)blockIdx.x - cb_, gx_ = (long long)gridDim.x - cb_;\n";
+      else src << "  const long long bx_ = (long long)blockIdx.x, gx_ = (long long)gridDim.x;\n";
       src << "  double acc = 0.0;\n  int j_ = 0;\n"
           << "  for (long long b = bx_; b < A.ip[" << nt_slot << "]; b += gx_) {\n";
       if (ks.size() > 1)
@@ -2800,7 +2938,7 @@ Program generate(const Model &m, const Options &opt_in) {
       P.kernels.push_back(F);
       continue;
     }
-    if (!si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
+    if (opt.carrier && !si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
           << "  const long long b = (long long)blockIdx.x - cb_;\n";
@@ -2827,15 +2965,15 @@ Program generate(const Model &m, const Options &opt_in) {
       src << "  switch (lo_) {\n";
       for (size_t j = 0; j < ks.size(); ++j) src << "    case " << j << ":\n" << call(j, "      ") << "      break;\n";
       src << "  }\n";
-    } else
-    for (size_t j = 0; j < ks.size(); ++j) {
-      const size_t e = dec + 4 * j;
-      src << "  " << (j ? "else " : "");
-      if (j + 1 < ks.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
-      src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-          << "    const long long lb = " << (kopts[ks[j]].xcd_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n";
-      if (si) src << "    wg_ = A.ip[" << (sh_off + j) << "] + lb;\n";
-      src << call(j, "    ") << "  }\n";
+    } else {
+      // leading bodies that share an interleave class and a grid (the two halves of a split jac_coord!) take turns
+      size_t run = 1;
+      while (run < ks.size() && descs[ks[0]].inter >= 0 && descs[ks[run]].inter == descs[ks[0]].inter && descs[ks[run]].n_blocks == descs[ks[0]].n_blocks &&
+             descs[ks[run]].grid[0] == descs[ks[0]].grid[0] && descs[ks[run]].grid[1] == descs[ks[0]].grid[1]) ++run;
+      std::vector<bool> rm;
+      for (size_t k : ks) rm.push_back(kopts[k].xcd_remap != 0);
+      emit_dispatch_chain(src, ks.size(), dec, si ? 1 : run, opt.jac_split == 1 ? 1 : 2, rm, call,
+                          [&](size_t j) { return si ? "    wg_ = A.ip[" + std::to_string(sh_off + j) + "] + lb;\n" : std::string(); });
     }
     if (si) src << KernelBuilder::shared_epilogue(*si, "A.ip + " + std::to_string(sh_tbl), "wg_", "lds_blk", sh_lds);
     src << "}\n\n";
@@ -2863,11 +3001,16 @@ Program generate(const Model &m, const Options &opt_in) {
       int64_t nnz_again = 0;
       std::vector<HessClass> classes_again;
       for (size_t k : ks) {   // in the order of the first pass: the merged Hessian layout's offsets are running counters
+        // (jac_coord!'s two halves, Options::jac_split, are ONE body again here unless pair_inter asks for interleaved bodies:
+        // measured, the pair is fastest as jac_coord!'s workgroups followed by hess_coord!'s — 0.155 ms against 0.159 - 0.165
+        // for any interleaving at 1e6 quadrotor supports, profiles/r04_ab_jac_split.txt)
+        const bool rejoin = !opt.pair_inter && whole_of.count(k);
+        if (!opt.pair_inter && second_half.count(k)) continue;
         KernelDesc kd;
-        kd.name = descs[k].name + "_p"; kd.kind = descs[k].kind; kd.block = descs[k].block; kd.lds_slots = descs[k].lds_slots;
+        kd.name = (rejoin ? whole_of[k].second : descs[k].name) + "_p"; kd.kind = descs[k].kind; kd.block = descs[k].block; kd.lds_slots = descs[k].lds_slots; kd.inter = rejoin ? -1 : descs[k].inter;
         for (int d = 0; d < 3; ++d) kd.grid[d] = descs[k].grid[d];
         kd.n_blocks = descs[k].n_blocks;
-        auto kb = std::make_unique<KernelBuilder>(m, builders[k]->group(), kd.kind, kopts[k], kd.name);
+        auto kb = std::make_unique<KernelBuilder>(m, rejoin ? *whole_of[k].first : builders[k]->group(), kd.kind, kopts[k], kd.name);
         if (!kb->build(nullptr)) throw std::runtime_error("internal: pair body without outputs");
         if (kd.kind == KK_HESS && opt.hess_merge) kb->merge_hess(nnz_again, classes_again);
         pb.push_back(std::move(kb));
@@ -2896,6 +3039,11 @@ Program generate(const Model &m, const Options &opt_in) {
         F.x_ranges.insert(F.x_ranges.end(), d.x_ranges.begin(), d.x_ranges.end());
         F.lds_slots = std::max(F.lds_slots, d.lds_slots);
       }
+      {
+        std::vector<const KernelBuilder *> bs;
+        for (auto &b : pb) bs.push_back(b.get());
+        F.alg_bytes_read = union_read_bytes(bs);   // x7..x9, u1..u3, h are loaded by both kinds' bodies: counted once
+      }
       if (F.grid[0] <= 2147483647LL) {   // (larger: the two calls stay separate launches)
         F.n_blocks = F.grid[0];
         const size_t dec = F.ip.size();
@@ -2920,10 +3068,12 @@ Program generate(const Model &m, const Options &opt_in) {
             << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
         if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
         else src << "  double* lds_blk = nullptr;\n";
-        src << "  double* lds4 = nullptr;\n"
-            << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
+        src << "  double* lds4 = nullptr;\n";
+        if (opt.carrier)
+        src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
             << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
             << "  const long long b = (long long)blockIdx.x - cb_;\n";
+        else src << "  const long long b = blockIdx.x;\n";
         auto call = [&](size_t jj, const std::string &ind) {
           const KernelDesc &d = pd[ord[jj]];
           std::ostringstream c;
@@ -2942,15 +3092,18 @@ Program generate(const Model &m, const Options &opt_in) {
               << ";\n  switch (lo_) {\n";
           for (size_t jj = 0; jj < ord.size(); ++jj) src << "    case " << jj << ":\n" << call(jj, "      ") << "      break;\n";
           src << "  }\n";
-        } else
-          for (size_t jj = 0; jj < ord.size(); ++jj) {
-            const size_t e = dec + 4 * jj;
-            src << "  " << (jj ? "else " : "");
-            if (jj + 1 < ord.size()) src << "if (b < A.ip[" << (e + 4) << "]) ";
-            src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-                << "    const long long lb = " << (pxcd[ord[jj]] ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
-                << call(jj, "    ") << "  }\n";
-          }
+        } else {
+          // bodies of one grid (jac_coord!'s halves and hess_coord! of the same support grid) take turns: all resident together
+          size_t run = 1;
+          auto same = [&](size_t a, size_t b2) {
+            return pd[ord[a]].n_blocks == pd[ord[b2]].n_blocks && pd[ord[a]].grid[0] == pd[ord[b2]].grid[0] && pd[ord[a]].grid[1] == pd[ord[b2]].grid[1] &&
+                   pxcd[ord[a]] == pxcd[ord[b2]] && (opt.pair_inter || (pd[ord[a]].inter >= 0 && pd[ord[a]].inter == pd[ord[b2]].inter));
+          };
+          while (run < ord.size() && same(0, run)) ++run;
+          std::vector<bool> rm;
+          for (size_t jj = 0; jj < ord.size(); ++jj) rm.push_back(pxcd[ord[jj]]);
+          emit_dispatch_chain(src, ord.size(), dec, run, opt.jac_split == 1 ? 1 : 2, rm, call, [](size_t) { return std::string(); });
+        }
         src << "}\n\n";
         P.kernels.push_back(F);
       }

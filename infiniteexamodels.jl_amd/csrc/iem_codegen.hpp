@@ -35,6 +35,7 @@ struct KernelDesc {
   // calls must wait for an asynchronous halo exchange (iem_halo_exchange_async) and which may overlap it
   std::vector<std::pair<int64_t, int64_t>> x_ranges, v_ranges;
   int lds_slots = 0;        // the staging batch this kernel was generated with (Options::lds_slots or its large-grid override)
+  int inter = -1;           // >= 0: bodies of one launch with the same value (and the same grid) have their workgroups interleaved
 };
 
 struct Options {
@@ -102,6 +103,19 @@ struct Options {
   int fold_max_n = 6;      // ... for at most this many rows per element (the clones of a derivative row grow with its square)
   int pair_kernel = 1;     // 1: also emit the fused jac_coord! + hess_coord! launch (KK_PAIR, iem_jac_hess_coord)
   int store_wait = 0;      // experiment: s_waitcnt vmcnt(0) behind every flushed batch (paces a wave's outstanding stores)
+  // 1: the kernels of the carrier kinds (cons!, jac_coord!, hess_coord!, jprod!, obj, the pair) can carry a deferred halo
+  // exchange as one extra leading workgroup (iem_halo_wg).  Set by iem_create_sharded; an unsharded handle's kernels have no
+  // such prologue (and no LDS word for it) at all.
+  int carrier = 0;
+  // jac_coord! of a lane-fused support grid runs as TWO bodies behind the dispatcher, their
+  // workgroups interleaved so that both are resident: body a = the templates whose partials are item data or constants
+  // (linear rows: difference rows h, -1, +1 of src/transform.jl:511-562, affine dynamics) — no x load, no arithmetic, a
+  // fill-shaped body; body b = the rest (loads, trigonometry).  Halves the store fronts a workgroup keeps open; same bytes.
+  // 1: bodies alternate workgroup by workgroup; 2: in runs of 8 workgroups (one per XCD), so every XCD sees both; 0: off
+  int jac_split = 1;
+  int64_t jac_split_min = 0;    // ... only grids of more workgroups than this (0: every lane-fused grid — the source stays size-independent)
+  int pair_inter = 0;      // the fused pair: 1 = bodies of equal grids (jac_coord!'s halves, hess_coord!) interleaved the same way; 0 (default,
+                           // measured faster) = jac_coord! as ONE body, its workgroups first, hess_coord!'s behind them
   // runtime only (the generator ignores them)
   int comm_timeout_ms = 5000;   // bound of every mailbox wait (halo exchange / fold / all-reduce kernels)
 };

@@ -113,6 +113,18 @@ def main():
         vd.copy_(torch.tensor(vl))
         for out in (c, jv, hv, g, jt, hp, jp):
             out.fill_(float("nan"))
+        if use_async and not use_graph:
+            # ORDERING RULE (include/iem.h): a collective never overtakes a deferred exchange.  grad! neither touches a halo
+            # entry nor carries; iem_allreduce_obj_grad must flush the exchange FIRST on every rank — the halo entries are
+            # in x after a plain device synchronisation (iem_synchronize / iem_comm_status, which flush too, are not called)
+            xo = xd.clone()
+            gm.halo_exchange_async(xo)
+            if not gm.halo_reads()["grad"][0]:
+                gm.grad(xo, g)
+            gm.allreduce_obj_grad(f, g)
+            torch.cuda.synchronize()
+            assert np.array_equal(xo.cpu().numpy(), xg[vm]), "iem_allreduce_obj_grad overtook a deferred halo exchange"
+            g.fill_(float("nan"))
         if use_graph and it >= 2:
             if graph is None:                              # iterations 0, 1 ran eagerly (warm-up); capture once, replay after
                 graph = torch.cuda.CUDAGraph()

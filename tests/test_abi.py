@@ -114,7 +114,7 @@ def test_launch_plan_reports_algorithmic_bytes(lane_fused):
     from infiniteexamodels.jl_amd import transcribe, workloads
     S = 4096
     plan = iemlib.emit_launch_plan(transcribe.exa_core(workloads.quadrotor(S)).to_blob())
-    jac = [l for l in plan.splitlines() if l.startswith("kernel iem_jac_g0")][0].split()
+    jac = [l for l in plan.splitlines() if l.startswith("kernel iem_jac_")][0].split()   # (one launch: iem_jac_all = the data body + the computed body)
     rbytes, wbytes = int(jac[jac.index("rbytes") + 1]), int(jac[jac.index("wbytes") + 1])
     assert wbytes == 8 * (62 * S - 18)
     assert 8 * (6 * S + (S - 1)) <= rbytes <= 8 * 7 * S   # 6 x-slabs + the stencil column

@@ -115,9 +115,13 @@ def test_cross_template_cse(lane_fused):
     """x7 feeds six templates: its load and its sincos appear once per lane in the fused kernel."""
     from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
     src, _ = iemlib.emit_source(transcribe.exa_core(workloads.quadrotor(100)).to_blob())
-    jac = src[src.index("void iem_jac_g0"):src.index("void iem_hess_g0")]
+    jac = src[src.index("void iem_jac_g0b_body"):src.index("void iem_hess_g0")]
     assert jac.count("sincos(") == 3 and jac.count(" tan(") == 1
     assert jac.count("? X[") == 6   # x7, x8, x9, u1, u2, u3 (u4 and every affine row enter linearly: no loads)
+    # the rows whose partials are item data (difference rows h, -1, +1; affine dynamics; point constraints) sit in a body of
+    # their own (Options::jac_split): no x load, no arithmetic
+    data = src[src.index("void iem_jac_g0a_body"):src.index("void iem_jac_g0b_body")]
+    assert "X[" not in data.split("{", 1)[1] and "sincos(" not in data and data.count("iem_stage<3>") == 9 and data.count("iem_stage<2>") == 3
 
 
 @pytest.mark.parametrize("name", ["quadrotor_100", "pandemic_20x3", "opf_7", "operator_zoo", "irregular", "rosenbrock"])
@@ -436,8 +440,12 @@ def test_a_carried_halo_exchange_leaves_every_tile_in_place(name, grid_mode):
     om = OracleModel(blob)
     x, y = cases.eval_point_for(name, om)
     v = np.random.default_rng(5).standard_normal(om.nvar)
+    from infiniteexamodels.jl_amd import lib as iemlib
     ref = EmulatedModel(core, blob)
-    em = EmulatedModel(core, blob)
+    assert "iem_halo_wg(*A.comm" not in ref.source      # an unsharded handle's kernels have no carrier prologue at all
+    with iemlib.options(carrier=1):                     # (what iem_create_sharded sets)
+        em = EmulatedModel(core, blob)
+    assert "iem_halo_wg(*A.comm" in em.source
     em.carry = True
     block = em.kernels[0]["block"]
     n = 0
