@@ -221,6 +221,21 @@ int iem_hess_coord(iem_model *m, const double *d_x, const double *d_y, double ob
  * kinds are resident together. */
 int iem_jac_hess_coord(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_jac, double *d_hess);
 
+/* One launch per SOLVER PHASE (extensions; identical bytes to the separate calls, which remain).  An interior-point solver
+ * evaluates obj + cons! at every trial point of its line search and grad! + jac_coord! + hess_coord! once per accepted
+ * point (ext/InfiniteExaModelsMadNLP.jl:49-50,64, ext/InfiniteExaModelsIpopt.jl:48-49 of the reference); on the grids
+ * the reference benchmarks (ESCAPE34/run_cases_gpu.jl:89-102: 1 000 - 16 000 supports) every call is one 5-7 us launch,
+ * so the phase costs what its launches cost.
+ *   iem_eval_trial     c = cons(x) into d_c and f = obj(x): returned in *h_obj (the call then waits for the scalar, like
+ *                      iem_obj), or — h_obj == NULL — collected later by iem_obj_end (the call arms it like iem_obj_begin)
+ *   iem_eval_accepted  g = grad(x), jac values, Lagrangian Hessian values (obj_weight, y) — asynchronous on the stream
+ * Outputs are fully overwritten.  Handles without the fused kernels make the separate calls themselves. */
+int iem_eval_trial(iem_model *m, const double *d_x, double *d_c, double *h_obj /* may be NULL */);
+int iem_eval_accepted(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_g, double *d_jac, double *d_hess);
+/* ... and all five of ONE point in one launch — the solver's first trial point is usually the accepted one; h_obj as above */
+int iem_eval_all(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_c, double *d_g, double *d_jac, double *d_hess,
+                 double *h_obj /* may be NULL */);
+
 /* matrix-free products (NLPModels jprod! / jtprod! / hprod!; ExaModels' `prod = true` path —
  * not used by the reference's solvers): Jv (ncon), J'v (nvar), Hv (nvar) with
  * H the Hessian of obj_weight*f + y'c. */

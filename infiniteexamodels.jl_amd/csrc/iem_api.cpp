@@ -206,7 +206,7 @@ struct iem_model {
   bool halo_deferred = false;
   double *halo_vec = nullptr;
   void *d_comm = nullptr;        // IemHaloArgs in device memory (x unused: the carrier kernel passes its own)
-  bool reads_halo_x[iem::KK_PAIR + 1] = {}, reads_halo_v[iem::KK_PAIR + 1] = {}, carrier[iem::KK_PAIR + 1] = {};
+  bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
   struct KktMod { hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr; };
@@ -361,7 +361,7 @@ int compile_or_load(iem_model *m) {
 // Builds the static part of a kernel's argument block once (iem_create); launching only rewrites
 // the head {x, theta, y, v, out, w, aux, comm}.
 void build_argbuf(iem_model *m, const iem::KernelDesc &kd, const void *d_table, std::vector<uint64_t> &buf) {
-  buf.assign(8, 0);
+  buf.assign(13, 0);   // head: x, theta, y, v, out, w, aux, comm, p2 .. p6
   auto push_ptr = [&](const void *p) { buf.push_back((uint64_t)(uintptr_t)p); };
   if (kd.tables_in_memory) {
     const uint64_t *tb = (const uint64_t *)d_table;
@@ -409,13 +409,16 @@ int prepare_program(iem_model *m, const iem::Program &prog, std::vector<void *> 
 
 // `carry`: the launch also carries the deferred halo exchange of x — one extra leading workgroup column (iem_halo_wg)
 int launch_one(iem_model *m, const iem::KernelDesc &kd, hipFunction_t fn, std::vector<uint64_t> &buf, const double *x, const double *y,
-               double *out, double w, const double *v, double *aux, bool carry = false) {
+               double *out, double w, const double *v, double *aux, bool carry = false, double *p2 = nullptr, double *p3 = nullptr,
+               double *p4 = nullptr, double *p5 = nullptr, double *p6 = nullptr) {
   if (kd.n_blocks <= 0) return IEM_OK;   // a support grid none of whose templates has an item
   buf[0] = (uint64_t)(uintptr_t)x; buf[1] = (uint64_t)(uintptr_t)m->d_theta; buf[2] = (uint64_t)(uintptr_t)y;
   buf[3] = (uint64_t)(uintptr_t)v; buf[4] = (uint64_t)(uintptr_t)out;
   std::memcpy(&buf[5], &w, 8);
   buf[6] = (uint64_t)(uintptr_t)aux;
   buf[7] = carry ? (uint64_t)(uintptr_t)m->d_comm : 0;
+  buf[8] = (uint64_t)(uintptr_t)p2; buf[9] = (uint64_t)(uintptr_t)p3;
+  buf[10] = (uint64_t)(uintptr_t)p4; buf[11] = (uint64_t)(uintptr_t)p5; buf[12] = (uint64_t)(uintptr_t)p6;
   size_t sz = buf.size() * 8;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)kd.grid[0] + (carry ? 1u : 0u), (unsigned)kd.grid[1], (unsigned)kd.grid[2], (unsigned)kd.block, 1, 1, 0,
@@ -474,22 +477,8 @@ int halo_plan(iem_model *m, int kind, const void *x, const void *v, bool *carry)
 
 int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux);
 
-int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
-  return launch_kind_raw(m, kind, x, y, out, w, v, aux);
-}
-
-int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux) {
-  bool carry = false;
-  int rc0 = halo_plan(m, kind, x, v, &carry);
-  if (rc0) return rc0;
-  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
-    if (m->prog.kernels[k].kind == kind) {
-      if (m->prog.kernels[k].n_blocks <= 0) continue;
-      int rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], x, y, out, w, v, aux, carry);
-      if (rc) return rc;
-      carry = false;   // the first kernel of the call carries it
-    }
-  if (carry) { m->halo_deferred = true; }   // (no kernel of the kind was launched: still pending)
+// what runs BEHIND the kernels of a scatter kind (also behind the one-launch accepted-point kernel, for grad!)
+int kind_followups(iem_model *m, int kind, double *out, double *aux) {
   if (!m->prog.axis[kind].empty()) {   // sums over a non-lane axis: the rows the kernels parked -> one write per entry (iem_axis_sum_kernel)
     int64_t n0 = 1;
     for (auto &a : m->prog.axis[kind]) n0 = std::max(n0, a.n0);
@@ -507,6 +496,25 @@ int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, do
     HIP_TRY(hipModuleLaunchKernel(m->fn_gather, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, m->stream, args, nullptr));
   }
   return IEM_OK;
+}
+
+int launch_kind(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v = nullptr, double *aux = nullptr) {
+  return launch_kind_raw(m, kind, x, y, out, w, v, aux);
+}
+
+int launch_kind_raw(iem_model *m, int kind, const double *x, const double *y, double *out, double w, const double *v, double *aux) {
+  bool carry = false;
+  int rc0 = halo_plan(m, kind, x, v, &carry);
+  if (rc0) return rc0;
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    if (m->prog.kernels[k].kind == kind) {
+      if (m->prog.kernels[k].n_blocks <= 0) continue;
+      int rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], x, y, out, w, v, aux, carry);
+      if (rc) return rc;
+      carry = false;   // the first kernel of the call carries it
+    }
+  if (carry) { m->halo_deferred = true; }   // (no kernel of the kind was launched: still pending)
+  return kind_followups(m, kind, out, aux);
 }
 
 int launch_kind_alt(iem_model *m, int kind, const double *x, const double *y, double *out, double w) {
@@ -835,6 +843,7 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "pair_kernel") == 0) { o.pair_kernel = (int)value; return IEM_OK; }
   if (std::strcmp(name, "store_wait") == 0) { o.store_wait = (int)value; return IEM_OK; }
   if (std::strcmp(name, "carrier") == 0) { o.carrier = value != 0; return IEM_OK; }
+  if (std::strcmp(name, "phase_kernels") == 0) { o.phase_kernels = value != 0; return IEM_OK; }
   if (std::strcmp(name, "jac_split") == 0) { if (value < 0 || value > 2) return fail(IEM_E_ARG, "jac_split must be 0, 1 or 2"); o.jac_split = (int)value; return IEM_OK; }
   if (std::strcmp(name, "jac_split_min") == 0) { if (value < 0) return fail(IEM_E_ARG, "jac_split_min must be >= 0"); o.jac_split_min = value; return IEM_OK; }
   if (std::strcmp(name, "pair_inter") == 0) { o.pair_inter = value != 0; return IEM_OK; }
@@ -1054,11 +1063,11 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
       return false;
     };
     for (const iem::KernelDesc &kd : m->prog.kernels) {
-      if (kd.kind < 0 || kd.kind > iem::KK_PAIR) continue;
+      if (kd.kind < 0 || kd.kind > iem::KK_LAST) continue;
       m->reads_halo_x[kd.kind] = m->reads_halo_x[kd.kind] || hits(kd.x_ranges);
       m->reads_halo_v[kd.kind] = m->reads_halo_v[kd.kind] || hits(kd.v_ranges);
     }
-    for (int k : {(int)iem::KK_CONS, (int)iem::KK_JAC, (int)iem::KK_HESS, (int)iem::KK_JPROD, (int)iem::KK_OBJ, (int)iem::KK_PAIR}) m->carrier[k] = true;
+    for (int k : {(int)iem::KK_CONS, (int)iem::KK_JAC, (int)iem::KK_HESS, (int)iem::KK_JPROD, (int)iem::KK_OBJ, (int)iem::KK_PAIR, (int)iem::KK_TRIAL, (int)iem::KK_ACCEPTED, (int)iem::KK_ALL}) m->carrier[k] = true;
   }
   if ((rc = prepare_program(m, m->prog, m->d_tables, m->argbuf)) != IEM_OK) return bail(rc);
   // second code object for the tuner: only for block-store models with a large jac/hess grid (below ~2e5 supports
@@ -1339,6 +1348,81 @@ int iem_jac_hess_coord(iem_model *m, const double *d_x, const double *d_y, doubl
     }
   int rc = iem_jac_coord(m, d_x, d_jac);
   if (rc == IEM_OK) rc = iem_hess_coord(m, d_x, d_y, obj_weight, d_hess);
+  return rc;
+}
+
+/* One launch per solver phase (kernel kinds KK_TRIAL / KK_ACCEPTED): an interior-point solver evaluates obj + cons! at every
+ * TRIAL point of its line search and grad! + jac_coord! + hess_coord! once per ACCEPTED point (the reference's solvers:
+ * ext/InfiniteExaModelsMadNLP.jl:49-50,64, ext/InfiniteExaModelsIpopt.jl:48-49).  The member kinds' bodies — the very
+ * functions the separate calls run — sit behind one workgroup-id dispatcher: identical bytes, one launch instead of two /
+ * three (5-7 us each on the grids the reference benchmarks, ESCAPE34/run_cases_gpu.jl:89-102).  Handles without the kernel
+ * (option "phase_kernels" = 0, a model without objective or without constraints, kinds of different workgroup sizes) make
+ * the separate calls. */
+int iem_eval_trial(iem_model *m, const double *d_x, double *d_c, double *h_obj) {
+  if (!m || !d_x || (!d_c && m->model.ncon)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    if (m->prog.kernels[k].kind == iem::KK_TRIAL && m->prog.n_partials > 0) {
+      if (m->obj_armed) return fail(IEM_E_ARG, "iem_eval_trial: the previous iem_obj_begin / iem_eval_trial has not been collected (iem_obj_end)");
+      *reinterpret_cast<volatile uint64_t *>(m->h_obj) = kObjSentinel;
+      bool carry = false;
+      int rc = halo_plan(m, iem::KK_TRIAL, d_x, nullptr, &carry);
+      // out = c, aux = the objective scalar (mapped host memory), p2 = the objective's partials
+      if (rc == IEM_OK) rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], d_x, nullptr, d_c, 0.0, nullptr, m->d_hobj, carry, m->d_partials);
+      if (rc) return rc;
+      m->obj_armed = true;
+      return h_obj ? iem_obj_end(m, h_obj) : IEM_OK;
+    }
+  int rc = iem_obj_begin(m, d_x);
+  if (rc == IEM_OK) rc = iem_cons(m, d_x, d_c);
+  if (rc == IEM_OK && h_obj) rc = iem_obj_end(m, h_obj);
+  return rc;
+}
+
+int iem_eval_accepted(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_g, double *d_jac, double *d_hess) {
+  if (!m || !d_x || !d_g || (!d_y && m->model.ncon) || (!d_jac && m->model.nnzj) || (!d_hess && m->model.nnzh)) return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    if (m->prog.kernels[k].kind == iem::KK_ACCEPTED) {
+      for (auto &z : m->grad_zero)   // zero only what grad!'s bodies do not overwrite completely
+        HIP_TRY(hipMemsetAsync(d_g + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
+      bool carry = false;
+      int rc = halo_plan(m, iem::KK_ACCEPTED, d_x, nullptr, &carry);
+      // out = jac values, aux = hess values, p2 = g, p3 = grad!'s reduction buffer
+      if (rc == IEM_OK) rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], d_x, d_y, d_jac, obj_weight, nullptr, d_hess, carry, d_g, m->d_red[iem::KK_GRAD]);
+      if (rc == IEM_OK) rc = kind_followups(m, iem::KK_GRAD, d_g, m->d_red[iem::KK_GRAD]);
+      return rc;
+    }
+  int rc = iem_grad(m, d_x, d_g);
+  if (rc == IEM_OK) rc = iem_jac_hess_coord(m, d_x, d_y, obj_weight, d_jac, d_hess);
+  return rc;
+}
+
+/* obj, cons!, grad!, jac_coord!, hess_coord! of ONE point in ONE launch (kernel kind KK_ALL): the five evaluations a solver
+ * makes when its first trial point is accepted.  h_obj as in iem_eval_trial. */
+int iem_eval_all(iem_model *m, const double *d_x, const double *d_y, double obj_weight, double *d_c, double *d_g, double *d_jac, double *d_hess,
+                 double *h_obj) {
+  if (!m || !d_x || !d_g || (!d_c && m->model.ncon) || (!d_y && m->model.ncon) || (!d_jac && m->model.nnzj) || (!d_hess && m->model.nnzh))
+    return fail(IEM_E_ARG, "null argument");
+  DevGuard dg_(m->device);
+  for (size_t k = 0; k < m->prog.kernels.size(); ++k)
+    if (m->prog.kernels[k].kind == iem::KK_ALL && m->prog.n_partials > 0) {
+      if (m->obj_armed) return fail(IEM_E_ARG, "iem_eval_all: the previous iem_obj_begin / iem_eval_trial / iem_eval_all has not been collected (iem_obj_end)");
+      for (auto &z : m->grad_zero)
+        HIP_TRY(hipMemsetAsync(d_g + z.first, 0, (size_t)(z.second - z.first) * 8, m->stream));
+      *reinterpret_cast<volatile uint64_t *>(m->h_obj) = kObjSentinel;
+      bool carry = false;
+      int rc = halo_plan(m, iem::KK_ALL, d_x, nullptr, &carry);
+      if (rc == IEM_OK) rc = launch_one(m, m->prog.kernels[k], m->fns[k], m->argbuf[k], d_x, d_y, d_jac, obj_weight, nullptr, d_hess, carry, d_g, m->d_red[iem::KK_GRAD],
+                                        d_c, m->d_partials, m->d_hobj);
+      if (rc == IEM_OK) rc = kind_followups(m, iem::KK_GRAD, d_g, m->d_red[iem::KK_GRAD]);
+      if (rc) return rc;
+      m->obj_armed = true;
+      return h_obj ? iem_obj_end(m, h_obj) : IEM_OK;
+    }
+  int rc = iem_eval_trial(m, d_x, d_c, nullptr);
+  if (rc == IEM_OK) rc = iem_eval_accepted(m, d_x, d_y, obj_weight, d_g, d_jac, d_hess);
+  if (rc == IEM_OK && h_obj) rc = iem_obj_end(m, h_obj);
   return rc;
 }
 
@@ -1707,7 +1791,7 @@ int iem_halo_wait(iem_model *m) {
 }
 
 int iem_halo_reads(const iem_model *m, int kind, int *out_x, int *out_v, int *out_carrier) {
-  if (!m || kind < 0 || kind > iem::KK_PAIR) return fail(IEM_E_ARG, "bad argument");
+  if (!m || kind < 0 || kind > iem::KK_LAST) return fail(IEM_E_ARG, "bad argument");
   if (out_x) *out_x = m->reads_halo_x[kind] ? 1 : 0;
   if (out_v) *out_v = m->reads_halo_v[kind] ? 1 : 0;
   if (out_carrier) *out_carrier = (m->carrier[kind] && !m->reads_halo_x[kind]) ? 1 : 0;

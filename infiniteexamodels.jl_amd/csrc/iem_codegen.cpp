@@ -1816,7 +1816,8 @@ class KernelBuilder {
       os << "  (void)X; (void)TH; (void)Y; (void)V; (void)FA; (void)IA; (void)A; (void)AUX; (void)lds_blk; (void)lds4; (void)BY_; (void)BZ_; (void)GX_; (void)GY_; (void)GZ_;\n";
       kd.tables_in_memory = false;
     } else {
-    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n";
+    os << "struct Args_" << name_ << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n"
+       << "  double* p2; double* p3; double* p4; double* p5; double* p6;\n";
     if (kd.tables_in_memory)
       os << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
     else
@@ -2332,16 +2333,16 @@ static int64_t union_read_bytes(const Builders &bs) {
 // resident together (Options::jac_split / pair_inter).  mode 1: workgroup r of the run -> body r % run, tile r / run;
 // mode 2: in runs of 8 consecutive workgroups (hardware deals workgroups round-robin over the 8 XCDs: every XCD then
 // works on every body), the last n % 8 tiles of each body behind them.  `dec`: decode table {first, gx, gy, gz} per body.
-static void emit_dispatch_chain(std::ostream &src, size_t nb, size_t dec, size_t run, int mode, const std::vector<bool> &remap,
+static void emit_dispatch_chain(std::ostream &src, size_t nb, size_t dec, size_t run, int mode, const std::vector<bool> &remap, const std::string &b,
                                 const std::function<std::string(size_t, const std::string &)> &call,
                                 const std::function<std::string(size_t)> &extra) {
   size_t j0 = 0;
   if (run >= 2) {
     const size_t e = dec;
     src << "  ";
-    if (run < nb) src << "if (b < A.ip[" << (dec + 4 * run) << "]) ";
+    if (run < nb) src << "if (" << b << " < A.ip[" << (dec + 4 * run) << "]) ";
     src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-        << "    const long long n_ = gx * gy * gz, r_ = b - A.ip[" << e << "];\n    long long j_, lq_;\n";
+        << "    const long long n_ = gx * gy * gz, r_ = " << b << " - A.ip[" << e << "];\n    long long j_, lq_;\n";
     if (mode == 1)
       src << "    j_ = r_ % " << run << "; lq_ = r_ / " << run << ";\n";
     else
@@ -2360,9 +2361,9 @@ static void emit_dispatch_chain(std::ostream &src, size_t nb, size_t dec, size_t
   for (size_t j = j0; j < nb; ++j) {
     const size_t e = dec + 4 * j;
     src << "  " << (j ? "else " : "");
-    if (j + 1 < nb) src << "if (b < A.ip[" << (e + 4) << "]) ";
+    if (j + 1 < nb) src << "if (" << b << " < A.ip[" << (e + 4) << "]) ";
     src << "{\n    const long long gx = A.ip[" << (e + 1) << "], gy = A.ip[" << (e + 2) << "], gz = A.ip[" << (e + 3) << "];\n"
-        << "    const long long lb = " << (remap[j] ? "iem_xcd_remap(b - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : "b - A.ip[" + std::to_string(e) + "]") << ";\n"
+        << "    const long long lb = " << (remap[j] ? "iem_xcd_remap(" + b + " - A.ip[" + std::to_string(e) + "], gx * gy * gz)" : b + " - A.ip[" + std::to_string(e) + "]") << ";\n"
         << extra(j) << call(j, "    ") << "  }\n";
   }
 }
@@ -2806,27 +2807,132 @@ Program generate(const Model &m, const Options &opt_in) {
   auto ns_end = [&](int tile) {
     if (mixed) src << "}  // namespace iem_t" << tile << "\n#undef IEM_TILE\n#define IEM_TILE " << opt.block << "\n\n";
   };
+  // ---- per-kind launches ------------------------------------------------------------------------------------------------
+  // A kind's bodies are emitted ONCE (__device__ functions) together with its tables; the dispatch code that routes a
+  // workgroup id to a body is generated from a KindEmit at a TABLE BASE, so that the kind's own kernel (base 0) and the
+  // one-launch-per-solver-phase kernels below (iem_eval_trial: obj + cons!; iem_eval_accepted: grad! + jac_coord! +
+  // hess_coord! — each member kind at its own base behind one workgroup-id dispatcher) run the very same bodies.
+  struct KindEmit {
+    int kind = -1, tile = 0;
+    std::vector<size_t> ks;                      // descs of the kind, largest grid first
+    std::vector<size_t> oip, odp, ofa, oia;      // table offsets of each body
+    KernelDesc F;                                // the kind's own launch; F.ip / dp / fa / ia = its tables at base 0
+    size_t dec = 0, tbl = 0, sh_tbl = 0, sh_off = 0, nt_slot = 0;
+    bool table = false;                          // workgroup -> body table behind the decode table
+    const KernelBuilder::SharedInfo *si = nullptr;
+    int sh_lds = 0;
+    bool any_remap = false;
+    std::vector<bool> remap;
+    size_t run = 1;                              // leading bodies whose workgroups are interleaved (Options::jac_split)
+  };
+  std::map<int, KindEmit> emitted;
+  const bool phases_on = opt.phase_kernels && !opt.no_fuse && opt.fuse_groups && !opt.hess_merge;
+  auto in_a_phase = [&](int kind) { return phases_on && (kind == KK_CONS || kind == KK_GRAD || kind == KK_JAC || kind == KK_HESS); };
+  // the code that takes local workgroup id `b` (of the kind's launch) to its body, tables at the given bases; OUT / AUX: the
+  // pointer expressions the bodies get as their output and aux buffers.  Objective: `b` = walker index, `nw` = walkers.
+  auto dispatch_code = [&](const KindEmit &E, size_t ipb, size_t dpb, size_t fab, size_t iab, const std::string &tblx, const std::string &b, const std::string &nw,
+                           const std::string &OUT, const std::string &AUX, const std::string &ind0) {
+    std::ostringstream c;
+    const bool is_obj = E.kind == KK_OBJ;
+    const auto &ks = E.ks;
+    auto ipx = [&](size_t i) { return "A.ip[" + std::to_string(ipb + i) + "]"; };
+    auto call = [&](size_t j, const std::string &ind) {
+      std::ostringstream s;
+      s << ind << (is_obj ? "acc += " : "") << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, " << OUT << ", A.w, " << AUX << ", A.ip + " << (ipb + E.oip[j])
+        << ", A.dp + " << (dpb + E.odp[j]) << ", A.fa + " << (fab + E.ofa[j]) << ", A.ia + " << (iab + E.oia[j])
+        << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n";
+      return s.str();
+    };
+    const size_t dec = E.dec;
+    if (is_obj) {
+      // every lane adds the terms of its tiles b, b + nw, ... in that order; the body index only grows
+      c << ind0 << "double acc = 0.0;\n" << ind0 << "int j_ = 0;\n"
+        << ind0 << "for (long long t_ = " << b << "; t_ < " << ipx(E.nt_slot) << "; t_ += " << nw << ") {\n";
+      if (ks.size() > 1)
+        c << ind0 << "  while (j_ + 1 < " << ks.size() << " && t_ >= A.ip[" << (ipb + dec) << " + 4 * (j_ + 1)]) ++j_;\n";
+      c << ind0 << "  const long long gx = A.ip[" << (ipb + dec) << " + 4 * j_ + 1], gy = A.ip[" << (ipb + dec) << " + 4 * j_ + 2], gz = A.ip[" << (ipb + dec) << " + 4 * j_ + 3];\n"
+        << ind0 << "  const long long lb = t_ - A.ip[" << (ipb + dec) << " + 4 * j_];\n";
+      if (ks.size() == 1 && opt.obj_unroll > 1) {
+        // one body: two tiles per trip (t_ and t_ + nw) so that the second tile's loads are in flight while the first is
+        // summed; a tile index past the end decodes to a workgroup column outside the grid, where every lane's guard is
+        // false and the body adds 0
+        c << call(0, ind0 + "  ")
+          << ind0 << "  { const long long b2 = t_ + " << nw << "; const bool in2 = b2 < " << ipx(E.nt_slot) << ";\n"
+          << ind0 << "    const long long lb2 = b2 - A.ip[" << (ipb + dec) << " + 4 * j_];\n"
+          << ind0 << "    acc += " << descs[ks[0]].name << "_body(A.x, A.th, A.y, A.v, " << OUT << ", A.w, " << AUX << ", A.ip + " << (ipb + E.oip[0]) << ", A.dp + " << (dpb + E.odp[0])
+          << ", A.fa + " << (fab + E.ofa[0]) << ", A.ia + " << (iab + E.oia[0]) << ", lds_blk, lds4, in2 ? lb2 % gx : gx, in2 ? (lb2 / gx) % gy : 0, in2 ? lb2 / (gx * gy) : 0, gx, gy, gz);\n"
+          << ind0 << "    t_ += " << nw << "; }\n";
+      } else if (ks.size() == 1) c << call(0, ind0 + "  ");
+      else {
+        c << ind0 << "  switch (j_) {\n";
+        for (size_t j = 0; j < ks.size(); ++j) c << ind0 << "    case " << j << ":\n" << call(j, ind0 + "      ") << ind0 << "      break;\n";
+        c << ind0 << "  }\n";
+      }
+      c << ind0 << "}\n"
+        << ind0 << "iem_block_partial(acc, " << OUT << ", " << b << ", lds4, " << nw << ", " << AUX << ");\n";
+      return c.str();
+    }
+    if (E.si) c << ind0 << "long long wg_ = 0;\n";
+    if (ks.size() > 4) {
+      // many bodies (one per template on a small grid): workgroup -> body table (one scalar load), or a binary search of
+      // the table of first workgroups, then a jump table — a chain of 80 compares costs microseconds
+      if (E.table) c << ind0 << "const int lo_ = (int)A.ip[" << tblx << " + " << b << "];\n";
+      else c << ind0 << "int lo_ = 0, hi_ = " << ks.size() << ";\n"
+             << ind0 << "while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (" << b << " >= A.ip[" << (ipb + dec) << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n";
+      c << ind0 << "const long long gx = A.ip[" << (ipb + dec) << " + 4 * lo_ + 1], gy = A.ip[" << (ipb + dec) << " + 4 * lo_ + 2], gz = A.ip[" << (ipb + dec) << " + 4 * lo_ + 3];\n"
+        << ind0 << "const long long lb = " << (E.any_remap ? "iem_xcd_remap(" + b + " - A.ip[" + std::to_string(ipb + dec) + " + 4 * lo_], gx * gy * gz)"
+                                                            : b + " - A.ip[" + std::to_string(ipb + dec) + " + 4 * lo_]") << ";\n";
+      if (E.si) c << ind0 << "wg_ = A.ip[" << (ipb + E.sh_off) << " + lo_] + lb;\n";
+      c << ind0 << "switch (lo_) {\n";
+      for (size_t j = 0; j < ks.size(); ++j) c << ind0 << "  case " << j << ":\n" << call(j, ind0 + "    ") << ind0 << "    break;\n";
+      c << ind0 << "}\n";
+    } else {
+      std::ostringstream ch;
+      emit_dispatch_chain(ch, ks.size(), ipb + dec, E.si ? 1 : E.run, opt.jac_split == 1 ? 1 : 2, E.remap, b, call,
+                          [&](size_t j) { return E.si ? "    wg_ = A.ip[" + std::to_string(ipb + E.sh_off + j) + "] + lb;\n" : std::string(); });
+      c << ch.str();
+    }
+    if (E.si) c << KernelBuilder::shared_epilogue(*E.si, "A.ip + " + std::to_string(ipb + E.sh_tbl), "wg_", "lds_blk", E.sh_lds);
+    return c.str();
+  };
+  auto args_struct = [&](const KernelDesc &F) {
+    const size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
+    const size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
+    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n"
+        << "  double* p2; double* p3; double* p4; double* p5; double* p6;\n";
+    if (F.tables_in_memory)
+      src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
+    else
+      src << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
+    src << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt.min_waves > 0 ? ", " + std::to_string(opt.min_waves) : std::string())
+        << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
+  };
   for (int kind = 0; kind < KK_COUNT; ++kind) {
     std::vector<size_t> ks;
     for (size_t k = 0; k < descs.size(); ++k) if (descs[k].kind == kind) ks.push_back(k);
     if (ks.empty()) continue;
     const bool is_obj = kind == KK_OBJ;
     const int ktile = descs[ks[0]].block;   // one workgroup size per kind (kind_options)
-    if (!is_obj && (ks.size() == 1 || !opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2))) {   // fuse_groups = 2: experiments (one launch of per-template bodies)
+    if (!is_obj && !in_a_phase(kind) && (ks.size() == 1 || !opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2))) {   // fuse_groups = 2: experiments (one launch of per-template bodies)
+      for (size_t k : ks) { ns_begin(ktile); src << builders[k]->emit(descs[k]); ns_end(ktile); P.kernels.push_back(descs[k]); }
+      continue;
+    }
+    if (!is_obj && (!opt.fuse_groups || (opt.no_fuse && opt.fuse_groups < 2))) {
       for (size_t k : ks) { ns_begin(ktile); src << builders[k]->emit(descs[k]); ns_end(ktile); P.kernels.push_back(descs[k]); }
       continue;
     }
     ns_begin(ktile);
     std::stable_sort(ks.begin(), ks.end(), [&](size_t a, size_t b) { return descs[a].n_blocks > descs[b].n_blocks; });
-    KernelDesc F;
+    KindEmit &E = emitted[kind];
+    E.kind = kind; E.tile = ktile; E.ks = ks;
+    KernelDesc &F = E.F;
     F.name = std::string("iem_") + kname[kind] + "_all" + name_tag;
     F.kind = kind; F.block = ktile;
     F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
-    std::vector<size_t> oip, odp, ofa, oia;   // table offsets of each body
     for (size_t k : ks) {
       src << builders[k]->emit(descs[k], true);
       const KernelDesc &d = descs[k];
-      oip.push_back(F.ip.size()); odp.push_back(F.dp.size()); ofa.push_back(F.fa.size()); oia.push_back(F.ia.size());
+      E.oip.push_back(F.ip.size()); E.odp.push_back(F.dp.size()); E.ofa.push_back(F.fa.size()); E.oia.push_back(F.ia.size());
       F.ip.insert(F.ip.end(), d.ip.begin(), d.ip.end());
       F.dp.insert(F.dp.end(), d.dp.begin(), d.dp.end());
       F.fa.insert(F.fa.end(), d.fa.begin(), d.fa.end());
@@ -2837,6 +2943,8 @@ Program generate(const Model &m, const Options &opt_in) {
       F.x_ranges.insert(F.x_ranges.end(), d.x_ranges.begin(), d.x_ranges.end());
       F.v_ranges.insert(F.v_ranges.end(), d.v_ranges.begin(), d.v_ranges.end());
       F.lds_slots = std::max(F.lds_slots, d.lds_slots);
+      E.remap.push_back(kopts[k].xcd_remap != 0);
+      E.any_remap = E.any_remap || kopts[k].xcd_remap;
     }
     if (F.grid[0] > 2147483647LL) throw std::runtime_error("support grids too large for one launch");
     {
@@ -2846,7 +2954,7 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     const int64_t n_tiles = F.grid[0];
     // workgroup decode table: per body {first workgroup, gx, gy, gz} (launch-size dependent -> arguments)
-    const size_t dec = F.ip.size();
+    E.dec = F.ip.size();
     int64_t first = 0;
     for (size_t k : ks) {
       const KernelDesc &d = descs[k];
@@ -2855,130 +2963,159 @@ Program generate(const Model &m, const Options &opt_in) {
     }
     // scatter kinds with shared entries: the last workgroup's tables, and each body's first workgroup of
     // the call in the numbering the bodies park under (descs order, not the sorted one)
-    const KernelBuilder::SharedInfo *si = nullptr;
-    size_t sh_tbl = 0, sh_off = 0;
-    int sh_lds = 0;
-    for (size_t k : ks) if (builders[k]->shared().on) si = &builders[k]->shared();
-    if (si) {
-      sh_tbl = F.ip.size();
-      const std::vector<int64_t> t = KernelBuilder::shared_final_table(*si);
+    for (size_t k : ks) if (builders[k]->shared().on) E.si = &builders[k]->shared();
+    if (E.si) {
+      E.sh_tbl = F.ip.size();
+      const std::vector<int64_t> t = KernelBuilder::shared_final_table(*E.si);
       F.ip.insert(F.ip.end(), t.begin(), t.end());
-      sh_off = F.ip.size();
-      for (size_t k : ks) { F.ip.push_back(builders[k]->shared().red_off); sh_lds = std::max(sh_lds, builders[k]->shared_lds_doubles()); }
-      F.lds_bytes = std::max(F.lds_bytes, sh_lds * 8);
+      E.sh_off = F.ip.size();
+      for (size_t k : ks) { F.ip.push_back(builders[k]->shared().red_off); E.sh_lds = std::max(E.sh_lds, builders[k]->shared_lds_doubles()); }
+      F.lds_bytes = std::max(F.lds_bytes, E.sh_lds * 8);
     }
-    size_t nt_slot = 0;
     if (is_obj) {
-      nt_slot = F.ip.size();
+      E.nt_slot = F.ip.size();
       F.ip.push_back(n_tiles);
       F.grid[0] = std::min<int64_t>(n_tiles, std::max(1, opt.obj_wgs));
       F.alg_bytes_written = 8 * F.grid[0];
       P.n_partials = F.grid[0];
     }
     F.n_blocks = F.grid[0];
-    const size_t tbl = F.ip.size();
-    if (!is_obj && ks.size() > 4 && F.grid[0] <= (1 << 18))
+    E.tbl = F.ip.size();
+    if (!is_obj && ks.size() > 4 && F.grid[0] <= (1 << 18)) {
+      E.table = true;
       for (size_t j = 0; j < ks.size(); ++j) F.ip.insert(F.ip.end(), (size_t)descs[ks[j]].n_blocks, (int64_t)j);
-    size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
-    size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
-    // the workgroup->body table has one entry per workgroup: in device memory always, so that the
-    // argument struct (hence the source) does not depend on the launch size
-    F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > tbl;
-    src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n";
-    if (F.tables_in_memory)
-      src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
-    else
-      src << "  long long ip[" << nip << "]; double dp[" << ndp << "]; const double* fa[" << nfa << "]; const long long* ia[" << nia << "];\n};\n";
-    src << "extern \"C\" __global__ __launch_bounds__(IEM_TILE" << (opt.min_waves > 0 ? ", " + std::to_string(opt.min_waves) : std::string())
-        << ") void " << F.name << "(const Args_" << F.name << " A) {\n";
+    }
+    // leading bodies that share an interleave class and a grid (the two halves of a split jac_coord!) take turns
+    while (!is_obj && E.run < ks.size() && descs[ks[0]].inter >= 0 && descs[ks[E.run]].inter == descs[ks[0]].inter && descs[ks[E.run]].n_blocks == descs[ks[0]].n_blocks &&
+           descs[ks[E.run]].grid[0] == descs[ks[0]].grid[0] && descs[ks[E.run]].grid[1] == descs[ks[0]].grid[1]) ++E.run;
+    {
+      const size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
+      const size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
+      // the workgroup->body table has one entry per workgroup: in device memory always, so that the
+      // argument struct (hence the source) does not depend on the launch size
+      F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > E.tbl;
+    }
+    args_struct(F);
     if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
     else src << "  double* lds_blk = nullptr;\n";
     if (is_obj) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
     else src << "  double* lds4 = nullptr;\n";
-    auto call = [&](size_t j, const std::string &ind) {
-      std::ostringstream c;
-      c << ind << (is_obj ? "acc += " : "") << descs[ks[j]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[j] << ", A.dp + " << odp[j] << ", A.fa + " << ofa[j]
-        << ", A.ia + " << oia[j] << ", lds_blk, lds4, lb % gx, (lb / gx) % gy, lb / (gx * gy), gx, gy, gz);\n";
-      return c.str();
-    };
     if (is_obj) {
-      // every lane adds the terms of its tiles b, b + gridDim.x, ... in that order; the body index only grows
       // (a pending halo exchange rides on this launch as one extra leading workgroup; the walkers are the others)
       if (opt.carrier)
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
           << "  const long long bx_ = (long long)blockIdx.x - cb_, gx_ = (long long)gridDim.x - cb_;\n";
       else src << "  const long long bx_ = (long long)blockIdx.x, gx_ = (long long)gridDim.x;\n";
-      src << "  double acc = 0.0;\n  int j_ = 0;\n"
-          << "  for (long long b = bx_; b < A.ip[" << nt_slot << "]; b += gx_) {\n";
-      if (ks.size() > 1)
-        src << "    while (j_ + 1 < " << ks.size() << " && b >= A.ip[" << dec << " + 4 * (j_ + 1)]) ++j_;\n";
-      src << "    const long long gx = A.ip[" << dec << " + 4 * j_ + 1], gy = A.ip[" << dec << " + 4 * j_ + 2], gz = A.ip[" << dec << " + 4 * j_ + 3];\n"
-          << "    const long long lb = b - A.ip[" << dec << " + 4 * j_];\n";
-      if (ks.size() == 1 && opt.obj_unroll > 1) {
-        // one body: two tiles per trip (b and b + gridDim.x) so that the second tile's loads are in flight
-        // while the first is summed; a tile index past the end decodes to a workgroup column outside the
-        // grid, where every lane's guard is false and the body adds 0
-        src << call(0, "    ")
-            << "    { const long long b2 = b + gx_; const bool in2 = b2 < A.ip[" << nt_slot << "];\n"
-            << "      const long long lb2 = b2 - A.ip[" << dec << " + 4 * j_];\n"
-            << "      acc += " << descs[ks[0]].name << "_body(A.x, A.th, A.y, A.v, A.out, A.w, A.aux, A.ip + " << oip[0] << ", A.dp + " << odp[0] << ", A.fa + " << ofa[0]
-            << ", A.ia + " << oia[0] << ", lds_blk, lds4, in2 ? lb2 % gx : gx, in2 ? (lb2 / gx) % gy : 0, in2 ? lb2 / (gx * gy) : 0, gx, gy, gz);\n"
-            << "      b += gx_; }\n";
-      } else if (ks.size() == 1) src << call(0, "    ");
-      else {
-        src << "    switch (j_) {\n";
-        for (size_t j = 0; j < ks.size(); ++j) src << "      case " << j << ":\n" << call(j, "        ") << "        break;\n";
-        src << "    }\n";
-      }
-      src << "  }\n"
-          << "  iem_block_partial(acc, A.out, bx_, lds4, gx_, A.aux);\n";
+      src << dispatch_code(E, 0, 0, 0, 0, std::to_string(E.tbl), "bx_", "gx_", "A.out", "A.aux", "  ");
       src << "}\n\n";
       ns_end(ktile);
       P.kernels.push_back(F);
       continue;
     }
-    if (opt.carrier && !si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
+    if (opt.carrier && !E.si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
           << "  const long long b = (long long)blockIdx.x - cb_;\n";
     else
     src << "  const long long b = blockIdx.x;\n";
-    bool any_remap = false;   // (many bodies = templates side by side on small grids: one flag for all of them)
-    for (size_t k : ks) any_remap = any_remap || kopts[k].xcd_remap;
-    if (si) src << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; long long wg_ = 0;\n";
-    if (ks.size() > 4) {
-      // many bodies (one per template on a small grid): binary search of the workgroup id in the
-      // table of first workgroups, then a jump table — a chain of 80 compares costs microseconds
-      if (F.grid[0] <= (1 << 18)) {
-        // one load: workgroup -> body table behind the decode table (a binary search would be a chain
-        // of dependent scalar loads, ~0.4 us each when the tables live in device memory)
-        src << "  const int lo_ = (int)A.ip[" << tbl << " + b];\n";
-      } else
-      src << "  int lo_ = 0, hi_ = " << ks.size() << ";\n"
-          << "  while (hi_ - lo_ > 1) { const int mid_ = (lo_ + hi_) >> 1; if (b >= A.ip[" << dec << " + 4 * mid_]) lo_ = mid_; else hi_ = mid_; }\n";
-      src
-          << "  const long long gx = A.ip[" << dec << " + 4 * lo_ + 1], gy = A.ip[" << dec << " + 4 * lo_ + 2], gz = A.ip[" << dec << " + 4 * lo_ + 3];\n"
-          << "  const long long lb = " << (any_remap ? "iem_xcd_remap(b - A.ip[" + std::to_string(dec) + " + 4 * lo_], gx * gy * gz)"
-                                                          : "b - A.ip[" + std::to_string(dec) + " + 4 * lo_]") << ";\n";
-      if (si) src << "  wg_ = A.ip[" << sh_off << " + lo_] + lb;\n";
-      src << "  switch (lo_) {\n";
-      for (size_t j = 0; j < ks.size(); ++j) src << "    case " << j << ":\n" << call(j, "      ") << "      break;\n";
-      src << "  }\n";
-    } else {
-      // leading bodies that share an interleave class and a grid (the two halves of a split jac_coord!) take turns
-      size_t run = 1;
-      while (run < ks.size() && descs[ks[0]].inter >= 0 && descs[ks[run]].inter == descs[ks[0]].inter && descs[ks[run]].n_blocks == descs[ks[0]].n_blocks &&
-             descs[ks[run]].grid[0] == descs[ks[0]].grid[0] && descs[ks[run]].grid[1] == descs[ks[0]].grid[1]) ++run;
-      std::vector<bool> rm;
-      for (size_t k : ks) rm.push_back(kopts[k].xcd_remap != 0);
-      emit_dispatch_chain(src, ks.size(), dec, si ? 1 : run, opt.jac_split == 1 ? 1 : 2, rm, call,
-                          [&](size_t j) { return si ? "    wg_ = A.ip[" + std::to_string(sh_off + j) + "] + lb;\n" : std::string(); });
-    }
-    if (si) src << KernelBuilder::shared_epilogue(*si, "A.ip + " + std::to_string(sh_tbl), "wg_", "lds_blk", sh_lds);
+    if (E.si) src << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux;\n";
+    src << dispatch_code(E, 0, 0, 0, 0, std::to_string(E.tbl), "b", "", "A.out", "A.aux", "  ");
     src << "}\n\n";
     ns_end(ktile);
     P.kernels.push_back(F);
+  }
+  // ---- one launch per solver phase (KK_TRIAL: obj + cons! at a trial point; KK_ACCEPTED: grad! + jac_coord! + hess_coord!
+  // at an accepted point — the call pattern of ext/InfiniteExaModelsMadNLP.jl:49-50,64 and ext/InfiniteExaModelsIpopt.jl:48-49
+  // of the reference).  Member kinds keep their workgroup ranges (largest member first), each decoded by its own dispatch
+  // code at its own table base; bytes identical to the separate calls (same bodies).  Pointers: trial  out = c, aux = the
+  // objective scalar, p2 = the objective's partials;  accepted  out = jac values, aux = hess values, p2 = g, p3 = grad!'s
+  // reduction buffer.  Follow-ups of grad! (axis sums, plan-driven gather, runtime memsets) stay with the runtime.
+  if (phases_on) {
+    struct Member { int kind; std::string out, aux; };
+    struct Phase { int id; const char *name; std::vector<Member> mem; };
+    const Phase phases[] = {
+      {KK_TRIAL, "iem_trial_all", {{KK_CONS, "A.out", "nullptr"}, {KK_OBJ, "A.p2", "A.aux"}}},
+      {KK_ACCEPTED, "iem_accepted_all", {{KK_JAC, "A.out", "nullptr"}, {KK_HESS, "A.aux", "nullptr"}, {KK_GRAD, "A.p2", "A.p3"}}},
+      // all five evaluations of one point in ONE launch (iem_eval_all: the solver's first trial point is usually accepted —
+      // obj, cons!, grad!, jac_coord!, hess_coord! at the same x): p4 = c, p5 = the objective's partials, p6 = its scalar
+      {KK_ALL, "iem_point_all", {{KK_JAC, "A.out", "nullptr"}, {KK_HESS, "A.aux", "nullptr"}, {KK_CONS, "A.p4", "nullptr"}, {KK_GRAD, "A.p2", "A.p3"}, {KK_OBJ, "A.p5", "A.p6"}}},
+    };
+    for (const Phase &ph : phases) {
+      bool ok = true;
+      int tile = 0;
+      std::vector<Member> present;   // (a linear program has no hess_coord! kernel: the accepted point is grad! + jac_coord!)
+      for (const Member &mb : ph.mem) {
+        auto it = emitted.find(mb.kind);
+        if (it == emitted.end()) { if (ph.id == KK_TRIAL || mb.kind == KK_OBJ || mb.kind == KK_CONS) ok = false; continue; }
+        if (!tile) tile = it->second.tile;
+        ok = ok && it->second.tile == tile;   // (kinds of different workgroup sizes cannot share a launch)
+        present.push_back(mb);
+      }
+      if (!ok || present.size() < 2 || (ph.id == KK_ALL && present.size() < 3)) continue;
+      KernelDesc F;
+      F.name = std::string(ph.name) + name_tag;
+      F.kind = ph.id; F.block = tile;
+      F.grid[0] = 0; F.grid[1] = F.grid[2] = 1;
+      struct Base { size_t ip, dp, fa, ia; int64_t first, n; size_t tbl; };
+      std::vector<Base> base;
+      std::vector<const KernelBuilder *> bs;
+      bool has_obj = false, has_si = false;
+      for (const Member &mb : present) {
+        const KindEmit &E = emitted[mb.kind];
+        // the member's tables WITHOUT its per-workgroup table (the only part whose length depends on the launch size:
+        // those go behind everything else, so that every index the source names is size-independent)
+        base.push_back(Base{F.ip.size(), F.dp.size(), F.fa.size(), F.ia.size(), F.grid[0], E.F.grid[0], 0});
+        F.ip.insert(F.ip.end(), E.F.ip.begin(), E.F.ip.begin() + (long)E.tbl);
+        F.dp.insert(F.dp.end(), E.F.dp.begin(), E.F.dp.end());
+        F.fa.insert(F.fa.end(), E.F.fa.begin(), E.F.fa.end());
+        F.ia.insert(F.ia.end(), E.F.ia.begin(), E.F.ia.end());
+        F.grid[0] += E.F.grid[0];
+        F.lds_bytes = std::max(F.lds_bytes, E.F.lds_bytes);
+        F.alg_bytes_written += E.F.alg_bytes_written;
+        F.x_ranges.insert(F.x_ranges.end(), E.F.x_ranges.begin(), E.F.x_ranges.end());
+        F.lds_slots = std::max(F.lds_slots, E.F.lds_slots);
+        for (size_t k : E.ks) bs.push_back(builders[k].get());
+        has_obj = has_obj || mb.kind == KK_OBJ;
+        has_si = has_si || E.si != nullptr;
+      }
+      if (F.grid[0] > 2147483647LL) continue;
+      F.n_blocks = F.grid[0];
+      F.alg_bytes_read = union_read_bytes(bs);
+      const size_t mdec = F.ip.size();            // per member {first workgroup, workgroups, start of its workgroup -> body table}: launch-size dependent -> arguments
+      F.ip.resize(mdec + 3 * base.size());
+      for (size_t i = 0; i < base.size(); ++i) {
+        const KindEmit &E = emitted[present[i].kind];
+        base[i].tbl = F.ip.size();
+        F.ip.insert(F.ip.end(), E.F.ip.begin() + (long)E.tbl, E.F.ip.end());
+        F.ip[mdec + 3 * i] = base[i].first; F.ip[mdec + 3 * i + 1] = base[i].n; F.ip[mdec + 3 * i + 2] = (int64_t)base[i].tbl;
+      }
+      F.tables_in_memory = true;                  // (member tables may hold per-workgroup entries; one form for every size)
+      ns_begin(tile);
+      args_struct(F);
+      if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
+      else src << "  double* lds_blk = nullptr;\n";
+      if (has_obj) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
+      else src << "  double* lds4 = nullptr;\n";
+      if (opt.carrier && !has_si)
+        src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
+            << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
+            << "  const long long pb_ = (long long)blockIdx.x - cb_;\n";
+      else src << "  const long long pb_ = blockIdx.x;\n";
+      for (size_t i = 0; i < present.size(); ++i) {
+        const KindEmit &E = emitted[present[i].kind];
+        src << "  " << (i ? "else " : "");
+        if (i + 1 < present.size()) src << "if (pb_ < A.ip[" << (mdec + 3 * (i + 1)) << "]) ";
+        src << "{\n    const long long b = pb_ - A.ip[" << (mdec + 3 * i) << "];\n";
+        if (E.si) src << "    double* __restrict__ OUT = " << present[i].out << "; double* __restrict__ AUX = " << present[i].aux << ";\n";
+        src << dispatch_code(E, base[i].ip, base[i].dp, base[i].fa, base[i].ia, "A.ip[" + std::to_string(mdec + 3 * i + 2) + "]", "b", "A.ip[" + std::to_string(mdec + 3 * i + 1) + "]",
+                             present[i].out, present[i].aux, "    ");
+        src << "  }\n";
+      }
+      src << "}\n\n";
+      ns_end(tile);
+      P.kernels.push_back(F);
+    }
   }
   // jac_coord! + hess_coord! in ONE launch (KK_PAIR; iem_jac_hess_coord).  The two calls are independent given x (and y):
   // behind one workgroup-id dispatcher their bodies share a launch — one ramp and one drain instead of two, and on a grid
@@ -3059,7 +3196,8 @@ Program generate(const Model &m, const Options &opt_in) {
         const size_t nip = std::max<size_t>(1, F.ip.size()), ndp = std::max<size_t>(1, F.dp.size());
         const size_t nfa = std::max<size_t>(1, F.fa.size()), nia = std::max<size_t>(1, F.ia.size());
         F.tables_in_memory = (nip + ndp + nfa + nia) > 320 || F.ip.size() > tbl;
-        src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n";
+        src << "struct Args_" << F.name << " {\n  const double* x; const double* th; const double* y; const double* v; double* out; double w; double* aux; const IemHaloArgs* comm;\n"
+            << "  double* p2; double* p3; double* p4; double* p5; double* p6;\n";
         if (F.tables_in_memory)
           src << "  const long long* ip; const double* dp; const double* const* fa; const long long* const* ia;\n};\n";
         else
@@ -3102,7 +3240,7 @@ Program generate(const Model &m, const Options &opt_in) {
           while (run < ord.size() && same(0, run)) ++run;
           std::vector<bool> rm;
           for (size_t jj = 0; jj < ord.size(); ++jj) rm.push_back(pxcd[ord[jj]]);
-          emit_dispatch_chain(src, ord.size(), dec, run, opt.jac_split == 1 ? 1 : 2, rm, call, [](size_t) { return std::string(); });
+          emit_dispatch_chain(src, ord.size(), dec, run, opt.jac_split == 1 ? 1 : 2, rm, "b", call, [](size_t) { return std::string(); });
         }
         src << "}\n\n";
         P.kernels.push_back(F);

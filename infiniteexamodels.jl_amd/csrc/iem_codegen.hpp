@@ -12,7 +12,13 @@ namespace iem {
 enum KernelKind { KK_CONS = 0, KK_JAC = 1, KK_HESS = 2, KK_OBJ = 3, KK_GRAD = 4, KK_JPROD = 5, KK_JTPROD = 6, KK_HPROD = 7, KK_COUNT = 8,
                   // jac_coord! + hess_coord! in ONE launch (iem_jac_hess_coord): the bodies of both kinds behind one workgroup-id
                   // dispatcher; `out` = the Jacobian values, `aux` = the Hessian values.  Not a per-kind table index (KK_COUNT stays 8).
-                  KK_PAIR = 8 };
+                  KK_PAIR = 8,
+                  // one launch per solver phase (iem_eval_trial: obj + cons!; iem_eval_accepted: grad! + jac_coord! + hess_coord!): the
+                  // member kinds' bodies behind one workgroup-id dispatcher.  Pointers: trial out = c, aux = objective scalar, p2 =
+                  // partials; accepted out = jac values, aux = hess values, p2 = g, p3 = grad!'s reduction buffer
+                  KK_TRIAL = 9, KK_ACCEPTED = 10,
+                  // ... and all five evaluations of one point in one launch (iem_eval_all): p4 = c, p5 = the objective's partials, p6 = its scalar
+                  KK_ALL = 11, KK_LAST = 11 };
 
 struct KernelDesc {
   std::string name;
@@ -107,6 +113,8 @@ struct Options {
   // exchange as one extra leading workgroup (iem_halo_wg).  Set by iem_create_sharded; an unsharded handle's kernels have no
   // such prologue (and no LDS word for it) at all.
   int carrier = 0;
+  int phase_kernels = 1;   // 1: also emit the one-launch-per-solver-phase kernels (KK_TRIAL, KK_ACCEPTED); their member kinds then
+                           // always take the bodies-behind-a-dispatcher form, which the phase kernels share
   // jac_coord! of a lane-fused support grid runs as TWO bodies behind the dispatcher, their
   // workgroups interleaved so that both are resident: body a = the templates whose partials are item data or constants
   // (linear rows: difference rows h, -1, +1 of src/transform.jl:511-562, affine dynamics) — no x load, no arithmetic, a

@@ -84,7 +84,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_shard_template_items", "iem_shard_blob", "iem_comm_export", "iem_comm_connect", "iem_halo_exchange", "iem_halo_exchange_async", "iem_halo_wait", "iem_halo_reads", "iem_halo_fold", "iem_allreduce_obj_grad", "iem_comm_status",
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_obj_begin", "iem_obj_end", "iem_grad", "iem_cons",
-           "iem_jac_coord", "iem_hess_coord", "iem_jac_hess_coord", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
+           "iem_jac_coord", "iem_hess_coord", "iem_jac_hess_coord", "iem_eval_trial", "iem_eval_accepted", "iem_eval_all", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
            "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_csr_spmv", "iem_kkt_chain_factor", "iem_kkt_chain_solve", "iem_kkt_source", "iem_kkt_create", "iem_kkt_destroy", "iem_kkt_info", "iem_kkt_layout", "iem_kkt_analyse_blob", "iem_kkt_assemble", "iem_kkt_factor", "iem_kkt_solve", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
@@ -150,6 +150,9 @@ def lib():
     L.iem_obj_begin.argtypes = [vp, vp]
     L.iem_obj_end.argtypes = [vp, C.POINTER(dbl)]
     L.iem_jac_hess_coord.argtypes = [vp, vp, vp, dbl, vp, vp]
+    L.iem_eval_trial.argtypes = [vp, vp, vp, C.POINTER(dbl)]
+    L.iem_eval_accepted.argtypes = [vp, vp, vp, dbl, vp, vp, vp]
+    L.iem_eval_all.argtypes = [vp, vp, vp, dbl, vp, vp, vp, vp, C.POINTER(dbl)]
     L.iem_grad.argtypes = [vp, vp, vp]
     L.iem_cons.argtypes = [vp, vp, vp]
     L.iem_jac_coord.argtypes = [vp, vp, vp]
@@ -197,7 +200,7 @@ def set_option(name: str, value: int):
 OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=0, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
                        min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=0, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2, autotune=0, autotune_min_blocks=400, pull_scatter=1, fold_colloc=2, fold_max_n=6, det_axis=1, det_scatter=1, det_scatter_max=1 << 28, lazy_loads=2, lazy_min_loads=48, lazy_all_kinds=0, name_tag=0,
                        big_batch_slots=48, big_batch_jac=4000, big_batch_hess=4000, big_xcd=1, big_tile=1024, pair_kernel=1, store_wait=0, comm_timeout_ms=5000,
-                       carrier=0, jac_split=1, jac_split_min=0, pair_inter=0)
+                       carrier=0, phase_kernels=1, jac_split=1, jac_split_min=0, pair_inter=0)
 
 
 def option_array(opts: dict):

@@ -35,7 +35,7 @@ class MI355XBackend:
         return f"MI355XBackend(device={self.device}" + (f", shard={self.shard})" if self.shard else ")")
 
 
-KERNEL_KINDS = ("cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod", "pair")   # iem_kernel_info_t.kind
+KERNEL_KINDS = ("cons", "jac", "hess", "obj", "grad", "jprod", "jtprod", "hprod", "pair", "trial", "accepted", "point")   # iem_kernel_info_t.kind
 
 
 def _ptr(t) -> int:
@@ -248,6 +248,51 @@ class ExaModel:
         self.counters.neval_hess += 1
         return jac, hess
 
+    def eval_trial(self, x, c=None, defer_obj: bool = False):
+        """``obj(m, x)`` and ``cons!(m, x, c)`` in ONE launch (``iem_eval_trial``: what a line search evaluates at a trial
+        point, ``ext/InfiniteExaModelsMadNLP.jl:49-50`` of the reference).  Returns ``(f, c)``; ``defer_obj``: returns
+        ``(None, c)`` at once and :meth:`obj_end` collects the value later."""
+        self._chk(x, self.meta.nvar, "x")
+        c = c if c is not None else self._new(self.meta.ncon)
+        self._chk(c, self.meta.ncon, "c")
+        self._sync_stream()
+        out = C.c_double()
+        _lib.check(self._L.iem_eval_trial(self._h, _ptr(x), _ptr(c), None if defer_obj else C.byref(out)))
+        self.counters.neval_obj += 1
+        self.counters.neval_cons += 1
+        return (None if defer_obj else float(out.value)), c
+
+    def eval_accepted(self, x, y, g=None, jac=None, hess=None, obj_weight: float = 1.0):
+        """``grad!``, ``jac_coord!`` and ``hess_coord!`` in ONE launch (``iem_eval_accepted``: what a solver evaluates once
+        per accepted point, ``ext/InfiniteExaModelsMadNLP.jl:64``).  Identical bytes to the three calls."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(y, self.meta.ncon, "y")
+        g = g if g is not None else self._new(self.meta.nvar)
+        jac = jac if jac is not None else self._new(self.meta.nnzj)
+        hess = hess if hess is not None else self._new(self.meta.nnzh)
+        self._chk(g, self.meta.nvar, "g"); self._chk(jac, self.meta.nnzj, "jac"); self._chk(hess, self.meta.nnzh, "hess")
+        self._sync_stream()
+        _lib.check(self._L.iem_eval_accepted(self._h, _ptr(x), _ptr(y), float(obj_weight), _ptr(g), _ptr(jac), _ptr(hess)))
+        self.counters.neval_grad += 1
+        self.counters.neval_jac += 1
+        self.counters.neval_hess += 1
+        return g, jac, hess
+
+    def eval_all(self, x, y, c=None, g=None, jac=None, hess=None, obj_weight: float = 1.0, defer_obj: bool = False):
+        """All five evaluations of one point in ONE launch (``iem_eval_all``).  Returns ``(f, c, g, jac, hess)``."""
+        self._chk(x, self.meta.nvar, "x"); self._chk(y, self.meta.ncon, "y")
+        c = c if c is not None else self._new(self.meta.ncon)
+        g = g if g is not None else self._new(self.meta.nvar)
+        jac = jac if jac is not None else self._new(self.meta.nnzj)
+        hess = hess if hess is not None else self._new(self.meta.nnzh)
+        self._chk(c, self.meta.ncon, "c"); self._chk(g, self.meta.nvar, "g"); self._chk(jac, self.meta.nnzj, "jac"); self._chk(hess, self.meta.nnzh, "hess")
+        self._sync_stream()
+        out = C.c_double()
+        _lib.check(self._L.iem_eval_all(self._h, _ptr(x), _ptr(y), float(obj_weight), _ptr(c), _ptr(g), _ptr(jac), _ptr(hess),
+                                        None if defer_obj else C.byref(out)))
+        for k in ("obj", "cons", "grad", "jac", "hess"):
+            setattr(self.counters, "neval_" + k, getattr(self.counters, "neval_" + k) + 1)
+        return (None if defer_obj else float(out.value)), c, g, jac, hess
+
     def jprod(self, x, v, Jv=None):
         """``jprod!(m, x, v, Jv)``: Jacobian–vector product (ncon)."""
         self._chk(x, self.meta.nvar, "x"); self._chk(v, self.meta.nvar, "v")
@@ -344,7 +389,7 @@ class ExaModel:
                     check(rc)
         return step
 
-    def raw_loop(self, x, y, g, c, jac, hess, obj_weight: float = 1.0, fused: bool = True, defer_obj: bool = True):
+    def raw_loop(self, x, y, g, c, jac, hess, obj_weight: float = 1.0, fused: bool = True, defer_obj: bool = True, phases: bool = False, one_launch: bool = False):
         """``step() -> f`` closure: the five evaluations a solver makes at one point — obj, grad!, cons!, jac_coord!,
         hess_coord! (``ext/InfiniteExaModelsIpopt.jl:48-49``) — on fixed buffers, argument checks and stream lookup done
         once.  ``defer_obj``: the objective is launched FIRST (``iem_obj_begin``) and its value collected LAST
@@ -359,6 +404,22 @@ class ExaModel:
         ref = C.byref(out)
         obj, begin, end, grad, cons = L.iem_obj, L.iem_obj_begin, L.iem_obj_end, L.iem_grad, L.iem_cons
         jacf, hessf, pair = L.iem_jac_coord, L.iem_hess_coord, L.iem_jac_hess_coord
+
+        trial, accepted, allf = L.iem_eval_trial, L.iem_eval_accepted, L.iem_eval_all
+        if one_launch:  # all five evaluations of the point in ONE launch
+            def step():
+                rc = allf(h, px, py, w, pc, pg, pj, ph, ref)
+                if rc:
+                    check(rc)
+                return out.value
+            return step
+        if phases:      # one launch per solver phase: obj + cons! (value collected last), then grad! + jac_coord! + hess_coord!
+            def step():
+                rc = trial(h, px, pc, None) or accepted(h, px, py, w, pg, pj, ph) or end(h, ref)
+                if rc:
+                    check(rc)
+                return out.value
+            return step
 
         def step():
             rc = (begin(h, px) if defer_obj else obj(h, px, ref)) or grad(h, px, pg) or cons(h, px, pc) or \

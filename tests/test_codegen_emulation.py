@@ -36,6 +36,22 @@ def test_emulated_kernels_match_oracle(name, grid_mode):
         assert np.array_equal(jp, j) and np.array_equal(hp, h)
     else:                                           # only models without Jacobian or without Hessian entries have none
         assert om.nnzj == 0 or om.nnzh == 0
+    # one launch per solver phase (iem_eval_trial: obj + cons!; iem_eval_accepted: grad! + jac_coord! + hess_coord!): the
+    # member kinds' own bodies behind one dispatcher — the same BYTES as the separate calls
+    if om.ncon > 0 and em.n_partials > 0:
+        assert em.has("trial")
+        f, c = em.eval_trial(x)
+        assert f == em.obj(x) and np.array_equal(c, em.cons(x))
+    if em.has("accepted"):
+        g, ja, ha = em.eval_accepted(x, y, 0.7, om.nnzj, om.nnzh)
+        assert np.array_equal(g, em.grad(x)) and np.array_equal(ja, j) and np.array_equal(ha, h)
+    else:
+        assert (om.nnzj == 0) + (om.nnzh == 0) + (not em.has("grad")) >= 2
+    if em.has("point"):          # ... and all five of one point in one launch (iem_eval_all)
+        f, c, g, ja, ha = em.eval_all(x, y, 0.7, om.nnzj, om.nnzh)
+        assert f == em.obj(x) and np.array_equal(c, em.cons(x)) and np.array_equal(g, em.grad(x)) and np.array_equal(ja, j) and np.array_equal(ha, h)
+    else:
+        assert om.ncon == 0 or em.n_partials == 0
     # matrix-free products (jprod! / jtprod! / hprod!)
     rng = np.random.default_rng(5)
     v, vc = rng.standard_normal(om.nvar), rng.standard_normal(om.ncon)
@@ -459,4 +475,14 @@ def test_a_carried_halo_exchange_leaves_every_tile_in_place(name, grid_mode):
         jp, hp = em.jac_hess_coord(x, y, 0.7, om.nnzj, om.nnzh)
         assert np.array_equal(jp, ref.jac_coord(x, om.nnzj)) and np.array_equal(hp, ref.hess_coord(x, y, 0.7, om.nnzh))
         n += 1
+    # the solver-phase launches carry too (the accepted-point one unless its grad! member reduces shared entries)
+    f, c = em.eval_trial(x)
+    assert f == ref.obj(x) and np.array_equal(c, ref.cons(x))
+    n += 1
+    g, ja, ha = em.eval_accepted(x, y, 0.7, om.nnzj, om.nnzh)
+    assert np.array_equal(g, ref.grad(x)) and np.array_equal(ja, ref.jac_coord(x, om.nnzj)) and np.array_equal(ha, ref.hess_coord(x, y, 0.7, om.nnzh))
+    n += sum(1 for k in em.kernels if k["kind"] == 10 and em._can_carry(k))
+    f, c, g, ja, ha = em.eval_all(x, y, 0.7, om.nnzj, om.nnzh)
+    assert f == ref.obj(x) and np.array_equal(c, ref.cons(x)) and np.array_equal(g, ref.grad(x)) and np.array_equal(ja, ref.jac_coord(x, om.nnzj)) and np.array_equal(ha, ref.hess_coord(x, y, 0.7, om.nnzh))
+    n += sum(1 for k in em.kernels if k["kind"] == 11 and em._can_carry(k))
     assert em.carried == n * block, "exactly one workgroup per carrying launch ran the exchange"

@@ -90,6 +90,19 @@ def test_all_entry_points_match_oracle(name, torch_cuda, grid_mode):
         hv2 = torch.full((om.nnzh,), float("nan"), device="cuda", dtype=torch.float64)
         gm.jac_hess_coord(xd, yd, jv2, hv2, obj_weight=0.3)
         assert torch.equal(jv2, jv) and torch.equal(hv2, hv), "fused jac + hess launch differs from the two calls"
+        # one launch per solver phase into poisoned buffers: the BYTES of the separate calls (iem_eval_trial: obj + cons!;
+        # iem_eval_accepted: grad! + jac_coord! + hess_coord!, w = 0.3 as the last hess_coord! above)
+        cv2 = torch.full((om.ncon,), float("nan"), device="cuda", dtype=torch.float64)
+        f2, _ = gm.eval_trial(xd, cv2)
+        assert f2 == f and torch.equal(cv2, cv), "iem_eval_trial differs from obj + cons!"
+        _, cv3 = gm.eval_trial(xd, torch.full((om.ncon,), float("nan"), device="cuda", dtype=torch.float64), defer_obj=True)
+        assert gm.obj_end() == f and torch.equal(cv3, cv)
+        gv2, jv3, hv3 = (torch.full((n_,), float("nan"), device="cuda", dtype=torch.float64) for n_ in (om.nvar, om.nnzj, om.nnzh))
+        gm.eval_accepted(xd, yd, gv2, jv3, hv3, obj_weight=0.3)
+        assert torch.equal(gv2, gv) and torch.equal(jv3, jv) and torch.equal(hv3, hv), "iem_eval_accepted differs from the three calls"
+        cv4, gv4, jv4, hv4 = (torch.full((n_,), float("nan"), device="cuda", dtype=torch.float64) for n_ in (om.ncon, om.nvar, om.nnzj, om.nnzh))
+        f4 = gm.eval_all(xd, yd, cv4, gv4, jv4, hv4, obj_weight=0.3)[0]
+        assert f4 == f and torch.equal(cv4, cv) and torch.equal(gv4, gv) and torch.equal(jv4, jv) and torch.equal(hv4, hv), "iem_eval_all differs from the five calls"
         # obj in two halves (iem_obj_begin / iem_obj_end) around other launches: the same bits as obj
         gm.obj_begin(xd)
         gm.cons(xd, cv)

@@ -114,8 +114,10 @@ def measure(args):
     # pays): (a) the five calls in order, obj returning its scalar before anything else is launched; (b) obj DEFERRED:
     # iem_obj_begin first, iem_obj_end after the last launch; (c) deferred + the one-launch jac/hess pair
     forms = {}
+    # (d) ONE LAUNCH PER SOLVER PHASE: iem_eval_trial (obj + cons!, value collected last) + iem_eval_accepted (grad! + jac_coord!
+    # + hess_coord!) — the same five results from two launches
     for name, kw in (("five_calls", dict(fused=False, defer_obj=False)), ("obj_deferred", dict(fused=False, defer_obj=True)),
-                     ("obj_deferred_fused_pair", dict(fused=True, defer_obj=True))):
+                     ("obj_deferred_fused_pair", dict(fused=True, defer_obj=True)), ("two_phase_launches", dict(phases=True)), ("one_launch", dict(one_launch=True))):
         step = gm.raw_loop(x, y, g, c, jv, hv, obj_weight=1.0, **kw)
         for _ in range(10):
             fval = step()
@@ -126,6 +128,18 @@ def measure(args):
         torch.cuda.synchronize()
         forms[name] = (time.perf_counter() - t0) / args.iters * 1e3
     assert fval == gm.obj(x)
+    # the two phases on their own (event-timed blocks, like the per-call figures)
+    for name, f in (("eval_trial", lambda: gm.eval_trial(x, c)), ("eval_accepted", lambda: gm.eval_accepted(x, y, g, jv, hv, obj_weight=1.0)),
+                    ("eval_all", lambda: gm.eval_all(x, y, c, g, jv, hv, obj_weight=1.0))):
+        for _ in range(5):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms[name] = e0.elapsed_time(e1) / args.iters
     # what obj costs IN the loop: the deferred loop against the same loop without any objective call
     L_, h_ = gm._L, gm._h
     px, py, pg, pc, pj, ph = (t.data_ptr() for t in (x, y, g, c, jv, hv))
@@ -173,7 +187,11 @@ def measure(args):
         "n_kernels": gm.meta.n_kernels, "build_s": t_build, "loop_ms": loop_ms, "loops_per_s": 1e3 / loop_ms,
         "graph_loop_ms": graph_ms, "graph_loops_per_s": 1e3 / graph_ms, "loop_forms_ms": forms,
         "ms": ms, "alg_bytes": bytes_,
-        "GBps": {k: (bytes_[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else None) for k in ms},
+        "GBps": {k: (bytes_[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else None) for k in ms if k in bytes_},
+        "loop_alg_bytes": sum(bytes_[k] for k in ("obj", "grad", "cons", "jac_coord", "hess_coord")),
+        "loop_frac_of_8TBps": {k: sum(bytes_[q] for q in ("obj", "grad", "cons", "jac_coord", "hess_coord")) / (v * 1e-3) / 8e12
+                               for k, v in forms.items() if isinstance(v, float) and k != "four_calls_without_obj"},
+        "phase_kernels": sorted(kk["name"] for kk in gm.kernels() if kk["kind"] in ("trial", "accepted", "point")),
     }
     gm.close()
     return out
