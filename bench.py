@@ -31,9 +31,10 @@ kernel in front of it); the communication-free pair is reported beside it ("pair
 Before the ranks wire their mailboxes in-process, the same wiring + one checked exchange + one checked all-reduce
 run in CHILD processes (key "comm": peer-mapped memory is the one part that the one-GPU box can only rehearse with all
 ranks on one device — whatever it does on a real xGMI node must end in an entry of the line, never in a lost line).  If
-the children fail, or a rank cannot wire its mailbox, the timed step falls back to the communication-free pair and the
-line says so ("halo_in_timed_loop": false, "comm_fallback": reason); the torch.distributed (RCCL) fallback of the two
-exchanges is shard.ShardComm.  `--weak` adds the weak form of the same run under "weak".
+the children fail, a rank cannot wire its mailbox, or a mailbox wait times out during the warm-up, the timed step takes
+the torch.distributed fallback of the exchange instead (shard.ShardComm: a send / recv of the halo doubles, RCCL on GPUs) —
+still INSIDE the timed step; "comm_path" says which ("own" / "rccl"; "none" only if the fallback failed too, and then the
+value is not a multi-GPU step).  `--force-rccl` takes the fallback deliberately.  `--weak` adds the weak form of the same run under "weak".
 
 Inputs: x and y are resident in HBM and re-used every step (a solver's iterate); `roofline.frac_cold_inputs` is the same
 pair with K = 4 distinct (x, y) sets cycled per call (> 256 MiB in total: nothing of a call's inputs can sit in the
@@ -115,6 +116,23 @@ def cpu_baseline(sample_supports: int, seconds: float = 12.0):
         "interpreter_value": interp, "interpreter": "oracle/iem_oracle.c (generic tree interpreter), 1 thread",
         "max_abs_diff_vs_oracle": agree,
     }
+
+
+def choose_comm_path(children_ok: bool, wired: bool, warmup_status: int = 0, rccl_ok: bool = True):
+    """Which exchange the N > 1 TIMED step contains — never silently none:
+      'own'   the library's mailbox kernels (iem_halo_exchange_async riding on the step's first launch)
+      'rccl'  torch.distributed send / recv of the halo doubles (shard.ShardComm's fallback; backend nccl = RCCL over xGMI):
+              when the child-process check failed, a rank could not export / map a mailbox, or a mailbox wait timed out
+              during the warm-up
+      'none'  only when the fallback itself failed: the line then carries comm.path = 'none' and the reason
+    Returns (path, reason)."""
+    if children_ok and wired and warmup_status == 0:
+        return "own", ""
+    why = ("the child-process check of the mailbox path failed" if not children_ok else
+           "a rank could not export / map a mailbox" if not wired else f"a mailbox wait timed out during the warm-up (status {warmup_status})")
+    if rccl_ok:
+        return "rccl", why
+    return "none", why + "; the torch.distributed fallback failed too"
 
 
 def spawn_ranks(n: int, script: str = None) -> int:
@@ -290,6 +308,7 @@ def main():
     ap.add_argument("--emulate-shard", default="", help="R/N: time shard R of an N-way sharded run on this GPU")
     ap.add_argument("--graph", action="store_true", help="replay the jac+hess pair from a captured HIP graph instead of eager launches")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the (untimed) check of the halo exchange / objective all-reduce")
+    ap.add_argument("--no-comm-check", action="store_true", help="N > 1: skip only the child-process check; the exchange stays in the timed step")
     ap.add_argument("--comm-child", action="store_true", help=argparse.SUPPRESS)   # internal: run ONLY the comm section (see comm_isolated)
     ap.add_argument("--fused", action="store_true", help="the timed step is iem_jac_hess_coord (one launch) instead of the metric's own call pair "
                     "iem_jac_coord + iem_hess_coord (two launches, the default); the other form is always reported beside it")
@@ -301,6 +320,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurement of the ESCAPE34 (collocation) variant of the model")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--rehearse-comm", default="", help=argparse.SUPPRESS)   # with --rehearse-launch: simulate one branch of choose_comm_path
+    ap.add_argument("--force-rccl", action="store_true", help="N > 1: take the torch.distributed fallback of the halo exchange even when the mailboxes work")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU, no evaluation, NOT a measurement: spawn / rendezvous / reduce only (CPU test of the N>1 launch path)")
     args = ap.parse_args()
@@ -327,8 +348,17 @@ def main():
         t = torch.tensor([float(rank)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
+        out = {"rehearsal": True, "n_gpus": world, "max_rank_seen": int(t.item())}
+        if args.rehearse_comm:
+            # every branch of the comm-path selection with SIMULATED outcomes, agreed on by all ranks like the real run does
+            sim = {"own": (True, True, 0, True), "children_failed": (False, True, 0, True), "connect_failed": (True, False, 0, True),
+                   "warmup_timeout": (True, True, 4 if rank == world - 1 else 0, True), "rccl_failed": (True, False, 0, False)}[args.rehearse_comm]
+            st = torch.tensor([float(sim[2])], dtype=torch.float64)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)          # one rank's time-out is everybody's
+            path, why = choose_comm_path(sim[0], sim[1], int(st.item()), sim[3])
+            out["comm"] = {"path": path, "why": why, "world_size": dist.get_world_size()}
         if rank == 0:
-            print(json.dumps({"rehearsal": True, "n_gpus": world, "max_rank_seen": int(t.item())}), flush=True)
+            print(json.dumps(out), flush=True)
         dist.destroy_process_group()
         return
     torch.cuda.set_device(local_rank)
@@ -365,12 +395,16 @@ def main():
     # back clean do the ranks of THIS process wire their mailboxes and put the exchange into the timed step
     comm = None
     want_halo = world > 1 and use_dist and not args.no_comm and not args.emulate_shard and not args.comm_child
-    if want_halo and not (args.same_device and 2 * world > 6):
+    if want_halo and not args.no_comm_check and not (args.same_device and 2 * world > 6):
         comm = comm_isolated(args, dist, rank, world, local_rank, barrier)
         ok = [comm is None or "error" not in comm]
         if use_dist:
             dist.broadcast_object_list(ok, src=0)
-        want_halo = bool(ok[0])
+        children_ok = bool(ok[0])      # a failed check does NOT drop the exchange from the timed step: the torch.distributed fallback takes it
+    else:
+        children_ok = True
+    if args.force_rccl:
+        children_ok = False
 
     def measure(scaling: str, steps: int, warmup: int, with_halo: bool):
         """Build this rank's shard for `scaling`, run `warmup` untimed + exactly `steps` timed steps between barriers,
@@ -400,22 +434,36 @@ def main():
         xd, yd = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
         jac = torch.empty(gm.meta.nnzj, dtype=torch.float64, device=dev)
         hess = torch.empty(gm.meta.nnzh, dtype=torch.float64, device=dev)
-        halo_state = {"in_loop": False}
+        halo_state = {"in_loop": False, "path": "none"}
+        sc = None
         if with_halo:
-            # the library's own mailboxes or nothing: a rank that cannot wire them makes every rank time the
-            # communication-free pair, and the line says why (the RCCL fallback of the exchanges exists — shard.ShardComm —
-            # but a host-driven send/recv inside a 25-us step is not what this line measures)
-            sc = shard.ShardComm(gm, dist)
-            halo_state.update(kind=sc.kind, why=sc.why, in_loop=sc.kind == "own", mailbox_kind=gm.shard_info()["mailbox_kind"] if sc.kind == "own" else 0)
+            # the library's own mailboxes when every rank can wire them; otherwise (child check failed, export / connect
+            # refused, --force-rccl) the torch.distributed fallback of shard.ShardComm — the exchange is INSIDE the timed step
+            # either way (choose_comm_path)
+            sc = shard.ShardComm(gm, dist, force_fallback=not children_ok)
+            path, why = choose_comm_path(children_ok, sc.kind == "own")
+            if not children_ok and args.force_rccl:
+                why = "--force-rccl"
+            halo_state.update(kind=sc.kind, why=why or sc.why, path=path, in_loop=True,
+                              mailbox_kind=gm.shard_info()["mailbox_kind"] if sc.kind == "own" else 0)
 
-        # one step through the C-ABI; argument checks and the stream lookup of the Python wrapper are done once
-        # (ExaModel.raw_pair) — at 8 GPUs a step is 25 us of device time
-        step = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=halo_state["in_loop"])
+        def make_step(path):
+            """one step through the C-ABI; argument checks and the stream lookup of the Python wrapper are done once
+            (ExaModel.raw_pair) — at 8 GPUs a step is 25 us of device time"""
+            if path == "rccl":
+                pair = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=False)
+
+                def step():
+                    sc.halo_exchange(xd)      # dist.batch_isend_irecv of the halo doubles (RCCL on GPUs)
+                    pair()
+                return step
+            return gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=path == "own")
+        step = make_step(halo_state["path"])
         gm._tuned = gm.tune(xd, yd, jac, hess, obj_weight=1.0)   # no-op unless --opt autotune=1
 
         if args.graph:
             def eager():      # the wrappers follow torch's CURRENT stream, which the capture needs
-                if halo_state["in_loop"]:
+                if halo_state["path"] == "own":
                     gm.halo_exchange_async(xd)
                 if args.fused:
                     gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0)
@@ -434,20 +482,38 @@ def main():
         barrier()      # ranks build their shards at different speeds: start the first exchanges together
         for _ in range(warmup):
             step()
-        if halo_state["in_loop"]:
+        if halo_state["path"] == "own":
             # the warm-up steps carried real exchanges over this machine's links: if ANY rank saw a mailbox wait time out
-            # (bounded: comm_timeout_ms = 1 s on these handles), every rank times the communication-free step instead and
+            # (bounded: comm_timeout_ms = 1 s on these handles), every rank takes the torch.distributed fallback instead and
             # the line says so — a broken link must cost seconds, not steps x time-out
             st = gm.comm_status()
             flag = torch.tensor([float(st)], device=red_dev, dtype=torch.float64)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if flag.item() != 0:
-                halo_state.update(in_loop=False, why=f"a mailbox wait timed out during the warm-up (status {int(flag.item())})")
-                step = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=False)
                 try:
                     gm.synchronize()      # reports and clears the recorded time-out
                 except Exception:         # noqa: BLE001
                     pass
+                path, why = choose_comm_path(True, True, int(flag.item()))
+                sc = shard.ShardComm(gm, dist, force_fallback=True)
+                halo_state.update(path=path, why=why, kind=sc.kind)
+                step = make_step(path)
+        if halo_state["path"] == "rccl":
+            # the fallback's own rehearsal: a few steps, agreed on by all ranks; if IT fails the line says comm.path = none
+            ok = True
+            try:
+                for _ in range(max(2, warmup)):
+                    step()
+                torch.cuda.synchronize()
+            except Exception as e:        # noqa: BLE001
+                ok = False
+                halo_state["rccl_error"] = str(e)[:300]
+            flag = torch.tensor([0.0 if ok else 1.0], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() != 0:
+                path, why = choose_comm_path(False, False, 0, rccl_ok=False)
+                halo_state.update(path=path, why=halo_state.get("why", "") + "; " + why, in_loop=False)
+                step = make_step("none")
         barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events over the timed region, on the launch stream
@@ -460,9 +526,12 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         halo_state["loop_event_ms"] = ev0.elapsed_time(ev1) / steps
-        if halo_state["in_loop"]:
+        if halo_state["path"] == "own":
             halo_state["status"] = gm.comm_status()     # 0: every exchange of the timed loop completed
         if use_dist:
+            every = [None] * world
+            dist.all_gather_object(every, dt / steps * 1e3)
+            halo_state["rank_ms_per_step"] = {"min": min(every), "max": max(every), "all": every}
             t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -502,7 +571,7 @@ def main():
     n2 = min(args.steps, 200)
     secondary = {}
     # the other launch form of the same pair, and (N > 1) the same step without the exchange
-    other = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=not args.fused, halo=halo_state["in_loop"])
+    other = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=not args.fused, halo=halo_state["path"] == "own")
     secondary["fused_pair" if not args.fused else "separate_calls"] = {"ms_per_step": timed_loop(other, n2) / n2 * 1e3}
     if halo_state["in_loop"]:
         nohalo = gm.raw_pair(xd, yd, jac, hess, obj_weight=1.0, fused=args.fused, halo=False)
@@ -563,7 +632,7 @@ def main():
         del xs, ys
 
     reads_all = None
-    if world > 1 and use_dist and halo_state["in_loop"]:
+    if world > 1 and use_dist and halo_state["path"] == "own":
         reads_all = [None] * world       # rank 0 has no left neighbour: what the stencil makes a rank wait for shows on rank 1
         dist.all_gather_object(reads_all, {k: v[0] for k, v in gm.halo_reads().items() if k in ("cons", "jac", "hess", "pair")})
     line = None
@@ -607,7 +676,8 @@ def main():
                 traffic = None
         par = f"support-sharded x{world}, {args.scaling} scaling" + (f", shard {args.emulate_shard} emulated on one GPU" if args.emulate_shard else "")
         step_txt = ("iem_jac_hess_coord (one launch)" if args.fused else "iem_jac_coord + iem_hess_coord") + \
-                   (" behind iem_halo_exchange_async(x)" if halo_state["in_loop"] else "")
+                   (" behind iem_halo_exchange_async(x)" if halo_state["path"] == "own" else
+                    " behind a torch.distributed send/recv of the halo doubles (shard.ShardComm fallback)" if halo_state["path"] == "rccl" else "")
         roof = {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
                 "traffic_stale": stale, "traffic_source": traffic_src, "csrc_fingerprint": csrc_fingerprint(),
@@ -645,6 +715,8 @@ def main():
                        "kernels_from": "hiprtc at run time (code-object cache miss)" if any(k["jit"] for k in gm.kernels()) else "in-tree code-object cache"},
             "roofline": roof,
         }
+        line["launch"] = {"world_size": dist.get_world_size() if use_dist else 1, "device_count": torch.cuda.device_count(), "process_group": bool(use_dist),
+                          "rank_ms_per_step": halo_state.get("rank_ms_per_step")}
         line["pair_ms"] = {"median": float(np.median(pair_ms)), "p10": float(np.percentile(pair_ms, 10)),
                            "p90": float(np.percentile(pair_ms, 90)), "n": int(pair_ms.size)}
         for k, v in secondary.items():
@@ -652,7 +724,11 @@ def main():
             line[k] = v
         if world > 1:
             line["halo_in_timed_loop"] = bool(halo_state["in_loop"])
-            if halo_state["in_loop"]:
+            line["comm_path"] = {"path": halo_state["path"], "why": halo_state.get("why", ""), "backend": args.dist_backend,
+                                 "meaning": "own = the library's mailbox kernels; rccl = torch.distributed send/recv inside the timed step; none = no exchange could be made (the value then is NOT a multi-GPU step)"}
+            if halo_state.get("rccl_error"):
+                line["comm_path"]["rccl_error"] = halo_state["rccl_error"]
+            if halo_state["path"] == "own":
                 line["halo"] = {"exchange": "iem_halo_exchange_async (deferred; rides on the first launch of the step as one extra workgroup)", "mailbox_kind": halo_state.get("mailbox_kind"),
                                 "status_after_timed_loop": halo_state.get("status"), "reads_halo_rank1": reads_all[1] if reads_all else None,
                                 "meaning": "reads_halo: which calls of rank 1 need the exchange to be complete (their kernels can load a halo entry of x); the others can carry it"}
@@ -662,8 +738,8 @@ def main():
                 line["comm"] = comm
     # one-GPU rehearsal with many ranks: parents + children would exceed the box's per-GPU process limit — the checked
     # comm section runs in-process there
-    if world > 1 and use_dist and not args.no_comm and not args.emulate_shard and args.same_device and 2 * world > 6:
-        ccomm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, n2, connect=not halo_state["in_loop"])
+    if world > 1 and use_dist and not args.no_comm and not args.no_comm_check and not args.emulate_shard and args.same_device and 2 * world > 6:
+        ccomm = comm_section(gm, step, torch, dist, dev, red_dev, barrier, rank, world, n2, connect=halo_state["path"] != "own")
         if rank == 0:
             line["comm"] = ccomm
     # secondary measurement, outside the headline timed region: the weak form of the same run

@@ -371,16 +371,21 @@ class ShardComm:
         if self.kind == "own":
             return self.gm.halo_exchange_async(x) if overlap else self.gm.halo_exchange(x)
         b, dist, ops = self._dev(x), self.dist, []
+        # gloo moves host memory: device tensors are staged through the host (the one-GPU rehearsal of the fallback)
+        stage = x.is_cuda and dist.get_backend() == "gloo"
+        send = recv = None
         if self._right is not None:
             b["send"].copy_(x[b["src"]])
-            ops.append(dist.P2POp(dist.isend, b["send"], self._right))
+            send = b["send"].cpu() if stage else b["send"]
+            ops.append(dist.P2POp(dist.isend, send, self._right))
         if self._left is not None:
-            ops.append(dist.P2POp(dist.irecv, b["recv"], self._left))
+            recv = self._torch.empty(b["recv"].shape, dtype=b["recv"].dtype) if stage else b["recv"]
+            ops.append(dist.P2POp(dist.irecv, recv, self._left))
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
         if self._left is not None:
-            x[b["dst"]] = b["recv"]
+            x[b["dst"]] = recv.to(x.device) if stage else recv
         return x
 
     def allreduce_obj_grad(self, obj_dev, g):

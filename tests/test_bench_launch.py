@@ -27,6 +27,20 @@ def test_plain_launch_spawns_its_ranks(n):
     assert out == {"rehearsal": True, "n_gpus": n, "max_rank_seen": n - 1}
 
 
+@pytest.mark.parametrize("branch,path", [("own", "own"), ("children_failed", "rccl"), ("connect_failed", "rccl"), ("warmup_timeout", "rccl"),
+                                         ("rccl_failed", "none")])
+def test_comm_path_selection_branches(branch, path):
+    """What the N > 1 timed step contains (bench.choose_comm_path), every branch forced with simulated outcomes under gloo:
+    the library's mailboxes, the torch.distributed fallback when the child check / the wiring / a warm-up wait failed (one
+    rank's time-out is everybody's), and 'none' only when the fallback failed too."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--rehearse-comm", branch],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["comm"]["path"] == path and out["comm"]["world_size"] == 2
+    assert (out["comm"]["why"] == "") == (path == "own")
+
+
 def test_failed_rank_fails_the_launch():
     """Without a GPU a real run cannot start: every rank dies, and the parent must report it (non-zero
     exit, no JSON line) instead of hanging at a barrier."""

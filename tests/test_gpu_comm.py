@@ -70,8 +70,37 @@ def test_bench_line_carries_a_checked_comm_section(built):
     assert j["halo_in_timed_loop"] is True and "behind iem_halo_exchange_async" in j["config"]["step"]
     assert j["halo"]["status_after_timed_loop"] == 0 and j["halo"]["mailbox_kind"] in (1, 2, 3)
     assert j["halo"]["reads_halo_rank1"] == {"cons": True, "jac": False, "hess": False, "pair": False}   # difference rows are linear
+    assert j["comm_path"]["path"] == "own" and j["launch"]["world_size"] == 2 and len(j["launch"]["rank_ms_per_step"]["all"]) == 2
     # the timed step is the metric's own call pair; the one-launch form is reported beside it
     assert j["pair_no_halo"]["value"] > 0 and j["fused_pair"]["value"] > 0 and "iem_jac_coord + iem_hess_coord" in j["config"]["step"]
+
+
+def test_bench_line_with_the_torch_distributed_fallback_in_the_timed_step(built):
+    """The same N = 2 rehearsal with the mailboxes deliberately NOT used (--force-rccl): the timed step then contains the
+    torch.distributed send / recv of the halo doubles (shard.ShardComm's fallback; gloo here, RCCL on a multi-GPU node) — an
+    N > 1 line never times a communication-free step silently."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--force-rccl",
+                        "--supports", "40000", "--steps", "5", "--warmup", "2", "--no-comm-check"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["halo_in_timed_loop"] is True
+    assert j["comm_path"]["path"] == "rccl" and j["comm_path"]["why"] == "--force-rccl"
+    assert "torch.distributed send/recv" in j["config"]["step"] and j["pair_no_halo"]["value"] > j["value"] * 0.5
+
+
+def test_bench_under_a_process_group_of_one(built):
+    """`--gpus 1` under torchrun-style environment (RANK / WORLD_SIZE set): the process group is created, the line is the
+    single-GPU line (no exchange, no comm section)."""
+    import json
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--supports", "100000", "--steps", "10", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-variants", "--no-cold"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["launch"]["process_group"] is True and j["launch"]["world_size"] == 1
+    assert "comm_path" not in j and j["config"]["step"] == "iem_jac_coord + iem_hess_coord"
 
 
 def test_a_skipped_exchange_surfaces_as_an_error(built):
