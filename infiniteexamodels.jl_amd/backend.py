@@ -17,11 +17,22 @@ from typing import Any, Callable, Dict, Optional
 
 import numpy as np
 
-from . import results as _results
 from . import transcribe
 from .core import ExaCore
 from .infinite import FiniteParameterRef, InfiniteModel, ParameterFunctionRef
 from .model import ExaModel, MI355XBackend
+
+
+class _LazyResults:
+    """``contrib.results`` (status tables, result objects: outside SURVEY §8's scope, see ``contrib/__init__.py``) is only
+    loaded when a result query or an ``optimize()`` needs it; the evaluation path never imports it."""
+
+    def __getattr__(self, name):
+        from .contrib import results
+        return getattr(results, name)
+
+
+_results = _LazyResults()
 
 
 class ExaTranscriptionBackend:
@@ -51,6 +62,7 @@ class ExaTranscriptionBackend:
         self.core = self.model = self.results = None
         self.prev_options = {}
         self._solved_once = False
+        self._y0 = None          # a rebuild discards the warm start with the model (src/infiniteopt_backend.jl:595-615 keeps it inside the model)
         self.solve_time = float("nan")
         self.data = transcribe.ExaMappingData()
         return self

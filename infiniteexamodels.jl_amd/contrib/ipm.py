@@ -55,7 +55,7 @@ class InteriorPointSolver:
     # ------------------------------------------------------------------------------------------------------------
     def __call__(self, model, x0=None, y0=None, **options) -> IPMResult:
         import torch
-        from . import lib as _lib
+        from .. import lib as _lib
         o = dict(self.opt); o.update(options)
         t_start = time.perf_counter()
         meta = model.meta
@@ -209,6 +209,8 @@ class InteriorPointSolver:
                     if (neg == m and doubtful == 0) or tries >= 24:
                         break
                     dw = 1e-4 if dw == 0.0 else dw * (100.0 if tries <= 2 else 8.0)
+                if not (neg == m and doubtful == 0):
+                    break      # no usable factorisation within the permitted shifts: never a direction from stale factors (-> small_step)
                 d = lin.solve(rhs, refine=o["refine"], rtol=float(o["linear_rtol"]))
                 dx, dy = d[:n], d[n:]
                 ds = (dy[ine_idx] - r_s) / torch.clamp(sig_s, min=1e-300) if mI else s.clone()
@@ -364,9 +366,9 @@ class _DeviceLinear:
     between solves (shared with ``newton.LagrangeNewtonSolver``)."""
 
     def __init__(self, model, dense_limit: int):
-        from . import lib as _lib
-        from .kkt import KKTSystem
-        from .kkt_chain import ChainKKT
+        from .. import lib as _lib
+        from ..kkt import KKTSystem
+        from ..kkt_chain import ChainKKT
         from .newton import _Dense
         cached = getattr(model, "_newton_linear", None)
         if cached is None:

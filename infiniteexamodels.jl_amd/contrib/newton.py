@@ -81,9 +81,9 @@ class LagrangeNewtonSolver:
 
     def __call__(self, model, x0=None, y0=None, **options) -> NewtonResult:
         import torch
-        from . import lib as _lib
-        from .kkt import KKTSystem
-        from .kkt_chain import ChainKKT
+        from .. import lib as _lib
+        from ..kkt import KKTSystem
+        from ..kkt_chain import ChainKKT
         o = dict(self.opt); o.update(options)
         t_start = time.perf_counter()
         meta = model.meta
@@ -167,6 +167,8 @@ class LagrangeNewtonSolver:
                     if (neg == m and doubtful == 0) or tries >= 16:
                         break
                     dw = max(1e-4, dw * 10.0)
+                if not (neg == m and doubtful == 0):
+                    break      # no usable factorisation within the permitted shifts: never a direction from stale factors (-> small_step)
                 d = lin.solve(-r, refine=o["refine"], rtol=float(o["linear_rtol"]))
                 dx, dy = d[:n], d[n:]
                 # the weight follows the multipliers of THIS step — up at once, down by halves (the wild multipliers of the

@@ -17,7 +17,7 @@ from typing import Any, Dict
 
 import numpy as np
 
-from .core import Constraint, Variable
+from ..core import Constraint, Variable
 
 
 def _host(v) -> np.ndarray:

@@ -121,7 +121,7 @@ def test_lagrange_newton_solver_in_the_backend_slot(built):
     from infiniteexamodels.jl_amd import lib as iemlib, workloads
     from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
     from infiniteexamodels.jl_amd.model import ExaModel, MI355XBackend
-    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
     im = workloads.quadrotor(200, backend=ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8, max_iter=40), backend=MI355XBackend()))
     res = im.optimize()
     assert res.status == "first_order" and res.kkt_residual <= 1e-8 and res.iterations <= 25, res.history
@@ -168,7 +168,7 @@ def test_lagrange_newton_solver_on_a_maximisation(built):
     from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
     from infiniteexamodels.jl_amd.infinite import InfiniteModel
     from infiniteexamodels.jl_amd.model import MI355XBackend
-    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
     from pyoracle import OracleModel
 
     def build(sense):
@@ -203,7 +203,7 @@ def test_lagrange_newton_solver_on_the_equality_constrained_examples(built, buil
     stationarity re-checked through the oracle"""
     from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
     from infiniteexamodels.jl_amd.model import MI355XBackend
-    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
     from pyoracle import OracleModel
     import warnings
     with warnings.catch_warnings():
@@ -223,7 +223,7 @@ def test_interior_point_solver_reaches_the_references_constants_on_the_device(bu
     problem, and the two-stage LP of examples/2stage_example.jl."""
     from infiniteexamodels.jl_amd import workloads
     from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
-    from infiniteexamodels.jl_amd.ipm import InteriorPointSolver
+    from infiniteexamodels.jl_amd.contrib.ipm import InteriorPointSolver
     from infiniteexamodels.jl_amd.model import MI355XBackend
     from pyoracle import OracleModel
     mk = lambda **kw: ExaTranscriptionBackend(InteriorPointSolver(**kw), backend=MI355XBackend())

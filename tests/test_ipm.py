@@ -9,7 +9,7 @@ import pytest
 import cases
 from host_model import HostLinear, HostModel
 from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
-from infiniteexamodels.jl_amd.ipm import InteriorPointSolver
+from infiniteexamodels.jl_amd.contrib.ipm import InteriorPointSolver
 
 TOL = 1e-6
 

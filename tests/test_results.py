@@ -8,7 +8,7 @@ import scipy.sparse as sp
 from scipy.optimize import minimize
 
 import cases
-from infiniteexamodels.jl_amd import results as R
+from infiniteexamodels.jl_amd.contrib import results as R
 from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
 from infiniteexamodels.jl_amd.infinite import DomainRestriction, InfiniteModel, OrthogonalCollocation
 from pyoracle import OracleModel

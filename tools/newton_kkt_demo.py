@@ -21,8 +21,8 @@ from infiniteexamodels.jl_amd.model import ExaModel
 
 def newton(gm, iters=12, delta_w=1e-8, delta_c=1e-10, tol=1e-8, log=None):
     """Returns (x, y, history); every vector stays on the device.  (The method itself lives in the package:
-    ``infiniteexamodels.jl_amd.newton.LagrangeNewtonSolver`` — what ``ExaTranscriptionBackend`` takes in its solver slot.)"""
-    from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+    ``infiniteexamodels.jl_amd.contrib.newton.LagrangeNewtonSolver`` — what ``ExaTranscriptionBackend`` takes in its solver slot.)"""
+    from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
     res = LagrangeNewtonSolver(tol=tol, max_iter=iters, delta_w=delta_w, delta_c=delta_c, log=log)(gm)
     return res.solution, res.multipliers, res.history
 

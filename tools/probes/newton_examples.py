@@ -7,7 +7,7 @@ warnings.simplefilter("ignore")
 from infiniteexamodels.jl_amd import lib as iemlib, workloads
 from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
 from infiniteexamodels.jl_amd.model import MI355XBackend
-from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
 
 mk = lambda: ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8, max_iter=60), backend=MI355XBackend())
 cases = {"quadrotor 2000": lambda: workloads.quadrotor(2000, backend=mk()),

@@ -6,7 +6,7 @@ warnings.simplefilter("ignore")
 from infiniteexamodels.jl_amd import workloads
 from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
 from infiniteexamodels.jl_amd.model import MI355XBackend
-from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
 sizes = [int(a) for a in sys.argv[1:]] or [500, 1000, 2000, 5000, 20000, 100000]
 for n in sizes:
     im = workloads.quadrotor(n, backend=ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8, max_iter=60), backend=MI355XBackend()))

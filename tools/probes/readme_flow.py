@@ -2,7 +2,7 @@ import sys, time; sys.path.insert(0, '.')
 from infiniteexamodels.jl_amd import workloads
 from infiniteexamodels.jl_amd.backend import ExaTranscriptionBackend
 from infiniteexamodels.jl_amd.model import MI355XBackend
-from infiniteexamodels.jl_amd.newton import LagrangeNewtonSolver
+from infiniteexamodels.jl_amd.contrib.newton import LagrangeNewtonSolver
 t0 = time.time()
 im = workloads.quadrotor(100_000, backend=ExaTranscriptionBackend(LagrangeNewtonSolver(tol=1e-8), backend=MI355XBackend()))
 im.set_silent()
