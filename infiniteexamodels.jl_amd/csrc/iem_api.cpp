@@ -1855,28 +1855,46 @@ namespace {
 // chain's latency — beat one wave per tile row (quadrotor_oc3, 84 x 84 blocks: 11.6 ms with four waves, 10.3 with six, 5.8
 // with two; 40 x 40: 2.60 -> 2.40 with one).  With a border the products Z = D^-1 E and E' Z dominate and want the waves
 // (OPF, 60 + 52: 3.6 ms with four, 4.6 with two, 7.0 with one).  profiles/r03_kkt_shape_ab.txt
+struct KktKnobs { int wmax = -1, wpe = -1; std::string contract = "off", defs; };
+KktKnobs kkt_knobs() {
+  KktKnobs k;
+  const char *on = getenv("IEM_KKT_EXPERIMENTS");
+  if (!on || std::strcmp(on, "1") != 0) return k;     // production: the environment cannot change kernel shape, numerics or source
+  if (const char *e = getenv("IEM_KKT_WMAX")) { const int v = atoi(e); if (v >= 1 && v <= 6) k.wmax = v; }
+  if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) k.wpe = v; }
+  if (const char *e = getenv("IEM_KKT_CONTRACT")) { if (!std::strcmp(e, "fast") || !std::strcmp(e, "on") || !std::strcmp(e, "off")) k.contract = e; }
+  if (const char *e = getenv("IEM_KKT_DEFS")) {        // extra "#define NAME VALUE" lines only: [A-Za-z0-9_ #\n]
+    bool ok = true;
+    for (const char *c = e; *c; ++c) ok = ok && (std::isalnum((unsigned char)*c) || *c == '_' || *c == ' ' || *c == '#' || *c == '\n');
+    if (ok) k.defs = e;
+  }
+  return k;
+}
 void kkt_shape(int nb, int ne, int *wmax, int *wpe) {
   const int R = (nb + 15) / 16;
   if (ne > 0 || R <= 2) { *wmax = 4; *wpe = nb <= 48 ? 4 : 0; }
   else if (R == 3) { *wmax = 1; *wpe = 3; }
   else if (R == 4) { *wmax = 2; *wpe = 3; }
   else { *wmax = 2; *wpe = 2; }
-  if (const char *e = getenv("IEM_KKT_WMAX")) { const int v = atoi(e); if (v >= 1 && v <= 6) *wmax = v; }
-  if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) *wpe = v; }
+  // experiment overrides (tools/sessions/kkt_shape_ab.sh): honoured only when IEM_KKT_EXPERIMENTS=1, and read ONCE per process —
+  // the launch shape of a cached module can never drift from the KKT_T it was compiled with
+  static const KktKnobs knobs = kkt_knobs();
+  if (knobs.wmax >= 1) *wmax = knobs.wmax;
+  if (knobs.wpe >= 0) *wpe = knobs.wpe;
 }
 std::string kkt_source(int nb, int ne, int nc) {
   // (fused multiply-adds would be allowed here — nothing compares these kernels bit for bit — and take 1 000 of the 2 350 FP64
   // instructions out of a 40 x 40 kkt_eliminate, but the factorisation does not get faster for it: 2.52 against 2.45 ms at 1e5
   // quadrotor supports, 3.22 against 3.54 for the bordered OPF blocks, solves 9 % slower — the panel steps wait on their
   // dependency chain, not on issue slots.  IEM_KKT_CONTRACT=fast switches them on; profiles/r03_kkt_shape_ab.txt)
-  const char *contract = getenv("IEM_KKT_CONTRACT");
-  std::string s = std::string("// iem-flags: -O3 -ffp-contract=") + (contract ? contract : "off") + " -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
+  static const KktKnobs knobs = kkt_knobs();
+  std::string s = std::string("// iem-flags: -O3 -ffp-contract=") + knobs.contract + " -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
   s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
   int wmax, wpe;
   kkt_shape(nb, ne, &wmax, &wpe);
   if (wpe > 0) s += "#define KKT_WPE " + std::to_string(wpe) + "\n";
   if (wmax != 4) s += "#define KKT_WMAX " + std::to_string(wmax) + "\n";
-  if (const char *e = getenv("IEM_KKT_DEFS")) s += std::string(e) + "\n";     // (experiments: extra #define lines)
+  if (!knobs.defs.empty()) s += knobs.defs + "\n";     // (experiments, IEM_KKT_EXPERIMENTS=1 only: extra #define lines)
   s += kKktSource;
   return s;
 }
@@ -2172,7 +2190,14 @@ int iem_kkt_factor(iem_kkt *k, int64_t *out_inertia) {
     for (size_t i = 0; i < G.size(); ++i) k->Gs[i] = G[i] - gp[i];
     std::vector<double> ev;
     iem::sym_eigenvalues(k->Gs, L.ne, ev);
-    for (double e : ev) if (e < 0.0) ++neg;
+    double emax = 0.0;
+    for (double e : ev) emax = std::max(emax, std::fabs(e));
+    for (double e : ev) {
+      // a zero / near-zero eigenvalue is neither sign: reported as DOUBTFUL so that a host doing the usual inertia correction
+      // (neg == ncon && doubtful == 0) shifts and factorises again instead of solving with a singular border
+      if (std::fabs(e) <= 1e-14 * emax || emax == 0.0) ++doubtful;
+      else if (e < 0.0) ++neg;
+    }
   }
   long long info[3] = {0, 0, 0};
   HIP_TRY(hipStreamSynchronize(m->stream));

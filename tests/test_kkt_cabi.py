@@ -139,3 +139,35 @@ def test_assemble_factor_solve_through_the_c_abi(name, built):
         np.testing.assert_allclose(xs, want, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(want).max()))
     iemlib.check(L_.iem_kkt_destroy(k))
     gm.close()
+
+
+@pytest.mark.gpu
+def test_a_singular_system_is_reported_as_doubtful(built):
+    """[0 J'; J 0] of the farmer LP without any regularisation (sigma = 0, delta_w = delta_c = 0) is singular (nvar > ncon): a host
+    doing the usual inertia correction (neg == ncon and doubtful == 0) must see DOUBTFUL pivots — from the blocks or from the
+    border's Schur complement, whose zero eigenvalues count as doubtful, never as positive — and shift."""
+    import torch
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.model import ExaModel
+    core = cases.build_core("farmer_5")
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    gm = ExaModel(core, device=0, blob=blob)
+    k = C.c_void_p()
+    iemlib.check(gm._L.iem_kkt_create(gm._h, 0, C.byref(k)))
+    x, y = cases.eval_point_for("farmer_5", om, 5)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    sd = torch.zeros(om.nvar, dtype=torch.float64, device="cuda")
+    hv, jv = gm.hess_coord(xd, yd, obj_weight=1.0), gm.jac_coord(xd)
+    gm._sync_stream()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    iemlib.check(gm._L.iem_kkt_assemble(k, p(hv), p(jv), p(sd), 0.0, 0.0))
+    inertia = (C.c_int64 * 3)()
+    iemlib.check(gm._L.iem_kkt_factor(k, inertia))
+    assert inertia[2] > 0, tuple(inertia)
+    # regularised, the same object factorises cleanly again
+    iemlib.check(gm._L.iem_kkt_assemble(k, p(hv), p(jv), p(sd), 1e-2, 1e-6))
+    iemlib.check(gm._L.iem_kkt_factor(k, inertia))
+    assert (inertia[1], inertia[2]) == (om.ncon, 0), tuple(inertia)
+    iemlib.check(gm._L.iem_kkt_destroy(k))
+    gm.close()
