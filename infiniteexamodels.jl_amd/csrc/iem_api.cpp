@@ -1906,8 +1906,8 @@ bool kkt_fits(int nb, int ne, int nc) {
   return elim <= 160 * 1024 && upd <= 160 * 1024;
 }
 int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
-  if (nb < 4 || nb > 96 || nb % 4 || ne < 0 || ne > 64 || ne % 4 || nc < 4 || nc > 48 || nc % 4 || nc > nb || !kkt_fits(nb, ne, nc))
-    return fail(IEM_E_ARG, "chain KKT: block size must be a multiple of 4 in 4..96, border size a multiple of 4 in 0..64, coupling width a multiple of 4 in 4..48 (and <= the block size), tiles within the LDS of a CU");
+  if (nb < 4 || nb > 96 || nb % 4 || ne < 0 || ne > 128 || ne % 4 || nc < 4 || nc > 48 || nc % 4 || nc > nb || !kkt_fits(nb, ne, nc))
+    return fail(IEM_E_ARG, "chain KKT: block size must be a multiple of 4 in 4..96, border size a multiple of 4 in 0..128, coupling width a multiple of 4 in 4..48 (and <= the block size), tiles within the LDS of a CU");
   auto it = m->kkt_mods.find({nb, ne * 64 + nc});
   if (it == m->kkt_mods.end()) {
     iem_model::KktMod km;
@@ -2061,7 +2061,7 @@ int iem_kkt_analyse_blob(const void *blob, size_t nbytes, int group, iem_kkt_inf
     std::vector<int64_t> jr((size_t)M.nnzj), jc((size_t)M.nnzj), hr((size_t)M.nnzh), hc((size_t)M.nnzh);
     jac_structure_host(M, jr.data(), jc.data(), 0);
     hess_structure_host(M, hr.data(), hc.data(), 0);
-    iem::KktLayout L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 64, 48);
+    iem::KktLayout L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 128, 48);
     iem::KktPlan P = iem::kkt_plan(L, hr, hc, jr, jc);
     info->S = L.S; info->n = L.nvar + L.ncon; info->n_border = L.n_border; info->nb = L.nb; info->ne = L.ne; info->nc = L.nc;
     info->reach = L.reach; info->group = L.group; info->phase = L.phase; info->block_doubles = L.total();
@@ -2094,7 +2094,7 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
     jac_structure_host(M, jr.data(), jc.data(), 0);
     if (m->opt.hess_merge) return fail(IEM_E_ARG, "iem_kkt_create: the merged Hessian layout is not supported here");
     hess_structure_host(M, hr.data(), hc.data(), 0);
-    k->L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 64, 48);
+    k->L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 128, 48);
     if (!kkt_fits(k->L.nb, k->L.ne, k->L.nc)) return fail(IEM_E_ARG, "chain KKT: the tiles of a block do not fit the LDS of a CU");
     iem::KktPlan P = iem::kkt_plan(k->L, hr, hc, jr, jc);
     k->n_dest = (int64_t)P.dest.size(); k->n_h = P.n_h; k->n_j = P.n_j;
@@ -2188,15 +2188,22 @@ int iem_kkt_factor(iem_kkt *k, int64_t *out_inertia) {
     HIP_TRY(hipMemcpy(G.data(), k->d_flat + L.oG(), G.size() * 8, hipMemcpyDeviceToHost));
     k->Gs.resize(G.size());
     for (size_t i = 0; i < G.size(); ++i) k->Gs[i] = G[i] - gp[i];
-    std::vector<double> ev;
-    iem::sym_eigenvalues(k->Gs, L.ne, ev);
-    double emax = 0.0;
-    for (double e : ev) emax = std::max(emax, std::fabs(e));
-    for (double e : ev) {
-      // a zero / near-zero eigenvalue is neither sign: reported as DOUBTFUL so that a host doing the usual inertia correction
-      // (neg == ncon && doubtful == 0) shifts and factorises again instead of solving with a singular border
-      if (std::fabs(e) <= 1e-14 * emax || emax == 0.0) ++doubtful;
-      else if (e < 0.0) ++neg;
+    if (L.ne <= 64) {
+      std::vector<double> ev;
+      iem::sym_eigenvalues(k->Gs, L.ne, ev);
+      double emax = 0.0;
+      for (double e : ev) emax = std::max(emax, std::fabs(e));
+      for (double e : ev) {
+        // a zero / near-zero eigenvalue is neither sign: reported as DOUBTFUL so that a host doing the usual inertia correction
+        // (neg == ncon && doubtful == 0) shifts and factorises again instead of solving with a singular border
+        if (std::fabs(e) <= 1e-14 * emax || emax == 0.0) ++doubtful;
+        else if (e < 0.0) ++neg;
+      }
+    } else {      // (a laned 2-D grid's border, up to 128: LDL' pivot signs instead of Jacobi sweeps)
+      int64_t bn = 0, bd = 0;
+      iem::sym_inertia_ldl(k->Gs, L.ne, bn, bd);
+      // the padding's unit diagonal (n_border .. ne) is positive: nothing to subtract
+      neg += bn; doubtful += bd;
     }
   }
   long long info[3] = {0, 0, 0};

@@ -28,7 +28,7 @@
 // right-hand side (kkt_forward: z_i = D_i^-1 r_i, survivors take the R / C entries of their neighbours' z), the border
 // system (tiny, dense), the levels backward (kkt_backward).  FP64 throughout; no atomics on floating-point data.
 //
-// Compile-time: KKT_NB (block size, multiple of 4, <= 96), KKT_NE (border size, 0 or a multiple of 4, <= 64), KKT_NC
+// Compile-time: KKT_NB (block size, multiple of 4, <= 96), KKT_NE (border size, 0 or a multiple of 4, <= 128), KKT_NC
 // (coupling rows / columns, multiple of 4, <= 48).
 #ifndef IEM_KKT_DEVICE_H
 #define IEM_KKT_DEVICE_H

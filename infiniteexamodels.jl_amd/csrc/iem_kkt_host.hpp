@@ -26,6 +26,11 @@ namespace iem {
 struct KktLayout {
   int64_t nvar = 0, ncon = 0, S = 0, n_border = 0;
   int nb = 0, ne = 0, nc = 4, reach = 0, group = 0, phase = 0;
+  // LANES (2-D support grids, e.g. ESCAPE34/pandemic.jl: t x xi): when the blocks of one chain support would be too large
+  // (17 N_xi + 1 unknowns per time support), every point of the OTHER parameter(s) gets a chain of its own — block index =
+  // lane * (blocks per lane) + time block, zero coupling at the seams — and the unknowns that live on the chain's parameter
+  // alone (u(t): one per time support, coupled to every lane) form the border.  1: plain chain.
+  int64_t lanes = 1;
   std::vector<int64_t> blk, loc;        // per unknown: block (-1: border) and place in the block / the border
   std::vector<int64_t> counts;          // real unknowns per block
   std::vector<int32_t> rowsR, colsC;    // local rows (of block k) / columns (of block k - 1) of the coupling, padded with -1 to nc
@@ -95,78 +100,133 @@ inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, cons
     coords(group, vc); row_span(vc, hi, lo);
   }
   L.group = group;
-  for (int64_t r = 0; r < ncon; ++r) L.reach = (int)std::max<int64_t>(L.reach, hi[(size_t)r] - lo[(size_t)r]);
-  const int64_t R = std::max(L.reach, 1);
-  std::vector<int64_t> chain((size_t)n);
-  for (int64_t i = 0; i < nvar; ++i) chain[(size_t)i] = vc[(size_t)i];
-  for (int64_t r = 0; r < ncon; ++r) chain[(size_t)(nvar + r)] = hi[(size_t)r];     // a row sits with the LAST support it touches
-  std::vector<int64_t> ids, border;
-  for (int64_t u = 0; u < n; ++u) (chain[(size_t)u] >= 0 ? ids : border).push_back(u);
+  // lane of a variable: its flattened position along the OTHER dimensions of a slab that carries the chain's group (-1: the
+  // variable has no other dimension — or no chain coordinate at all)
+  std::vector<int64_t> vlane((size_t)nvar, -1);
+  int64_t nlanes = 1;
+  bool lanes_consistent = true;
+  for (const Slab &s : m.slabs)
+    for (int a = 0; a < s.nd; ++a) {
+      if (s.group[a] != group) continue;
+      int64_t stride = 1, other = 1;
+      for (int d = 0; d < a; ++d) stride *= s.dims[d];
+      for (int d = 0; d < s.nd; ++d) if (d != a) other *= s.dims[d];
+      if (other > 1) {
+        if (nlanes > 1 && nlanes != other) lanes_consistent = false;
+        nlanes = std::max(nlanes, other);
+        const int64_t len = s.length(), span = stride * s.dims[a];
+        for (int64_t i = 0; i < len; ++i) vlane[(size_t)(s.off + i)] = (i / span) * stride + (i % stride);
+      }
+      break;
+    }
   struct Cand { std::vector<int64_t> blk, loc, counts; int nb = 0; std::vector<int64_t> rows, cols; int64_t S = 0; };
-  auto arrange = [&](int64_t phase) {
-    Cand c;
-    c.blk.assign((size_t)n, -1); c.loc.assign((size_t)n, -1);
-    std::vector<int64_t> off((size_t)n, 0);
-    for (int64_t u : ids) { c.blk[(size_t)u] = (chain[(size_t)u] + phase) / R; off[(size_t)u] = (chain[(size_t)u] + phase) % R; c.S = std::max(c.S, c.blk[(size_t)u] + 1); }
-    auto gkey = [&](int64_t u) { return (c.blk[(size_t)u] * 2 + (u >= nvar ? 1 : 0)) * R + off[(size_t)u]; };
-    std::vector<int64_t> order(ids);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return gkey(a) < gkey(b); });
-    std::vector<int64_t> ordinal(order.size(), 0), size((size_t)(2 * R), 0);
-    for (size_t i = 0; i < order.size(); ++i) {
-      if (i && gkey(order[i]) == gkey(order[i - 1])) ordinal[i] = ordinal[i - 1] + 1;
-      const int64_t u = order[i], ko = (u >= nvar ? 1 : 0) * R + off[(size_t)u];
-      size[(size_t)ko] = std::max(size[(size_t)ko], ordinal[i] + 1);
+  // `use_lanes`: one chain per lane, lane-less chain variables to the border
+  auto build = [&](bool use_lanes) {
+    KktLayout B = L;
+    std::vector<int64_t> chain((size_t)n, -1), lane((size_t)n, 0);
+    std::vector<int64_t> rhi(hi), rlo(lo);
+    if (use_lanes) {
+      // rows: lane and span from their LANED variables only; a row whose variables sit in two lanes does not fit
+      std::vector<int64_t> rl((size_t)ncon, -1);
+      rhi.assign((size_t)ncon, -1); rlo.assign((size_t)ncon, INT64_MAX);
+      for (int64_t k = 0; k < nj; ++k) {
+        const int64_t v = jc[(size_t)k], r = jr[(size_t)k];
+        if (vlane[(size_t)v] < 0 || vc[(size_t)v] < 0) continue;
+        if (rl[(size_t)r] >= 0 && rl[(size_t)r] != vlane[(size_t)v]) throw std::runtime_error("chain KKT: a constraint row couples two lanes of the support grid");
+        rl[(size_t)r] = vlane[(size_t)v];
+        rhi[(size_t)r] = std::max(rhi[(size_t)r], vc[(size_t)v]); rlo[(size_t)r] = std::min(rlo[(size_t)r], vc[(size_t)v]);
+      }
+      for (int64_t i = 0; i < nvar; ++i) if (vlane[(size_t)i] >= 0 && vc[(size_t)i] >= 0) { chain[(size_t)i] = vc[(size_t)i]; lane[(size_t)i] = vlane[(size_t)i]; }
+      for (int64_t r = 0; r < ncon; ++r) if (rl[(size_t)r] >= 0) { chain[(size_t)(nvar + r)] = rhi[(size_t)r]; lane[(size_t)(nvar + r)] = rl[(size_t)r]; }
+      B.lanes = nlanes;
+    } else {
+      for (int64_t i = 0; i < nvar; ++i) chain[(size_t)i] = vc[(size_t)i];
+      for (int64_t r = 0; r < ncon; ++r) chain[(size_t)(nvar + r)] = hi[(size_t)r];     // a row sits with the LAST support it touches
     }
-    std::vector<int64_t> base((size_t)(2 * R), 0);
-    int64_t run = 0;
-    for (int64_t ko = 0; ko < 2 * R; ++ko) { base[(size_t)ko] = run; run += size[(size_t)ko]; }   // variables by position, then rows by position
-    for (size_t i = 0; i < order.size(); ++i) {
-      const int64_t u = order[i], ko = (u >= nvar ? 1 : 0) * R + off[(size_t)u];
-      c.loc[(size_t)u] = base[(size_t)ko] + ordinal[i];
+    B.reach = 0;
+    for (int64_t r = 0; r < ncon; ++r) if (rhi[(size_t)r] >= 0 && rlo[(size_t)r] != INT64_MAX) B.reach = (int)std::max<int64_t>(B.reach, rhi[(size_t)r] - rlo[(size_t)r]);
+    const int64_t R = std::max(B.reach, 1);
+    std::vector<int64_t> ids, border;
+    for (int64_t u = 0; u < n; ++u) (chain[(size_t)u] >= 0 ? ids : border).push_back(u);
+    auto arrange = [&](int64_t phase) {
+      Cand c;
+      c.blk.assign((size_t)n, -1); c.loc.assign((size_t)n, -1);
+      std::vector<int64_t> off((size_t)n, 0);
+      int64_t Sb = 0;
+      for (int64_t u : ids) Sb = std::max(Sb, (chain[(size_t)u] + phase) / R + 1);
+      for (int64_t u : ids) { c.blk[(size_t)u] = lane[(size_t)u] * Sb + (chain[(size_t)u] + phase) / R; off[(size_t)u] = (chain[(size_t)u] + phase) % R; }
+      c.S = ids.empty() ? 0 : B.lanes * Sb;
+      auto gkey = [&](int64_t u) { return (c.blk[(size_t)u] * 2 + (u >= nvar ? 1 : 0)) * R + off[(size_t)u]; };
+      std::vector<int64_t> order(ids);
+      std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return gkey(a) < gkey(b); });
+      std::vector<int64_t> ordinal(order.size(), 0), size((size_t)(2 * R), 0);
+      for (size_t i = 0; i < order.size(); ++i) {
+        if (i && gkey(order[i]) == gkey(order[i - 1])) ordinal[i] = ordinal[i - 1] + 1;
+        const int64_t u = order[i], ko = (u >= nvar ? 1 : 0) * R + off[(size_t)u];
+        size[(size_t)ko] = std::max(size[(size_t)ko], ordinal[i] + 1);
+      }
+      std::vector<int64_t> base((size_t)(2 * R), 0);
+      int64_t run = 0;
+      for (int64_t ko = 0; ko < 2 * R; ++ko) { base[(size_t)ko] = run; run += size[(size_t)ko]; }   // variables by position, then rows by position
+      for (size_t i = 0; i < order.size(); ++i) {
+        const int64_t u = order[i], ko = (u >= nvar ? 1 : 0) * R + off[(size_t)u];
+        c.loc[(size_t)u] = base[(size_t)ko] + ordinal[i];
+      }
+      for (size_t i = 0; i < border.size(); ++i) c.loc[(size_t)border[i]] = (int64_t)i;
+      c.counts.assign((size_t)c.S, 0);
+      for (int64_t u : ids) ++c.counts[(size_t)c.blk[(size_t)u]];
+      c.nb = (int)ceil4(run);
+      std::set<int64_t> rs, cs;
+      for (int64_t k = 0; k < nj; ++k) {
+        const int64_t ur = nvar + jr[k], uc = jc[k], kr = c.blk[(size_t)ur], kc = c.blk[(size_t)uc];
+        if (kr < 0 || kc < 0) continue;
+        if (kr == kc + 1) { rs.insert(c.loc[(size_t)ur]); cs.insert(c.loc[(size_t)uc]); }
+        else if (kc == kr + 1) { rs.insert(c.loc[(size_t)uc]); cs.insert(c.loc[(size_t)ur]); }
+      }
+      for (size_t k = 0; k < hr.size(); ++k) {
+        const int64_t ur = hr[k], uc = hc[k], kr = c.blk[(size_t)ur], kc = c.blk[(size_t)uc];
+        if (kr < 0 || kc < 0 || kr == kc) continue;
+        if (kr == kc + 1) { rs.insert(c.loc[(size_t)ur]); cs.insert(c.loc[(size_t)uc]); }
+        else if (kc == kr + 1) { rs.insert(c.loc[(size_t)uc]); cs.insert(c.loc[(size_t)ur]); }
+      }
+      c.rows.assign(rs.begin(), rs.end()); c.cols.assign(cs.begin(), cs.end());
+      return c;
+    };
+    bool have = false;
+    std::tuple<int64_t, int, int64_t> best_key;
+    Cand best;
+    for (int64_t phase = 0; phase < R; ++phase) {
+      Cand c = arrange(phase);
+      const std::tuple<int64_t, int, int64_t> key{(int64_t)std::max(c.rows.size(), c.cols.size()), c.nb, phase};
+      if (!have || key < best_key) { have = true; best_key = key; best = std::move(c); B.phase = (int)phase; }
     }
-    for (size_t i = 0; i < border.size(); ++i) c.loc[(size_t)border[i]] = (int64_t)i;
-    c.counts.assign((size_t)c.S, 0);
-    for (int64_t u : ids) ++c.counts[(size_t)c.blk[(size_t)u]];
-    c.nb = (int)ceil4(run);
-    std::set<int64_t> rs, cs;
-    for (int64_t k = 0; k < nj; ++k) {
-      const int64_t ur = nvar + jr[k], uc = jc[k], kr = c.blk[(size_t)ur], kc = c.blk[(size_t)uc];
-      if (kr < 0 || kc < 0) continue;
-      if (kr == kc + 1) { rs.insert(c.loc[(size_t)ur]); cs.insert(c.loc[(size_t)uc]); }
-      else if (kc == kr + 1) { rs.insert(c.loc[(size_t)uc]); cs.insert(c.loc[(size_t)ur]); }
-    }
-    for (size_t k = 0; k < hr.size(); ++k) {
-      const int64_t ur = hr[k], uc = hc[k], kr = c.blk[(size_t)ur], kc = c.blk[(size_t)uc];
-      if (kr < 0 || kc < 0 || kr == kc) continue;
-      if (kr == kc + 1) { rs.insert(c.loc[(size_t)ur]); cs.insert(c.loc[(size_t)uc]); }
-      else if (kc == kr + 1) { rs.insert(c.loc[(size_t)uc]); cs.insert(c.loc[(size_t)ur]); }
-    }
-    c.rows.assign(rs.begin(), rs.end()); c.cols.assign(cs.begin(), cs.end());
-    return c;
+    if (best.S < 1) throw std::runtime_error("chain KKT: no unknown lies on the chain");
+    B.S = best.S; B.blk.swap(best.blk); B.loc.swap(best.loc); B.counts.swap(best.counts);
+    B.n_border = (int64_t)border.size();
+    B.nb = best.nb; B.ne = (int)ceil4((int64_t)border.size());
+    if (B.nb > max_nb || B.ne > max_ne)
+      throw std::runtime_error("chain KKT: blocks of " + std::to_string(*std::max_element(B.counts.begin(), B.counts.end())) + " unknowns / a border of " +
+                               std::to_string(border.size()) + " exceed the dense-block solver's limits (" + std::to_string(max_nb) + " / " + std::to_string(max_ne) + ")");
+    B.nc = (int)std::max<int64_t>(ceil4((int64_t)std::max(best.rows.size(), best.cols.size())), 4);
+    if (B.reach > 0 && (B.nc > max_nc || B.nc > B.nb))
+      throw std::runtime_error("chain KKT: the coupling between neighbouring blocks spans " + std::to_string(best.rows.size()) + " rows / " +
+                               std::to_string(best.cols.size()) + " columns (limit " + std::to_string(max_nc) + ")");
+    B.rowsR.assign((size_t)B.nc, -1); B.colsC.assign((size_t)B.nc, -1);
+    for (size_t i = 0; i < best.rows.size(); ++i) B.rowsR[i] = (int32_t)best.rows[i];
+    for (size_t i = 0; i < best.cols.size(); ++i) B.colsC[i] = (int32_t)best.cols[i];
+    return B;
   };
-  bool have = false;
-  std::tuple<int64_t, int, int64_t> best_key;
-  Cand best;
-  for (int64_t phase = 0; phase < R; ++phase) {
-    Cand c = arrange(phase);
-    const std::tuple<int64_t, int, int64_t> key{(int64_t)std::max(c.rows.size(), c.cols.size()), c.nb, phase};
-    if (!have || key < best_key) { have = true; best_key = key; best = std::move(c); L.phase = (int)phase; }
+  // the plain chain first (every model it fits keeps its layout); a 2-D grid whose time blocks are too large gets lanes
+  try {
+    return build(false);
+  } catch (const std::runtime_error &plain) {
+    if (nlanes <= 1 || !lanes_consistent) throw;
+    try {
+      return build(true);
+    } catch (const std::runtime_error &laned) {
+      throw std::runtime_error(std::string(plain.what()) + "; one chain per lane of the support grid (" + std::to_string(nlanes) + " lanes): " + laned.what());
+    }
   }
-  if (best.S < 1) throw std::runtime_error("chain KKT: no unknown lies on the chain");
-  L.S = best.S; L.blk.swap(best.blk); L.loc.swap(best.loc); L.counts.swap(best.counts);
-  L.n_border = (int64_t)border.size();
-  L.nb = best.nb; L.ne = (int)ceil4((int64_t)border.size());
-  if (L.nb > max_nb || L.ne > max_ne)
-    throw std::runtime_error("chain KKT: blocks of " + std::to_string(*std::max_element(L.counts.begin(), L.counts.end())) + " unknowns / a border of " +
-                             std::to_string(border.size()) + " exceed the dense-block solver's limits (" + std::to_string(max_nb) + " / " + std::to_string(max_ne) + ")");
-  L.nc = (int)std::max<int64_t>(ceil4((int64_t)std::max(best.rows.size(), best.cols.size())), 4);
-  if (L.reach > 0 && (L.nc > max_nc || L.nc > L.nb))
-    throw std::runtime_error("chain KKT: the coupling between neighbouring blocks spans " + std::to_string(best.rows.size()) + " rows / " +
-                             std::to_string(best.cols.size()) + " columns (limit " + std::to_string(max_nc) + ")");
-  L.rowsR.assign((size_t)L.nc, -1); L.colsC.assign((size_t)L.nc, -1);
-  for (size_t i = 0; i < best.rows.size(); ++i) L.rowsR[i] = (int32_t)best.rows[i];
-  for (size_t i = 0; i < best.cols.size(); ++i) L.colsC[i] = (int32_t)best.cols[i];
-  return L;
 }
 
 // where the entry (ur, uc) of K goes in the flat buffer (-1: dropped — the upper coupling blocks and the border's row block, by symmetry)
@@ -269,6 +329,34 @@ inline void sym_eigenvalues(std::vector<double> a, int n, std::vector<double> &e
   }
   ev.resize((size_t)n);
   for (int i = 0; i < n; ++i) ev[(size_t)i] = a[(size_t)(i * n + i)];
+}
+
+// inertia of a symmetric matrix by LDL' with symmetric (diagonal) pivoting — O(n^3 / 3), for borders beyond what the Jacobi sweeps
+// above handle cheaply.  A pivot below `rel` times the largest diagonal seen is DOUBTFUL (counted, then skipped).
+inline void sym_inertia_ldl(std::vector<double> a, int n, int64_t &neg, int64_t &doubtful, double rel = 1e-14) {
+  neg = doubtful = 0;
+  std::vector<char> done((size_t)n, 0);
+  double scale = 0.0;
+  for (int i = 0; i < n; ++i) scale = std::max(scale, std::fabs(a[(size_t)(i * n + i)]));
+  for (int step = 0; step < n; ++step) {
+    int p = -1;
+    for (int i = 0; i < n; ++i) if (!done[(size_t)i] && (p < 0 || std::fabs(a[(size_t)(i * n + i)]) > std::fabs(a[(size_t)(p * n + p)]))) p = i;
+    const double d = a[(size_t)(p * n + p)];
+    done[(size_t)p] = 1;
+    if (std::fabs(d) <= rel * scale || d == 0.0) {
+      // (a zero diagonal with off-diagonal mass would need a 2 x 2 pivot: one positive and one negative eigenvalue — reported as
+      // doubtful here, which makes the caller shift; the regularised systems this is used on are quasi-definite)
+      ++doubtful;
+      continue;
+    }
+    if (d < 0.0) ++neg;
+    for (int i = 0; i < n; ++i) {
+      if (done[(size_t)i]) continue;
+      const double f = a[(size_t)(i * n + p)] / d;
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; ++j) if (!done[(size_t)j]) a[(size_t)(i * n + j)] -= f * a[(size_t)(p * n + j)];
+    }
+  }
 }
 
 // A x = b for a small dense matrix, partial pivoting (in place on copies); false when singular

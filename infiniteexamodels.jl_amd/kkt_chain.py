@@ -30,7 +30,7 @@ import numpy as np
 
 from . import lib as _lib
 
-MAX_NB, MAX_NE, MAX_NC = 96, 64, 48
+MAX_NB, MAX_NE, MAX_NC = 96, 128, 48
 
 
 def fits_lds(nb: int, ne: int, nc: int = 4) -> bool:
@@ -94,66 +94,120 @@ class ChainLayout:
             vc = coords(group)
             hi, lo = row_span(vc)
         self.group = int(group)
-        self.reach = int((hi - lo).max()) if self.ncon else 0
-        R = max(self.reach, 1)                      # supports per block: a row then spans at most two consecutive blocks
-        self.supports_per_block = R
-        chain = np.concatenate([vc, hi])            # variables, then rows (a row sits with the LAST support it touches)
+        # LANES (2-D support grids, ESCAPE34/pandemic.jl: t x xi): lane of a variable = its flattened position along the OTHER
+        # dimensions of a slab that carries the chain's group (-1: none).  When the plain chain's blocks are too large, every
+        # lane gets a chain of its own (block = lane * blocks-per-lane + time block, zero coupling at the seams) and the
+        # variables on the chain's parameter alone (u(t)) go to the border — csrc/iem_kkt_host.hpp does the same.
+        vlane = np.full(self.nvar, -1, dtype=np.int64)
+        nlanes, consistent = 1, True
+        for off, dims, gs in slabs:
+            if group in gs:
+                a = list(gs).index(group)
+                n_ = int(np.prod(dims))
+                stride = int(np.prod(dims[:a])) if a else 1
+                other = n_ // dims[a]
+                if other > 1:
+                    consistent = consistent and nlanes in (1, other)
+                    nlanes = max(nlanes, other)
+                    i = np.arange(n_)
+                    vlane[off:off + n_] = (i // (stride * dims[a])) * stride + (i % stride)
+        jrn, jcn = jr.numpy(), jc.numpy()
         n = self.nvar + self.ncon
         kind = (np.arange(n) >= self.nvar).astype(np.int64)
-        on = chain >= 0
-        ids = np.nonzero(on)[0]
-        border = np.nonzero(~on)[0]                 # border: variables first, then rows (already in that order)
-        jrn, jcn = jr.numpy(), jc.numpy()
 
-        def arrange(phase):
-            """Blocks of R supports starting at support -phase: (blk, loc, counts, nb, coupling rows, coupling columns).
-            Inside a block the unknowns sit in FIXED places — variables before rows, each kind by the support's position in
-            the block, then by index, every (kind, position) group at the same base in every block — so that a block with
-            fewer unknowns (the first support has no difference row, the last block may be short) leaves holes instead of
-            shifting the others: the coupling then lives on the same few local rows / columns in every block."""
-            blk = np.where(on, (chain + phase) // R, -1)
-            off = np.where(on, (chain + phase) % R, 0)
-            S = int(blk.max()) + 1 if on.any() else 0
-            gk = (blk[ids] * 2 + kind[ids]) * R + off[ids]       # (block, kind, position in the block); ids ascend: a stable sort keeps index order
-            perm = np.argsort(gk, kind="stable")
-            order, g = ids[perm], gk[perm]
-            first = np.concatenate([[True], g[1:] != g[:-1]]) if order.size else np.zeros(0, bool)
-            pos = np.arange(order.size)
-            ordinal = pos - np.maximum.accumulate(np.where(first, pos, 0))
-            size = np.bincount(g, minlength=S * 2 * R).reshape(S, 2, R).max(axis=0) if S else np.zeros((2, R), dtype=np.int64)   # largest (kind, position) group over the blocks
-            base = np.zeros((2, R), dtype=np.int64)
-            base[0] = np.concatenate([[0], np.cumsum(size[0])[:-1]])
-            base[1] = size[0].sum() + np.concatenate([[0], np.cumsum(size[1])[:-1]])
-            loc = np.full(n, -1, dtype=np.int64)
-            loc[order] = base[kind[order], off[order]] + ordinal
-            loc[border] = np.arange(border.size)
-            counts = np.bincount(blk[ids], minlength=S)
-            nb = _ceil4(size.sum())
-            # the coupling K[block k, block k-1]: J entries whose row sits one block after the variable, and the transposes
-            # of those whose variable sits one block after the row
-            kr, kc = blk[self.nvar + jrn], blk[jcn]
-            low = (kr >= 0) & (kc >= 0) & (kr == kc + 1)
-            up = (kr >= 0) & (kc >= 0) & (kc == kr + 1)
-            rows = np.unique(np.concatenate([loc[self.nvar + jrn[low]], loc[jcn[up]]]))
-            cols = np.unique(np.concatenate([loc[jcn[low]], loc[self.nvar + jrn[up]]]))
-            return blk, loc, counts, nb, rows, cols, S
+        def build(use_lanes: bool):
+            if use_lanes:
+                laned = (vlane[jcn] >= 0) & (vc[jcn] >= 0)
+                rl = np.full(self.ncon, -1, dtype=np.int64)
+                rhi = np.full(self.ncon, -1, dtype=np.int64)
+                rlo = np.full(self.ncon, np.iinfo(np.int64).max, dtype=np.int64)
+                np.maximum.at(rl, jrn[laned], vlane[jcn[laned]])
+                rmin = np.full(self.ncon, np.iinfo(np.int64).max, dtype=np.int64)
+                np.minimum.at(rmin, jrn[laned], vlane[jcn[laned]])
+                if ((rl >= 0) & (rmin != rl)).any():
+                    raise _lib.IemError("chain KKT: a constraint row couples two lanes of the support grid")
+                np.maximum.at(rhi, jrn[laned], vc[jcn[laned]])
+                np.minimum.at(rlo, jrn[laned], vc[jcn[laned]])
+                vch = np.where((vlane >= 0) & (vc >= 0), vc, -1)
+                chain = np.concatenate([vch, np.where(rl >= 0, rhi, -1)])
+                lane = np.concatenate([np.where(vch >= 0, vlane, 0), np.where(rl >= 0, rl, 0)])
+                lanes = nlanes
+                span = np.where(rhi >= 0, rhi - np.where(rlo == np.iinfo(np.int64).max, rhi, rlo), 0)
+            else:
+                chain = np.concatenate([vc, hi])            # variables, then rows (a row sits with the LAST support it touches)
+                lane = np.zeros(n, dtype=np.int64)
+                lanes = 1
+                span = hi - lo
+            reach = int(span.max()) if self.ncon else 0
+            R = max(reach, 1)                       # supports per block: a row then spans at most two consecutive blocks
+            on = chain >= 0
+            ids = np.nonzero(on)[0]
+            border = np.nonzero(~on)[0]                 # border: variables first, then rows (already in that order)
 
-        best = None
-        for phase in range(R):                      # where the blocks start decides how WIDE the coupling is (collocation: blocks that
-            cand = arrange(phase)                   # end on an element boundary couple through the boundary node only)
-            key = (max(cand[4].size, cand[5].size), cand[3], phase)
-            if best is None or key < best[0]:
-                best = (key, cand)
-        blk, loc, counts, nb, rows, cols, self.S = best[1]
-        self.phase = best[0][2]
-        if self.S < 1:
-            raise _lib.IemError("chain KKT: no unknown lies on the chain")
-        self.blk, self.loc, self.counts = blk, loc, counts
-        self.n_border = int(border.size)
-        self.nb, self.ne = nb, _ceil4(border.size)
-        if self.nb > max_nb or self.ne > max_ne or not fits_lds(self.nb, self.ne):
-            raise _lib.IemError(f"chain KKT: blocks of {int(counts.max())} unknowns / a border of {border.size} exceed the dense-block solver's "
-                                f"limits ({max_nb} / {max_ne}, the tiles of a block in LDS); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
+            def arrange(phase):
+                """Blocks of R supports starting at support -phase: (blk, loc, counts, nb, coupling rows, coupling columns).
+                Inside a block the unknowns sit in FIXED places — variables before rows, each kind by the support's position in
+                the block, then by index, every (kind, position) group at the same base in every block — so that a block with
+                fewer unknowns (the first support has no difference row, the last block may be short) leaves holes instead of
+                shifting the others: the coupling then lives on the same few local rows / columns in every block."""
+                tb = np.where(on, (chain + phase) // R, -1)
+                Sb = int(tb.max()) + 1 if on.any() else 0
+                blk = np.where(on, lane * Sb + tb, -1)
+                off = np.where(on, (chain + phase) % R, 0)
+                S = lanes * Sb
+                gk = (blk[ids] * 2 + kind[ids]) * R + off[ids]       # (block, kind, position in the block); ids ascend: a stable sort keeps index order
+                perm = np.argsort(gk, kind="stable")
+                order, g = ids[perm], gk[perm]
+                first = np.concatenate([[True], g[1:] != g[:-1]]) if order.size else np.zeros(0, bool)
+                pos = np.arange(order.size)
+                ordinal = pos - np.maximum.accumulate(np.where(first, pos, 0))
+                size = np.bincount(g, minlength=S * 2 * R).reshape(S, 2, R).max(axis=0) if S else np.zeros((2, R), dtype=np.int64)   # largest (kind, position) group over the blocks
+                base = np.zeros((2, R), dtype=np.int64)
+                base[0] = np.concatenate([[0], np.cumsum(size[0])[:-1]])
+                base[1] = size[0].sum() + np.concatenate([[0], np.cumsum(size[1])[:-1]])
+                loc = np.full(n, -1, dtype=np.int64)
+                loc[order] = base[kind[order], off[order]] + ordinal
+                loc[border] = np.arange(border.size)
+                counts = np.bincount(blk[ids], minlength=S)
+                nb = _ceil4(size.sum())
+                # the coupling K[block k, block k-1]: J entries whose row sits one block after the variable, and the transposes
+                # of those whose variable sits one block after the row
+                kr, kc = blk[self.nvar + jrn], blk[jcn]
+                low = (kr >= 0) & (kc >= 0) & (kr == kc + 1)
+                up = (kr >= 0) & (kc >= 0) & (kc == kr + 1)
+                rows = np.unique(np.concatenate([loc[self.nvar + jrn[low]], loc[jcn[up]]]))
+                cols = np.unique(np.concatenate([loc[jcn[low]], loc[self.nvar + jrn[up]]]))
+                return blk, loc, counts, nb, rows, cols, S
+
+            best = None
+            for phase in range(R):                      # where the blocks start decides how WIDE the coupling is (collocation: blocks that
+                cand = arrange(phase)                   # end on an element boundary couple through the boundary node only)
+                key = (max(cand[4].size, cand[5].size), cand[3], phase)
+                if best is None or key < best[0]:
+                    best = (key, cand)
+            blk, loc, counts, nb, rows, cols, S = best[1]
+            if S < 1:
+                raise _lib.IemError("chain KKT: no unknown lies on the chain")
+            ne = _ceil4(border.size)
+            if nb > max_nb or ne > max_ne or not fits_lds(nb, ne):
+                raise _lib.IemError(f"chain KKT: blocks of {int(counts.max())} unknowns / a border of {border.size} exceed the dense-block solver's "
+                                    f"limits ({max_nb} / {max_ne}, the tiles of a block in LDS); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
+            return dict(reach=reach, R=R, blk=blk, loc=loc, counts=counts, nb=nb, ne=ne, rows=rows, cols=cols, S=S, phase=best[0][2],
+                        n_border=int(border.size), lanes=lanes)
+
+        try:                                        # the plain chain first (every model it fits keeps its layout)
+            c = build(False)
+        except _lib.IemError as plain:
+            if nlanes <= 1 or not consistent:
+                raise
+            try:
+                c = build(True)
+            except _lib.IemError as laned:
+                raise _lib.IemError(f"{plain}; one chain per lane of the support grid ({nlanes} lanes): {laned}") from None
+        self.reach, self.supports_per_block, self.lanes = c["reach"], c["R"], c["lanes"]
+        self.blk, self.loc, self.counts, self.S, self.phase = c["blk"], c["loc"], c["counts"], c["S"], c["phase"]
+        self.n_border, self.nb, self.ne = c["n_border"], c["nb"], c["ne"]
+        rows, cols = c["rows"], c["cols"]
         # The coupling is NARROW: entries on a few local rows R of block k (the derivative-approximation rows of its first
         # support) and a few local columns C of block k-1 (the differentiated states) — from the Jacobian's structure here;
         # set_coupling() widens it if the caller's K holds more (a Hessian entry across two supports).

@@ -13,7 +13,7 @@ import chain_reference as ref
 from pyoracle import OracleModel
 from test_kkt import host_kkt
 
-MODELS = ["quadrotor_100", "quadrotor_5", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "hovercraft_oc4", "kinetic_20", "test_problem_1"]
+MODELS = ["quadrotor_100", "quadrotor_5", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "hovercraft_oc4", "kinetic_20", "test_problem_1", "pandemic_100x7"]
 
 
 @pytest.mark.parametrize("name", MODELS)
@@ -86,15 +86,19 @@ def test_host_analysis_agrees_on_every_small_case(built):
 
 def test_analysis_refuses_what_the_solver_cannot_hold(built):
     from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
-    big = transcribe.exa_core(workloads.pandemic(10, 40)).to_blob()     # 40 scenarios x 17 unknowns per time support
-    with pytest.raises(iemlib.IemError, match="exceed the dense-block solver's limits"):
+    big = transcribe.exa_core(workloads.pandemic(290, 40)).to_blob()     # 40 scenarios x 17 unknowns per time support; as lanes: a border of 300
+    with pytest.raises(iemlib.IemError, match="exceed the dense-block solver's limits.*one chain per lane"):
         iemlib.kkt_analyse_blob(big)
+    # ... while the same model on the reference's ladder grid (ESCAPE34/run_cases_gpu.jl:99-102: 100 + 10 supports) runs as lanes
+    info = iemlib.kkt_analyse_blob(transcribe.exa_core(workloads.pandemic(100, 40)).to_blob())[0]
+    assert (info["S"], info["nb"], info["ne"], info["n_border"], info["nc"]) == (40 * 110, 20, 112, 110, 4)
     with pytest.raises(iemlib.IemError, match="no infinite-parameter slab table"):   # a hand-built core: nothing to chain along
         iemlib.kkt_analyse_blob(cases.build_core("wide_rows").to_blob())
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["quadrotor_100", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "kinetic_20", "quadrotor_1000", "opf_600", "farmer_1000"])
+@pytest.mark.parametrize("name", ["quadrotor_100", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "kinetic_20", "quadrotor_1000", "opf_600", "farmer_1000",
+                                  "pandemic_100x7"])
 def test_assemble_factor_solve_through_the_c_abi(name, built):
     import torch
     from infiniteexamodels.jl_amd import lib as iemlib

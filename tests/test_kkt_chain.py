@@ -12,7 +12,7 @@ import chain_reference as ref
 from pyoracle import OracleModel
 from test_kkt import host_kkt
 
-MODELS = ["quadrotor_100", "quadrotor_5", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "test_problem_1", "kinetic_20", "irregular"]
+MODELS = ["quadrotor_100", "quadrotor_5", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "test_problem_1", "kinetic_20", "irregular", "pandemic_100x7"]
 
 
 def _system(name, seed=5):
@@ -76,9 +76,14 @@ def test_layout_picks_the_stencil_axis_and_refuses_oversized_blocks(built):
     of = OracleModel(f.to_blob())
     Lf = ChainLayout(f.slabs, of.nvar, of.ncon, *of.jac_structure())
     assert Lf.reach == 0 and Lf.S == 5 and Lf.n_border == 4   # x[1:3] and the row sum(x) <= 500
-    big = transcribe.exa_core(workloads.pandemic(10, 40))     # 40 scenarios x 17 unknowns per time support: too wide for dense blocks
+    wide = transcribe.exa_core(workloads.pandemic(10, 40))    # 40 scenarios x 17 unknowns per time support: too wide for dense blocks —
+    ow = OracleModel(wide.to_blob())                          # one chain per scenario (LANES), u(t) in the border
+    Lw = ChainLayout(wide.slabs, ow.nvar, ow.ncon, *ow.jac_structure())
+    assert (Lw.lanes, Lw.S, Lw.nb, Lw.n_border, Lw.nc, Lw.reach) == (40, 40 * 20, 20, 20, 4, 1)
+    assert (Lw.blk[Lw.blk >= 0] // 20).max() == 39 and set(np.nonzero(Lw.blk[:ow.nvar] < 0)[0]) == set(range(4 * 20 * 40, 4 * 20 * 40 + 20))   # the border IS the slab of u(t)
+    big = transcribe.exa_core(workloads.pandemic(290, 40))    # ... and a border of 300 time supports is too large for that too
     ob = OracleModel(big.to_blob())
-    with pytest.raises(iemlib.IemError, match="exceed the dense-block solver's limits"):
+    with pytest.raises(iemlib.IemError, match="exceed the dense-block solver's limits.*one chain per lane"):
         ChainLayout(big.slabs, ob.nvar, ob.ncon, *ob.jac_structure())
 
 

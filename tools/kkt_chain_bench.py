@@ -16,11 +16,14 @@ ap.add_argument("--workload", default="quadrotor")
 ap.add_argument("--supports", type=int, default=100_000)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--cabi", type=int, default=1, help="also time the iem_kkt_* object")
+ap.add_argument("--nxi", type=int, default=8, help="--workload pandemic: scenarios (the time axis has --supports + 10 supports)")
 args = ap.parse_args()
 mk = {"quadrotor": lambda: workloads.quadrotor(args.supports), "quadrotor_oc3": lambda: workloads.quadrotor(args.supports, collocation=3),
       "farmer": lambda: workloads.farmer(args.supports), "opf": lambda: workloads.opf(args.supports), "hovercraft": lambda: workloads.hovercraft(args.supports),
       "kinetic": lambda: workloads.kinetic_control(args.supports), "pandemic3": lambda: workloads.pandemic(args.supports, 3),
-      "pandemic5": lambda: workloads.pandemic(args.supports, 5)}[args.workload]
+      "pandemic5": lambda: workloads.pandemic(args.supports, 5),
+      # a 2-D grid as one chain per scenario, u(t) in the border (kkt_chain: lanes) — the reference's ladder, ESCAPE34/run_cases_gpu.jl:99-102
+      "pandemic": lambda: workloads.pandemic(args.supports, args.nxi)}[args.workload]
 t0 = time.perf_counter()
 core = transcribe.exa_core(mk())
 gm = ExaModel(core, device=0)
@@ -31,7 +34,7 @@ t2 = time.perf_counter()
 L = ck.layout
 n = gm.meta.nvar + gm.meta.ncon
 rng = np.random.default_rng(0)
-x = torch.tensor(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar) if args.workload not in ("farmer", "pandemic3", "pandemic5") else np.abs(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)) + 0.05, device="cuda")
+x = torch.tensor(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar) if args.workload not in ("farmer", "pandemic3", "pandemic5", "pandemic") else np.abs(gm.meta.x0 + 0.1 * rng.standard_normal(gm.meta.nvar)) + 0.05, device="cuda")
 y = torch.tensor(0.1 * np.random.default_rng(1).standard_normal(gm.meta.ncon), device="cuda")
 sigma = torch.tensor(0.5 + rng.random(gm.meta.nvar), device="cuda")
 rhs = torch.tensor(rng.standard_normal(n), device="cuda")
@@ -79,7 +82,7 @@ if args.cabi:
     cabi["abs_residual_without_refinement"] = float((ck._matvec(out) - rhs).abs().max().item())
     iemlib.check(gm._L.iem_kkt_destroy(k))
 flops = L.S * (2.0 * L.nb ** 3 * (1 + 2 + 3) + 2.0 * L.nb * L.nb * L.ne * 4)      # inverse + X, Y + three update products (+ border terms)
-print(json.dumps({"workload": args.workload, "supports": args.supports, "n": n, "nnz_K": kkt.nnz, "chain": {"S": L.S, "nb": L.nb, "ne": L.ne, "nc": L.nc, "reach": L.reach, "group": L.group, "phase": L.phase},
+print(json.dumps({"workload": args.workload, "supports": args.supports, "n": n, "nnz_K": kkt.nnz, "chain": {"S": L.S, "nb": L.nb, "ne": L.ne, "nc": L.nc, "reach": L.reach, "group": L.group, "phase": L.phase, "lanes": getattr(L, "lanes", 1)},
                   "setup_s": {"model_and_csr_plan": t1 - t0, "chain_layout_and_plan": t2 - t1}, "ms": ms,
                   "factor_GFLOP_dense": flops / 1e9, "factor_TFLOPs": flops / (ms["factor"] * 1e-3) / 1e12,
                   "block_bytes": int(ck.flat.numel() * 8 + (ck.BR.numel() + ck.Z.numel()) * 8),
