@@ -118,6 +118,42 @@ def cpu_baseline(sample_supports: int, seconds: float = 12.0):
     }
 
 
+def live_traffic(args):
+    """HBM bytes per launch of the jac / hess / pair kernels from the PMC counters, collected NOW on this box: two rocprofv3
+    `--pmc` passes (FETCH_SIZE, WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE tallies 128-byte
+    requests at 64 B on gfx950 -> x 2; both in KiB) of a child process that builds the same model and launches each kernel a
+    few times.  Run BEFORE this process touches the GPU; any failure yields None (the line then falls back to the committed
+    profile).  Returns ({kernel name: bytes per launch}, note)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="iem_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--supports", str(args.supports), "--store-mode", str(args.store_mode), "--nt", str(args.nt), "--fma", str(args.fma), "--hess-layout", args.hess_layout] + \
+              [a for kv in args.opt for a in ("--opt", kv)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", IEM_PMC_CHILD="1"), capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout).strip().splitlines()[-1][:200] if (r.stderr or r.stdout).strip() else ''}"
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Kernel_Name"].startswith("iem_") and row["Counter_Name"] == counter:
+                        acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not acc:
+                return None, f"no {counter} rows in the rocprofv3 output"
+            for k, v in acc.items():
+                out.setdefault(k, {})[counter] = sum(v) / len(v)
+        except Exception as e:      # noqa: BLE001 — the bench line must not depend on the profiler
+            return None, f"{counter} pass: {e}"[:300]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    res = {k: (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 for k, c in out.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+    return res, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of a child of THIS run: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, mean over its launches"
+
+
 def choose_comm_path(children_ok: bool, wired: bool, warmup_status: int = 0, rccl_ok: bool = True):
     """Which exchange the N > 1 TIMED step contains — never silently none:
       'own'   the library's mailbox kernels (iem_halo_exchange_async riding on the step's first launch)
@@ -320,6 +356,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurement of the ESCAPE34 (collocation) variant of the model")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not collect roofline.traffic with rocprofv3 --pmc child passes (then: the committed profile, flagged static)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: build the model, launch jac / hess / pair a few times, exit
     ap.add_argument("--rehearse-comm", default="", help=argparse.SUPPRESS)   # with --rehearse-launch: simulate one branch of choose_comm_path
     ap.add_argument("--force-rccl", action="store_true", help="N > 1: take the torch.distributed fallback of the halo exchange even when the mailboxes work")
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -329,12 +367,35 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    live, live_note = None, None
+    if (args.gpus == 1 and "RANK" not in os.environ and not args.no_live_traffic and not args.pmc_child and not args.emulate_shard and not args.rehearse_launch
+            and not os.environ.get("IEM_PMC_CHILD") and not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+            and "rocprof" not in os.environ.get("LD_PRELOAD", "")):
+        live, live_note = live_traffic(args)     # before this process touches the GPU: one process on the card at a time
+
     import torch
     import torch.distributed as dist
     from infiniteexamodels.jl_amd import lib as iemlib
     from infiniteexamodels.jl_amd import shard, transcribe, workloads
     from infiniteexamodels.jl_amd.model import ExaModel
 
+    if args.pmc_child:
+        # what rocprofv3 --pmc profiles for `roofline.traffic`: the same model, each kernel launched a few times
+        torch.cuda.set_device(0)
+        hopts = {"store_mode": args.store_mode, "nt_stores": args.nt, "fp_contract": args.fma}
+        for kv in args.opt:
+            k, v = kv.split("=")
+            hopts[k] = int(v)
+        core = transcribe.exa_core(workloads.quadrotor(args.supports))
+        gm = ExaModel(core, device=0, hess_layout=args.hess_layout, options=hopts)
+        x, y = eval_point(gm.meta.nvar, gm.meta.ncon, gm.meta.x0, gm.meta.nvar // 22)
+        xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+        jac = torch.empty(gm.meta.nnzj, dtype=torch.float64, device="cuda")
+        hess = torch.empty(gm.meta.nnzh, dtype=torch.float64, device="cuda")
+        for _ in range(4):
+            gm.jac_coord(xd, jac); gm.hess_coord(xd, yd, hess, obj_weight=1.0); gm.jac_hess_coord(xd, yd, jac, hess, obj_weight=1.0)
+        torch.cuda.synchronize()
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -663,9 +724,11 @@ def main():
         # passes of their own): read from the committed profile of the same command and size (tools/profile_gpu.sh →
         # profiles/), which records the fingerprint of the csrc tree it was taken from — `traffic_stale` says whether
         # that is THIS tree.
-        traffic, traffic_src, stale = None, None, None
+        traffic, traffic_src, stale, traffic_static = None, None, None, True
         prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
-        if os.path.exists(prof) and S_local == 1_000_000 and world == 1:
+        if live and kd["name"] in live:
+            traffic, traffic_src, stale, traffic_static = live[kd["name"]], live_note, False, False
+        elif os.path.exists(prof) and S_local == 1_000_000 and world == 1:
             try:
                 pj = json.load(open(prof))
                 traffic = pj["pmc"][kd["name"]]["hbm_bytes_per_launch"]
@@ -679,7 +742,8 @@ def main():
                    (" behind iem_halo_exchange_async(x)" if halo_state["path"] == "own" else
                     " behind a torch.distributed send/recv of the halo doubles (shard.ShardComm fallback)" if halo_state["path"] == "rccl" else "")
         roof = {"bound": "hbm", "kernel": kd["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": True,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_static": traffic_static,
+                "traffic_all_kernels": live, "traffic_note": None if live else live_note,
                 "traffic_stale": stale, "traffic_source": traffic_src, "csrc_fingerprint": csrc_fingerprint(),
                 "alg_bytes": alg, "kernel_ms": ms_dom, "kernel_ms_from": "100 back-to-back launches between one pair of HIP events on the launch stream",
                 "jac_ms": ms_jac, "hess_ms": ms_hess,

@@ -79,6 +79,15 @@ int main(int argc, char **argv) {
   IEM(iem_synchronize(m));
   printf("obj2 1 %.17g %.17g\n", f2, f2 * f2);
   if (report("jac2", jv2, meta.nnzj) || report("hess2", hv2, meta.nnzh)) return 1;
+  /* one launch per solver phase: obj + cons! at a trial point (iem_eval_trial), grad! + jac_coord! + hess_coord! at the
+   * accepted point (iem_eval_accepted) — identical results again */
+  double *c3, *g3, f3 = 0.0;
+  HIP(hipMalloc((void **)&c3, (size_t)meta.ncon * 8 + 8)); HIP(hipMalloc((void **)&g3, (size_t)meta.nvar * 8 + 8));
+  IEM(iem_eval_trial(m, x, c3, &f3));
+  IEM(iem_eval_accepted(m, x, y, 1.0, g3, jv2, hv2));
+  IEM(iem_synchronize(m));
+  printf("obj3 1 %.17g %.17g\n", f3, f3 * f3);
+  if (report("cons3", c3, meta.ncon) || report("grad3", g3, meta.nvar) || report("jac3", jv2, meta.nnzj) || report("hess3", hv2, meta.nnzh)) return 1;
   /* the linear solve of a solver iteration (where the reference plugs CUDSS, README.md:36-37): the KKT matrix of this
    * point, K = [H + 0.01 I, J'; J, -1e-6 I], assembled from the two value buffers above, factorised, and K s = (grad; cons)
    * solved — skipped (printed as such) when the model's blocks are beyond the chain solver */

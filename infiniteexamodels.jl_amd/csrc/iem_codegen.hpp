@@ -55,7 +55,7 @@ struct Options {
   int ablate = 0;      // timing experiments only (WRONG results): 1 no LDS transpose, 2 no transcendentals
   int min_waves = 0;   // >0: __launch_bounds__(256, min_waves) on the fused kernels
   int nt_stores = 1;   // 1: non-temporal stores for the streamed COO outputs
-  int wide_stores = 0; // 1: 16 bytes per lane in the block store
+  int wide_stores = 1; // 1: 16 bytes per lane in the block store (in-process A/B r04: jac_coord! -0.5 .. -1 %, hess_coord! -0.3 %; profiles/r04_ab_jac_split.txt)
   int overlap = 1;     // 1: block-store kernels overlap their tiles by 16 lanes so that every 128-byte line is written whole
   int xcd_remap = 0;   // 1: consecutive logical workgroups share an XCD (experiment: partial lines at block seams did NOT merge in its L2; -1.5 %)
   int split_small = 64; // support grids of at most this many workgroups run their templates side by side (0: never)

@@ -100,6 +100,29 @@ function jac_hess_coord!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Flo
                 m.handle, dptr(x), dptr(y), obj_weight, dptr(jac), dptr(hess)))
     return jac, hess
 end
+# One launch per SOLVER PHASE (include/iem.h: iem_eval_trial / iem_eval_accepted / iem_eval_all; identical bytes to the separate
+# calls): obj + cons! at a trial point of the line search, grad! + jac_coord! + hess_coord! at the accepted point
+# (ext/InfiniteExaModelsMadNLP.jl:49-50,64).  `eval_trial!` returns f; with `defer = true` it returns at once and `obj_end`
+# collects the value (a MadNLP callback that needs c first can overlap the scalar's round trip).
+function eval_trial!(m::MI355XModel, x::ROCVector{Float64}, c::ROCVector{Float64}; defer = false)
+    out = Ref{Float64}()
+    check(ccall((:iem_eval_trial, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                m.handle, dptr(x), dptr(c), defer ? C_NULL : out))
+    return defer ? nothing : out[]
+end
+function eval_accepted!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Float64}, g::ROCVector{Float64}, jac::ROCVector{Float64},
+                        hess::ROCVector{Float64}; obj_weight = 1.0)
+    check(ccall((:iem_eval_accepted, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                m.handle, dptr(x), dptr(y), obj_weight, dptr(g), dptr(jac), dptr(hess)))
+    return g, jac, hess
+end
+function eval_all!(m::MI355XModel, x::ROCVector{Float64}, y::ROCVector{Float64}, c::ROCVector{Float64}, g::ROCVector{Float64},
+                   jac::ROCVector{Float64}, hess::ROCVector{Float64}; obj_weight = 1.0)
+    out = Ref{Float64}()
+    check(ccall((:iem_eval_all, LIBIEM), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                m.handle, dptr(x), dptr(y), obj_weight, dptr(c), dptr(g), dptr(jac), dptr(hess), out))
+    return out[]
+end
 # obj in two halves: obj_begin! first, obj_end after the last launch of the evaluation point — the scalar's host round trip
 # overlaps grad!, cons!, jac_coord!, hess_coord! (ext/InfiniteExaModelsIpopt.jl:48-49 evaluates all five at one point)
 obj_begin!(m::MI355XModel, x::ROCVector{Float64}) =

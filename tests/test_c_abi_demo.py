@@ -51,6 +51,8 @@ def test_c_demo_matches_oracle(name, built, tmp_path):
     assert [int(v) for v in got["jac_structure"]] == [om.nnzj, int(jr.sum()), int(jc.sum())]
     # the deferred objective and the one-launch jac + hess pair give the very same numbers as the five plain calls
     assert got["obj2"] == got["obj"] and got["jac2"] == got["jac"] and got["hess2"] == got["hess"]
+    # ... and so does one launch per solver phase (iem_eval_trial, iem_eval_accepted)
+    assert got["obj3"] == got["obj"] and all(got[k + "3"] == got[k] for k in ("cons", "grad", "jac", "hess"))
     # the KKT solve from C (iem_kkt_*): K = [H + 0.01 I, J'; J, -1e-6 I] at this point, right-hand side (grad; cons)
     import scipy.sparse as sp
     from scipy.sparse.linalg import spsolve

@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-variants > $OUT/stats_bench.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-variants --no-live-traffic > $OUT/stats_bench.log 2>&1 || exit 1
 pass() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-live-traffic > $OUT/pmc_$name.log 2>&1
 }
 pass fetch FETCH_SIZE || exit 1
 pass write WRITE_SIZE || exit 1

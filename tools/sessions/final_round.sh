@@ -11,7 +11,7 @@ echo "profile ok"
 # write-queue credit stalls of jac_coord! in both shapes (split bodies, the default; one body): separate --pmc passes of the same command
 ( cd /tmp && export TMPDIR=/tmp
   for shape in 1 0; do
-    rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum --output-format csv -d $O/pmc_credit_split$shape -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-cold --opt jac_split=$shape > $O/pmc_credit_split$shape.log 2>&1 || echo "credit pass $shape failed"
+    rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum --output-format csv -d $O/pmc_credit_split$shape -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-cold --no-live-traffic --opt jac_split=$shape > $O/pmc_credit_split$shape.log 2>&1 || echo "credit pass $shape failed"
   done ) 
 python3 - $O <<'PY' > $O/credit_stalls.txt 2>&1
 import csv, glob, collections, sys, os
@@ -26,10 +26,10 @@ for shape in (1, 0):
 PY
 cat $O/credit_stalls.txt
 cp $R/gpurun_out/prof/summary.json $R/profiles/pmc_quadrotor_1e6.json    # (the box's copy of the tree: the bench lines below cite THIS profile; tools/collect_final.sh makes the same copy at home)
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard_stats -- python3 $R/bench.py --emulate-shard 3/8 --steps 200 --warmup 20 --no-cpu-baseline --no-cold > $O/shard_bench.json 2> $O/shard_bench.err ) || exit 1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/shard_stats -- python3 $R/bench.py --emulate-shard 3/8 --steps 200 --warmup 20 --no-cpu-baseline --no-cold --no-live-traffic > $O/shard_bench.json 2> $O/shard_bench.err ) || exit 1
 echo "shard stats ok"
 for i in 1 2 3 4 5 6 7 8 9 10; do
-  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-cold --no-variants > $O/run_$i.json 2> $O/run_$i.err || exit 1
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-cold --no-variants --no-live-traffic > $O/run_$i.json 2> $O/run_$i.err || exit 1
   python3 - $O/run_$i.json $i <<'PY' >> $O/bench_runs.txt
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j["roofline"]
