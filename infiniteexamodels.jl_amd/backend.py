@@ -6,7 +6,7 @@ Mirrored: the ``backend`` slot that selects the device evaluator (``:100``, forw
 (``:259-271``), the object / support mappings (``:274-350``), result queries (``:352-508``: statuses, objective,
 ``map_value``, ``map_dual``), the parameter / start-value update hooks (``:511-592``) and warm starts (``:595-615``).
 A solver is any callable ``solver(model, x0, y0, **options) -> result`` with ``result.solution`` / ``result.multipliers``
-(torch or numpy vectors; ``results.py`` lists the optional fields); one that keeps state between solves may offer
+(torch or numpy vectors; ``contrib/results.py`` lists the optional fields); one that keeps state between solves may offer
 ``resolve(model, x0, y0, **changed_options)`` and is then handed only the options that changed, as the reference's
 extensions do (``ext/InfiniteExaModelsIpopt.jl:10-60``).
 """

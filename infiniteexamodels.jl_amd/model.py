@@ -108,7 +108,7 @@ class ExaModel:
 
     # ---- lifecycle -----------------------------------------------------------
     def close(self):
-        cached = self.__dict__.pop("_newton_linear", None)     # what a solver keeps on the model between solves (newton.py)
+        cached = self.__dict__.pop("_newton_linear", None)     # what a solver keeps on the model between solves (contrib/newton.py)
         if cached is not None:
             cached[0].close()
         if getattr(self, "_h", None):

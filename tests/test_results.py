@@ -1,4 +1,4 @@
-"""The result side of the plug point (``backend.py`` / ``results.py``): what the reference's tests read back after
+"""The result side of the plug point (``backend.py`` / ``contrib/results.py``): what the reference's tests read back after
 ``optimize!`` — ``objective_value``, ``value(...)``, ``dual(...)``, statuses, supports — and the option diffing of a
 re-solve.  CPU only: the "solver" is SciPy's SLSQP on the oracle's evaluator (a stand-in for IpoptSolver of
 /root/reference/test/solve.jl), so the backend is built without a device (``backend = None``)."""
