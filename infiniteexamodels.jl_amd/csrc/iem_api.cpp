@@ -1067,7 +1067,15 @@ static int create_impl(const void *blob, size_t nbytes, int device, const iem_op
       m->reads_halo_x[kd.kind] = m->reads_halo_x[kd.kind] || hits(kd.x_ranges);
       m->reads_halo_v[kd.kind] = m->reads_halo_v[kd.kind] || hits(kd.v_ranges);
     }
-    for (int k : {(int)iem::KK_CONS, (int)iem::KK_JAC, (int)iem::KK_HESS, (int)iem::KK_JPROD, (int)iem::KK_OBJ, (int)iem::KK_PAIR, (int)iem::KK_TRIAL, (int)iem::KK_ACCEPTED, (int)iem::KK_ALL}) m->carrier[k] = true;
+    // a kind can carry a deferred exchange when EVERY kernel of it has the carrier prologue (a phase kernel whose grad! member
+    // reduces shared entries has none: one extra workgroup there would shift every tile)
+    bool any[iem::KK_LAST + 1] = {}, all[iem::KK_LAST + 1];
+    for (bool &a : all) a = true;
+    for (const iem::KernelDesc &kd : m->prog.kernels) {
+      if (kd.kind < 0 || kd.kind > iem::KK_LAST) continue;
+      any[kd.kind] = true; all[kd.kind] = all[kd.kind] && kd.carries;
+    }
+    for (int k = 0; k <= iem::KK_LAST; ++k) m->carrier[k] = any[k] && all[k];
   }
   if ((rc = prepare_program(m, m->prog, m->d_tables, m->argbuf)) != IEM_OK) return bail(rc);
   // second code object for the tuner: only for block-store models with a large jac/hess grid (below ~2e5 supports

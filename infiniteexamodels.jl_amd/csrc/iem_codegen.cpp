@@ -1829,6 +1829,7 @@ class KernelBuilder {
     os << "  double* __restrict__ OUT = A.out; double* __restrict__ AUX = A.aux; (void)AUX;\n";
     os << "  const double* const* FA = A.fa; const long long* const* IA = A.ia;\n";
     os << "  (void)X; (void)TH; (void)Y; (void)FA; (void)IA;\n";
+    kd.carries = carrier();
     if (carrier()) {
       // a pending asynchronous halo exchange rides on this launch: one EXTRA leading workgroup (column 0 of the grid;
       // one per row on 2-D / 3-D grids, only the first works) runs it while the others evaluate — they see workgroup
@@ -3002,6 +3003,7 @@ Program generate(const Model &m, const Options &opt_in) {
     else src << "  double* lds4 = nullptr;\n";
     if (is_obj) {
       // (a pending halo exchange rides on this launch as one extra leading workgroup; the walkers are the others)
+      F.carries = opt.carrier != 0;
       if (opt.carrier)
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
@@ -3013,7 +3015,8 @@ Program generate(const Model &m, const Options &opt_in) {
       P.kernels.push_back(F);
       continue;
     }
-    if (opt.carrier && !E.si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD))
+    F.carries = opt.carrier && !E.si && (kind == KK_CONS || kind == KK_JAC || kind == KK_HESS || kind == KK_JPROD);
+    if (F.carries)
       src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
           << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
           << "  const long long b = (long long)blockIdx.x - cb_;\n";
@@ -3097,7 +3100,8 @@ Program generate(const Model &m, const Options &opt_in) {
       else src << "  double* lds_blk = nullptr;\n";
       if (has_obj) src << "  __shared__ double lds4[IEM_TILE / 64 + 1];\n";
       else src << "  double* lds4 = nullptr;\n";
-      if (opt.carrier && !has_si)
+      F.carries = opt.carrier && !has_si;
+      if (F.carries)
         src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
             << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"
             << "  const long long pb_ = (long long)blockIdx.x - cb_;\n";
@@ -3207,6 +3211,7 @@ Program generate(const Model &m, const Options &opt_in) {
         if (F.lds_bytes > 0) src << "  __shared__ double lds_blk[" << (F.lds_bytes / 8) << "];\n";
         else src << "  double* lds_blk = nullptr;\n";
         src << "  double* lds4 = nullptr;\n";
+        F.carries = opt.carrier != 0;
         if (opt.carrier)
         src << "  const long long cb_ = A.comm != nullptr ? 1 : 0;   // a pending halo exchange rides on this launch: one extra leading workgroup\n"
             << "  if (cb_ && blockIdx.x == 0) { iem_halo_wg(*A.comm, const_cast<double*>(A.x)); return; }\n"

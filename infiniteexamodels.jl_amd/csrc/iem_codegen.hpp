@@ -41,6 +41,7 @@ struct KernelDesc {
   // calls must wait for an asynchronous halo exchange (iem_halo_exchange_async) and which may overlap it
   std::vector<std::pair<int64_t, int64_t>> x_ranges, v_ranges;
   int lds_slots = 0;        // the staging batch this kernel was generated with (Options::lds_slots or its large-grid override)
+  bool carries = false;     // the kernel has the halo-carrier prologue (Options::carrier): a launch may bring one extra leading workgroup
   int inter = -1;           // >= 0: bodies of one launch with the same value (and the same grid) have their workgroups interleaved
 };
 

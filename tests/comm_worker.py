@@ -74,9 +74,18 @@ def main():
         assert reads["cons"][0] and not reads["jac"][0] and not reads["hess"][0] and not reads["obj"][0], reads
         assert reads["obj"][2] and reads["jac"][2] and reads["pair"][2] and not reads["cons"][2] and not reads["grad"][2], reads   # who can carry
 
+    phase_it = [False]
+
     def loop():
         exchange(xd)
-        if use_async:
+        if use_async and phase_it[0]:
+            # the same evaluations through ONE LAUNCH PER SOLVER PHASE: the accepted-point launch (grad! + jac_coord! +
+            # hess_coord!) carries the deferred exchange when it can (no halo entry touched, no shared-entry epilogue), else it
+            # is flushed in front; the trial-point launch (obj + cons!) reads halo entries on ranks > 0
+            gm.eval_accepted(xd, yd, g, jv, hv, obj_weight=0.7)
+            fv, _ = gm.eval_trial(xd, c)
+            f.fill_(fv)
+        elif use_async:
             # solver order: obj carries the deferred exchange (one extra workgroup), grad! neither touches nor carries,
             # the fused pair and cons! find the halo entries in x
             gm.obj_device(xd, f); gm.grad(xd, g); gm.jac_hess_coord(xd, yd, jv, hv, obj_weight=0.7); gm.cons(xd, c)
@@ -125,6 +134,7 @@ def main():
             torch.cuda.synchronize()
             assert np.array_equal(xo.cpu().numpy(), xg[vm]), "iem_allreduce_obj_grad overtook a deferred halo exchange"
             g.fill_(float("nan"))
+        phase_it[0] = use_async and not use_graph and it % 2 == 1
         if use_graph and it >= 2:
             if graph is None:                              # iterations 0, 1 ran eagerly (warm-up); capture once, replay after
                 graph = torch.cuda.CUDAGraph()
