@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 R=${IEM_ROUND:-r04}
 P=gpurun_out/prof; F=gpurun_out/${R}_final
 cp $P/summary.json profiles/pmc_quadrotor_1e6.json
-cp "$(find $P/stats -name '*kernel_stats.csv' | head -1)" profiles/${R}_kernel_stats_bench_1e6.csv
-cp "$(find $F/shard_stats -name '*kernel_stats.csv' | head -1)" profiles/${R}_kernel_stats_shard_3_of_8.csv
+cp "$(ls -t $(find $P/stats -name '*kernel_stats.csv') | head -1)" profiles/${R}_kernel_stats_bench_1e6.csv     # the NEWEST: gpurun_out/ accumulates earlier sessions' files
+cp "$(ls -t $(find $F/shard_stats -name '*kernel_stats.csv') | head -1)" profiles/${R}_kernel_stats_shard_3_of_8.csv
 cp $F/shard_bench.json profiles/${R}_bench_shard_3_of_8_under_rocprof.json
 cp $F/bench_runs.txt profiles/${R}_bench_runs.txt
 cp $F/bench_default.json profiles/${R}_bench_default.json
