@@ -290,6 +290,11 @@ int iem_csr_spmv(iem_model *m, int64_t n, const int32_t *d_rowptr, const int32_t
  * of 4 in 4..48, nc <= nb.  Asynchronous on the handle's stream. */
 int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
                          const int32_t *d_cols, double *d_E, double *d_Z, double *d_Gp, int64_t *d_info, double tiny);
+/* ONE step of that reduction (no border), for a caller that interleaves work of its own between the levels — the span-sparse
+ * border of a laned 2-D grid, kkt_chain.HubChainKKT: what = 0 eliminate the blocks (2t+1)s, 1 fold them into the survivors 2ts,
+ * 2 the last remaining block, 3 clear the pivot counters (d_info). */
+int iem_kkt_chain_level(iem_model *m, int64_t S, int nb, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
+                        const int32_t *d_cols, int64_t *d_info, double tiny, int64_t s, int what);
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
                         const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
                         const double *d_xB, int phase);

@@ -1979,6 +1979,28 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double
   return kkt_launch(m, km->elim, A, 1, wg);
 }
 
+/* ONE step of the same reduction, for a caller that interleaves work of its own between the levels (kkt_chain.HubChainKKT: the
+ * span-sparse border of a laned 2-D grid).  what = 0: eliminate the blocks (2t+1)s (in-place inverses, BR kept), 1: fold them
+ * into the survivors 2ts, 2: the last remaining block (index 0), 3: clear the pivot counters.  No border (ne = 0 module). */
+int iem_kkt_chain_level(iem_model *m, int64_t S, int nb, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows, const int32_t *d_cols,
+                        int64_t *d_info, double tiny, int64_t s, int what) {
+  if (!m || S < 1 || !d_D || !d_Bt || !d_BR || !d_rows || !d_cols || !d_info || s < 1 || what < 0 || what > 3) return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
+  if (what == 3) { HIP_TRY(hipMemsetAsync(d_info, 0, 24, m->stream)); return IEM_OK; }
+  iem_model::KktMod *km = nullptr;
+  int rc = kkt_module(m, nb, 0, nc, &km);
+  if (rc) return rc;
+  int wmax, wpe_;
+  kkt_shape(nb, 0, &wmax, &wpe_);
+  const unsigned wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);
+  KktArgsH A{d_D, d_Bt, d_BR, nullptr, nullptr, nullptr, d_rows, d_cols, (long long *)d_info, (long long)S, (long long)s, 0, tiny};
+  if (what == 2) { A.final_block = 1; A.s = 1; return kkt_launch(m, km->elim, A, 1, wg); }
+  if (s >= S) return IEM_OK;
+  const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
+  if (what == 0) return kkt_launch(m, km->elim, A, n_elim, wg);
+  return kkt_launch(m, km->upd, A, n_surv, nc <= 8 ? 64u : nc <= 16 ? 128u : 256u);
+}
+
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
                         const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
                         const double *d_xB, int phase) {

@@ -53,7 +53,10 @@ class ChainLayout:
     supports a constraint row couples, else the one with the most supports)."""
 
     def __init__(self, slabs, nvar: int, ncon: int, jac_rows, jac_cols, group: Optional[int] = None,
-                 max_nb: int = MAX_NB, max_ne: int = MAX_NE):
+                 max_nb: int = MAX_NB, max_ne: int = MAX_NE, hubs: bool = False):
+        """``hubs``: the layout :class:`HubChainKKT` works on — always one chain per lane, every lane padded to a power of two
+        of time blocks, and NO limit on the border (the chain parameter's own variables, ``u(t)``: handled as span-sparse
+        border columns outside the chain kernels)."""
         import torch
         jr = torch.as_tensor(np.asarray(jac_rows, dtype=np.int64))
         jc = torch.as_tensor(np.asarray(jac_cols, dtype=np.int64))
@@ -152,6 +155,8 @@ class ChainLayout:
                 shifting the others: the coupling then lives on the same few local rows / columns in every block."""
                 tb = np.where(on, (chain + phase) // R, -1)
                 Sb = int(tb.max()) + 1 if on.any() else 0
+                if hubs and Sb > 1:
+                    Sb = 1 << (Sb - 1).bit_length()        # every lane a power of two of blocks: a reduction level never pairs two lanes
                 blk = np.where(on, lane * Sb + tb, -1)
                 off = np.where(on, (chain + phase) % R, 0)
                 S = lanes * Sb
@@ -189,15 +194,29 @@ class ChainLayout:
             if S < 1:
                 raise _lib.IemError("chain KKT: no unknown lies on the chain")
             ne = _ceil4(border.size)
-            if nb > max_nb or ne > max_ne or not fits_lds(nb, ne):
+            if hubs:
+                if nb > max_nb or not fits_lds(nb, 0):
+                    raise _lib.IemError(f"chain KKT: blocks of {int(counts.max())} unknowns exceed the dense-block solver's limit ({max_nb})")
+            elif nb > max_nb or ne > max_ne or not fits_lds(nb, ne):
                 raise _lib.IemError(f"chain KKT: blocks of {int(counts.max())} unknowns / a border of {border.size} exceed the dense-block solver's "
                                     f"limits ({max_nb} / {max_ne}, the tiles of a block in LDS); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
-            return dict(reach=reach, R=R, blk=blk, loc=loc, counts=counts, nb=nb, ne=ne, rows=rows, cols=cols, S=S, phase=best[0][2],
-                        n_border=int(border.size), lanes=lanes)
+            ph = best[0][2]
+            # time block of every unknown that has a chain coordinate at all (hubs: the border's own place on the time axis)
+            allchain = np.concatenate([vc, hi])
+            tblock = np.where(allchain >= 0, (allchain + ph) // R, -1)
+            return dict(reach=reach, R=R, blk=blk, loc=loc, counts=counts, nb=nb, ne=ne, rows=rows, cols=cols, S=S, phase=ph,
+                        n_border=int(border.size), lanes=lanes, tblock=tblock)
 
         try:                                        # the plain chain first (every model it fits keeps its layout)
-            c = build(False)
+            if hubs:
+                if nlanes <= 1 or not consistent:
+                    raise _lib.IemError("chain KKT (hub border): the chain's parameter has no second dimension to cut lanes along")
+                c = build(True)
+            else:
+                c = build(False)
         except _lib.IemError as plain:
+            if hubs:
+                raise
             if nlanes <= 1 or not consistent:
                 raise
             try:
@@ -207,6 +226,7 @@ class ChainLayout:
         self.reach, self.supports_per_block, self.lanes = c["reach"], c["R"], c["lanes"]
         self.blk, self.loc, self.counts, self.S, self.phase = c["blk"], c["loc"], c["counts"], c["S"], c["phase"]
         self.n_border, self.nb, self.ne = c["n_border"], c["nb"], c["ne"]
+        self.tblock = c["tblock"]
         rows, cols = c["rows"], c["cols"]
         # The coupling is NARROW: entries on a few local rows R of block k (the derivative-approximation rows of its first
         # support) and a few local columns C of block k-1 (the differentiated states) — from the Jacobian's structure here;
@@ -217,7 +237,7 @@ class ChainLayout:
         """Local rows (of block k) and columns (of block k-1) the coupling blocks live on; ``nc`` = their padded count."""
         self.rowsR, self.colsC = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
         self.nc = max(_ceil4(max(self.rowsR.size, self.colsC.size)), 4)
-        if self.reach > 0 and (self.nc > MAX_NC or self.nc > self.nb or not fits_lds(self.nb, self.ne, self.nc)):
+        if self.reach > 0 and (self.nc > MAX_NC or self.nc > self.nb or not fits_lds(self.nb, min(self.ne, MAX_NE), self.nc)):
             raise _lib.IemError(f"chain KKT: the coupling between neighbouring blocks spans {self.rowsR.size} rows / {self.colsC.size} columns "
                                 f"(limit {MAX_NC}); use kkt.KKTSystem (rocSOLVER re-factorisation) for this model")
         self._ridx = np.full(self.nb, -1, dtype=np.int64); self._ridx[self.rowsR] = np.arange(self.rowsR.size)
@@ -408,4 +428,330 @@ class ChainKKT:
         out[self._on] = r[self._pos]
         if L.ne:
             out[self._border] = xB[:L.n_border]
+        return out
+
+
+class HubChainKKT:
+    """The chain solver on a 2-D support grid whose border is too large for the dense-border kernels: BASELINE config 3,
+    ``ESCAPE34/pandemic.jl`` at 5 000 x 100 supports — one chain per scenario (lanes), and 5 000 HUBS ``u(t)``, each coupled to
+    the blocks of its own time support in every lane.
+
+    Block elimination with a SPAN-SPARSE border.  Eliminating block ``i`` of the chain (cyclic reduction, level ``s``) adds
+    ``-B D_i^-1 E_i`` to its neighbours' border columns and ``-E_i' D_i^-1 E_i`` to the hubs' Schur complement ``S``.  A block at
+    time ``t`` alive at level ``s`` only ever touches the hubs ``t - (s - 1) .. t + (s - 1)``: ``E`` is kept as ``nb x (2s - 1)``
+    per block (time-major, lanes contiguous), widened level by level; the contributions to ``S`` of the blocks eliminated at one
+    level fall on DISJOINT diagonal blocks of ``S`` and are batched matrix products over ``lanes x nb`` — the dense products the
+    matrix cores are for (rocBLAS through torch: plain library GEMMs).  The chain itself (block inverses on the FP64 matrix
+    cores, narrow couplings) runs through the same kernels as every other model, one level at a time
+    (``iem_kkt_chain_level``), with no border at all.  ``S`` (hubs x hubs, dense) is factorised by Cholesky: under an
+    interior-point regularisation with the correct inertia it is positive definite (the hubs are primal variables); a
+    failing Cholesky is reported as doubtful inertia.  Solve: two chain solves around the dense one
+    (``x_B = S^-1 (r_B - E' K_c^-1 r_c)``, ``x_c = K_c^-1 (r_c - E x_B)``), ``E`` being the ORIGINAL one-column-per-block border.
+
+    ``levels``: ``None`` = the device kernels; tests pass a dense restatement (``tests/chain_reference.py``) to check the hub
+    pipeline itself on CPU tensors."""
+
+    def __init__(self, kkt, group: Optional[int] = None, levels=None, device=None):
+        import torch
+        self._torch = t = torch
+        self.kkt = kkt
+        m = self.model = kkt.model
+        jr, jc = m.jac_structure(0)
+        self.layout = L = ChainLayout(m.core.slabs, m.meta.nvar, m.meta.ncon, jr, jc, group=group, hubs=True)
+        if L.reach != 1 or L.supports_per_block != 1:
+            raise _lib.IemError("chain KKT (hub border): only stencils of reach 1 (backward differences) are handled")
+        dev = self.device = device if device is not None else m.device
+        self.lanes, self.S, self.nb = int(L.lanes), int(L.S), int(L.nb)
+        self.Tp = Tp = self.S // self.lanes
+        n = L.nvar + L.ncon
+        border = np.nonzero(L.blk < 0)[0]
+        tb = L.tblock[border]
+        if (tb < 0).any():
+            raise _lib.IemError("chain KKT (hub border): a border unknown has no place on the chain's axis (finite variables are not handled here)")
+        order = np.argsort(tb, kind="stable")
+        cnt = np.bincount(tb, minlength=Tp)
+        self.hw = hw = int(cnt.max())
+        first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        ordinal = np.empty(border.size, dtype=np.int64)
+        ordinal[order] = np.arange(border.size) - first[tb[order]]
+        self.hub_of = np.full(n, -1, dtype=np.int64)
+        self.hub_of[border] = tb * hw + ordinal
+        self.T = int(tb.max()) + 1                      # time blocks that own a hub
+        self.H, self.Hp = self.T * hw, Tp * hw
+        # where the entries of K go: D | Bt through the layout's own plan (it may widen the coupling), E0 and S here
+        rowptr = kkt.rowptr.cpu().numpy().astype(np.int64)
+        rows = np.repeat(np.arange(kkt.n), np.diff(rowptr))
+        cols = kkt.colind.cpu().numpy().astype(np.int64)
+        kr, kc = L.blk[rows], L.blk[cols]
+        chain_only = (kr >= 0) & (kc >= 0)
+        src_c, dest_c = self._chain_plan(rows[chain_only], cols[chain_only])
+        src_c = np.nonzero(chain_only)[0][src_c]
+        e = (kr >= 0) & (kc < 0)
+        tr = kr[e] % Tp
+        hc = self.hub_of[cols[e]]
+        if (hc // hw != tr).any():
+            raise _lib.IemError("chain KKT (hub border): a border unknown couples to a block of another time support")
+        lane_e = kr[e] // Tp
+        # only a few local rows of a block ever hold border entries: the ones the hubs couple to, and the coupling rows /
+        # columns R, C the reduction carries them over — E lives on those rows Q alone (10 of 20 for the SIR model)
+        Q = np.union1d(np.union1d(np.unique(L.loc[rows[e]]), L.rowsR), L.colsC).astype(np.int64)
+        self.nQ = nQ = int(Q.size)
+        qidx = np.full(self.nb, -1, dtype=np.int64); qidx[Q] = np.arange(nQ)
+        dest_e = ((tr * self.lanes + lane_e) * nQ + qidx[L.loc[rows[e]]]) * hw + hc % hw       # E0: [Tp, lanes, nQ, hw]
+        g = (kr < 0) & (kc < 0)
+        dest_g = self.hub_of[rows[g]] * self.Hp + self.hub_of[cols[g]]
+        f64 = dict(dtype=t.float64, device=dev)
+        as_t = lambda a: t.as_tensor(np.ascontiguousarray(a), device=dev)
+        self._src_c, self._dest_c = as_t(src_c), as_t(dest_c)
+        self._src_e, self._dest_e = as_t(np.nonzero(e)[0]), as_t(dest_e)
+        self._src_g, self._dest_g = as_t(np.nonzero(g)[0]), as_t(dest_g)
+        nc = self.nc = int(L.nc)
+        self.flat = t.zeros(self.S * self.nb * self.nb + self.S * nc * nc, **f64)
+        self.D, self.Bt = self.flat[:self.S * self.nb * self.nb], self.flat[self.S * self.nb * self.nb:]
+        self.BR = t.zeros(self.S * nc * nc, **f64)
+        self.E0 = t.zeros(Tp * self.lanes * nQ * hw, **f64)
+        self._Q = as_t(Q)
+        self._qR, self._qC = as_t(qidx[L.rowsR]), as_t(qidx[L.colsC])
+        self.Sbig = t.zeros(self.Hp * self.Hp, **f64)
+        pd = L.pad_positions()
+        self._pad = as_t(pd[pd < self.S * self.nb * self.nb])          # the unit diagonal of the padding places (chain part)
+        virt = np.setdiff1d(np.arange(self.Hp), self.hub_of[border])
+        self._virt = as_t(virt * self.Hp + virt)                        # hubs nobody owns (time blocks beyond the last support)
+        rt, ct = L.coupling_tables()
+        self._rows, self._cols = t.as_tensor(rt, device=dev), t.as_tensor(ct, device=dev)
+        self._R = as_t(L.rowsR.astype(np.int64)); self._C = as_t(L.colsC.astype(np.int64))
+        self.info = t.zeros(3, dtype=t.int64, device=dev)
+        on = np.nonzero(L.blk >= 0)[0]
+        self._on, self._pos = as_t(on), as_t(L.blk[on] * self.nb + L.loc[on])
+        self._border, self._hub = as_t(border), as_t(self.hub_of[border])
+        self._r, self._z = t.zeros(self.S * self.nb, **f64), t.empty(self.S * self.nb, **f64)
+        self._levels = levels
+        self._chol = None
+        self.negative_pivots = None
+
+    def _chain_plan(self, rows, cols):
+        """(src, dest) of the chain-to-chain entries into D | Bt (the layout's plan with the border left out)."""
+        L = self.layout
+        kr, kc, lr, lc = L.blk[rows], L.blk[cols], L.loc[rows], L.loc[cols]
+        nb = self.nb
+        dest = np.full(rows.size, -1, dtype=np.int64)
+        diag, low = kr == kc, kr == kc + 1
+        if (np.abs(kr - kc) > 1).any():
+            raise _lib.IemError("chain KKT: an entry couples blocks that are not neighbours (the chain grouping does not fit this model)")
+        if low.any():
+            ri, ci = L._ridx[lr[low]], L._cidx[lc[low]]
+            if (ri < 0).any() or (ci < 0).any():
+                L.set_coupling(np.union1d(L.rowsR, lr[low]), np.union1d(L.colsC, lc[low]))
+                return self._chain_plan(rows, cols)
+            dest[low] = self.S * nb * nb + (kr[low] * L.nc + ri) * L.nc + ci
+        dest[diag] = (kr[diag] * nb + lr[diag]) * nb + lc[diag]
+        src = np.nonzero(dest >= 0)[0]
+        return src, dest[src]
+
+    def load(self):
+        """Blocks, one-column border and the hubs' own block from the CSR values of the last ``kkt.assemble``."""
+        v = self.kkt.vals.to(self.device)
+        self.flat.zero_(); self.E0.zero_(); self.Sbig.zero_()
+        if self._pad.numel():
+            self.flat[self._pad] = 1.0
+        self.flat.index_copy_(0, self._dest_c, v[self._src_c])
+        self.E0.index_copy_(0, self._dest_e, v[self._src_e])
+        self.Sbig.index_copy_(0, self._dest_g, v[self._src_g])
+        if self._virt.numel():
+            self.Sbig[self._virt] = 1.0
+        return self
+
+    # -- one level of the chain's reduction: device kernels, or the caller's restatement ------------------------------------
+    def _level(self, s: int, what: int, tiny: float = 1e-30):
+        if self._levels is not None:
+            return self._levels(self, s, what)
+        m = self.model
+        p = lambda a: C.c_void_p(a.data_ptr())
+        _lib.check(m._L.iem_kkt_chain_level(m._h, self.S, self.nb, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols),
+                                           p(self.info), float(tiny), int(s), int(what)))
+
+    def factor(self, clip_levels: int = 16, profile: Optional[dict] = None):
+        """``profile``: a dict that receives the milliseconds spent per phase (synchronising: diagnosis only)."""
+        t = self._torch
+        lanes, Tp, nb, nc, hw, Hp, H = self.lanes, self.Tp, self.nb, self.nc, self.hw, self.Hp, self.H
+        if self._levels is None:
+            self.model._sync_stream()
+        import time as _time
+        _t0 = [_time.perf_counter()]
+
+        def tick(name):
+            if profile is None:
+                return
+            if self.device != "cpu":
+                t.cuda.synchronize()
+            now = _time.perf_counter()
+            profile[name] = profile.get(name, 0.0) + (now - _t0[0]) * 1e3
+            _t0[0] = now
+        D = self.D.view(lanes, Tp, nb, nb)
+        Bt = self.Bt.view(lanes, Tp, nc, nc)
+        R, Cc, Q = self._qR, self._qC, self._Q              # positions of the coupling rows / columns inside Q
+        nR, nC, nQ = int(R.numel()), int(Cc.numel()), self.nQ
+        E = self.E0.view(Tp, lanes, nQ, hw).clone()
+        self._level(1, 3)
+        s = 1
+        while s < Tp:
+            tick("other")
+            self._level(s, 0)                                   # D of the blocks t = (2m+1)s now holds their inverses
+            tick("chain eliminate")
+            W = (2 * s - 1) * hw
+            te = t.arange(s, Tp, 2 * s, device=self.device)
+            n_e = int(te.numel())
+            Ee = E[1::2]                                        # [n_e, lanes, nQ, W]
+            Dq = D[:, te][:, :, Q[:, None], Q[None, :]].permute(1, 0, 2, 3)
+            Z = t.matmul(Dq, Ee)                                # (D_i^-1 E_i) on the rows Q
+            A2, Z2 = Ee.reshape(n_e, lanes * nQ, W), Z.reshape(n_e, lanes * nQ, W)
+            tick("Z = Dinv E")
+            if n_e > clip_levels:                               # many small intervals: one batched product, written onto the diagonal blocks of S
+                Cm = t.bmm(A2.transpose(1, 2), Z2)
+                Sv = t.as_strided(self.Sbig, (n_e, W, W), (2 * s * hw * (Hp + 1), Hp, 1), hw * (Hp + 1))
+                Sv -= Cm
+            else:                                               # few wide ones: clip each to the hubs that exist
+                for mi in range(n_e):
+                    h0 = (int(te[mi]) - s + 1) * hw
+                    w = min(W, H - h0)
+                    if w <= 0:
+                        continue
+                    Sv = t.as_strided(self.Sbig, (w, w), (Hp, 1), h0 * (Hp + 1))
+                    Sv -= A2[mi][:, :w].transpose(0, 1) @ Z2[mi][:, :w]
+            tick(f"S accumulate (levels of {'many' if n_e > clip_levels else 'few'} intervals)")
+            # the survivors t = 2ms: their border columns widen to the hubs of both neighbours
+            n_s = n_e
+            En = t.zeros(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device=self.device)
+            En[..., s * hw: s * hw + W] = E[0::2]
+            ts_ = te - s
+            if n_s > 1:                                         # left neighbour p = j - s (the block eliminated just before j)
+                Bj = Bt[:, ts_[1:]].permute(1, 0, 2, 3)[:, :, :nR, :nC]
+                upd = t.matmul(Bj, Z[:n_s - 1][:, :, Cc, :])    # Bt_j Z_p[C, :]
+                En[1:, :, R, 0:W] = En[1:, :, R, 0:W] - upd
+            Bq = Bt[:, te].permute(1, 0, 2, 3)[:, :, :nR, :nC]  # K[q, j] on rows R of q = j + s, columns C of j
+            updr = t.matmul(Bq.transpose(-1, -2), Z[:, :, R, :])
+            En[:, :, Cc, 2 * s * hw: 2 * s * hw + W] = En[:, :, Cc, 2 * s * hw: 2 * s * hw + W] - updr
+            E = En
+            tick("E update")
+            self._level(s, 1)                                   # fold the inverses into the survivors' blocks and couplings
+            tick("chain update")
+            s *= 2
+        # one block per lane is left (t = 0), coupled to every hub; the lanes do not couple: the remaining levels only invert them
+        Ef = E[0][:, :, (Tp - 1) * hw: (Tp - 1) * hw + H] if Tp > 1 else E[0][:, :, :H]
+        while s < self.S:
+            self._level(s, 0); self._level(s, 1)
+            s *= 2
+        self._level(1, 2)
+        tick("chain lane-final levels")
+        Zf = t.matmul(D[:, 0][:, Q[:, None], Q[None, :]], Ef)   # [lanes, nQ, H]
+        Sv = t.as_strided(self.Sbig, (H, H), (Hp, 1), 0)
+        Sv -= Ef.reshape(lanes * nQ, H).transpose(0, 1) @ Zf.reshape(lanes * nQ, H)
+        tick("S lane-final product")
+        self._dense_factor(Sv.contiguous())
+        tick("dense block LDL' of the hubs")
+        return self
+
+    # -- the hubs' Schur complement: block LDL' with 96 x 96 pivot blocks inverted by the chain solver's own kernel ------------
+    LEAF = 96
+
+    def _dense_factor(self, Sd):
+        """``S = L D L'`` in place, right-looking, pivot blocks of 96: ``D_k^-1`` by ``kkt_eliminate`` (the Gauss-Jordan inverse
+        on the FP64 matrix cores that inverts the chain's blocks — it also counts the pivot signs: the hubs' inertia is
+        MEASURED, not inferred), panels ``P_k = A21 D_k^-1`` and trailing updates as library GEMMs.  (rocSOLVER's potrf takes
+        16.5 ms for 5 000 x 5 000 here — 2 us per column in its unblocked panel kernel whatever the blocking,
+        tools/probes/chol_probe.py; this form is bound by 52 pivot blocks of 40 us and 8e10 flops of GEMM.)"""
+        t = self._torch
+        n, NB = int(Sd.shape[0]), self.LEAF
+        steps = (n + NB - 1) // NB
+        dev = self.device
+        self._Lfull = Sd                                            # unit lower block triangle below the pivot blocks, in place
+        self._Dinv = t.zeros(steps, NB, NB, dtype=t.float64, device=dev)
+        self._dinfo = t.zeros(steps, 3, dtype=t.int64, device=dev)
+        eye = t.eye(NB, dtype=t.float64, device=dev)
+        m = self.model
+        for ki, k in enumerate(range(0, n, NB)):
+            e = min(k + NB, n); w = e - k
+            blk = self._Dinv[ki]
+            blk.copy_(eye)
+            blk[:w, :w] = Sd[k:e, k:e]                               # (the last block is padded with a unit diagonal: positive pivots)
+            if self._levels is None:
+                p = lambda a: C.c_void_p(a.data_ptr())
+                _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, 0, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), 1e-30))
+            else:
+                M = blk.clone().numpy()
+                for j in range(NB):
+                    self._dinfo[ki, 0] += int(M[j, j] < 0)
+                    M[j + 1:, j + 1:] -= np.outer(M[j + 1:, j], M[j, j + 1:]) / M[j, j]
+                blk.copy_(t.linalg.inv(blk))
+            if e < n:
+                A21 = Sd[e:, k:e].clone()
+                P = A21 @ blk[:w, :w]
+                Sd[e:, e:] -= P @ A21.transpose(0, 1)
+                Sd[e:, k:e] = P
+        self._dense_n, self._dense_steps = n, steps
+        self._chol_ok = True
+
+    def _dense_solve(self, b):
+        t = self._torch
+        n, NB, steps = self._dense_n, self.LEAF, self._dense_steps
+        z = t.linalg.solve_triangular(self._Lfull_unit(), b.unsqueeze(1), upper=False, unitriangular=True).squeeze(1)
+        zp = t.zeros(steps * NB, dtype=t.float64, device=self.device); zp[:n] = z
+        w = t.bmm(self._Dinv, zp.view(steps, NB, 1)).reshape(-1)[:n]
+        return t.linalg.solve_triangular(self._Lfull_unit().transpose(0, 1), w.unsqueeze(1), upper=True, unitriangular=True).squeeze(1)
+
+    def _Lfull_unit(self):
+        """The block unit-lower factor as a plain unit-lower matrix: inside a pivot block's own columns the entries below the
+        diagonal belong to D_k (kept in ``_Dinv``), not to L — zeroed once after the factorisation."""
+        if getattr(self, "_Lclean", None) is not self._Lfull:
+            n, NB = self._dense_n, self.LEAF
+            for k in range(0, n, NB):
+                e = min(k + NB, n)
+                self._Lfull[k:e, k:e] = 0.0
+            self._Lclean = self._Lfull
+        return self._Lfull
+
+    def inertia(self):
+        """``(positive, negative, doubtful)``: the blocks' pivot signs; the hubs' Schur complement counts as all positive when its
+        Cholesky factorisation exists, as doubtful otherwise (the caller shifts and factorises again)."""
+        info = self.info.cpu().numpy()
+        dinfo = self._dinfo.cpu().numpy()
+        neg = int(info[0]) + int(dinfo[:, 0].sum())
+        n = self.layout.nvar + self.layout.ncon
+        return n - neg, neg, int(info[1]) + int(dinfo[:, 1].sum())
+
+    def _chain_solve(self, r):
+        """K_c y = r in place (r: S * nb, padded places zero)."""
+        if self._levels is not None:
+            return self._levels(self, r, "solve")
+        m = self.model
+        p = lambda a: C.c_void_p(a.data_ptr())
+        args = (m._h, self.S, self.nb, 0, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols), None, p(r), p(self._z), None)
+        _lib.check(m._L.iem_kkt_chain_solve(*args, None, 0))
+        _lib.check(m._L.iem_kkt_chain_solve(*args, None, 1))
+        return r
+
+    def solve(self, rhs):
+        t = self._torch
+        if self._levels is None:
+            self.model._sync_stream()
+        lanes, Tp, nb, hw, H = self.lanes, self.Tp, self.nb, self.hw, self.H
+        Q = self._Q
+        E0 = self.E0.view(Tp, lanes, self.nQ, hw)
+        r = self._r
+        r.zero_(); r[self._pos] = rhs[self._on]
+        y = self._chain_solve(r.clone())
+        yb = y.view(lanes, Tp, nb)[:, :, Q].permute(1, 0, 2)                          # [Tp, lanes, nQ]
+        rB = t.zeros(self.Hp, dtype=t.float64, device=self.device)
+        rB[self._hub] = rhs[self._border]
+        rB = rB - (E0 * yb.unsqueeze(-1)).sum((1, 2)).reshape(-1)                     # E' y: hub (t, k) collects its time support's blocks
+        xB = self._dense_solve(rB[:H])
+        xBp = t.zeros(self.Hp, dtype=t.float64, device=self.device); xBp[:H] = xB
+        corr = (E0 * xBp.view(Tp, 1, 1, hw)).sum(-1)                                  # E x_B: [Tp, lanes, nQ]
+        r2 = r.clone()
+        r2v = r2.view(lanes, Tp, nb)
+        r2v[:, :, Q] = r2v[:, :, Q] - corr.permute(1, 0, 2)
+        x = self._chain_solve(r2)
+        out = t.empty_like(rhs)
+        out[self._on] = x[self._pos]
+        out[self._border] = xBp[self._hub]
         return out

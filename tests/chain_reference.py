@@ -95,3 +95,71 @@ def solve(Dinv, X, Y, Z, G, Gp, r, rB):
                 v -= Y[i] @ r[i + s]
             r[i] = v
     return r, xB
+
+
+class HubLevels:
+    """Dense restatement (torch on the CPU) of what ``iem_kkt_chain_level`` / ``iem_kkt_chain_solve`` do to the chain part of
+    ``kkt_chain.HubChainKKT`` — so that the hub pipeline around them (span-sparse border columns, Schur complement of the hubs)
+    can be checked without a device.  ``__call__(hub, s, what)``: 0 eliminate level s, 1 update level s, 2 last block, 3 reset;
+    ``__call__(hub, r, "solve")``: K_c y = r with the ORIGINAL chain matrix (kept at reset)."""
+
+    def __call__(self, hub, s, what):
+        import torch
+        S, nb, nc = hub.S, hub.nb, hub.nc
+        D, Bt, BR = hub.D.view(S, nb, nb), hub.Bt.view(S, nc, nc), hub.BR.view(S, nc, nc)
+        R, C = hub._R, hub._C
+        nR, nC = R.numel(), C.numel()
+        if isinstance(what, str):
+            return self._solve(hub, s)
+        if what == 3:
+            hub.info.zero_()
+            self.D0, self.B0 = D.clone(), Bt.clone()
+            return
+
+        def invert(i):
+            M = D[i].clone().numpy()
+            for k in range(nb):
+                hub.info[0] += int(M[k, k] < 0)
+                M[k + 1:, k + 1:] -= np.outer(M[k + 1:, k], M[k, k + 1:]) / M[k, k]
+            D[i] = torch.linalg.inv(D[i])
+        if what == 2:
+            invert(0)
+        elif what == 0:
+            for i in range(s, S, 2 * s):
+                if i + s < S:
+                    BR[i] = Bt[i + s]
+                invert(i)
+        else:
+            new = {}
+            for j in range(0, S, 2 * s):
+                p, q = j - s, j + s
+                if j > 0:
+                    Bj = Bt[j][:nR, :nC]
+                    D[j][R[:, None], R[None, :]] -= Bj @ D[p][C[:, None], C[None, :]] @ Bj.T
+                    nb_ = torch.zeros(nc, nc, dtype=torch.float64)
+                    if p - s >= 0:
+                        nb_[:nR, :nC] = -Bj @ D[p][C[:, None], R[None, :]] @ Bt[p][:nR, :nC]
+                    new[j] = nb_
+                if q < S:
+                    Bq = Bt[q][:nR, :nC]
+                    D[j][C[:, None], C[None, :]] -= Bq.T @ D[q][R[:, None], R[None, :]] @ Bq
+            for j, v in new.items():
+                Bt[j] = v
+
+    def _solve(self, hub, r):
+        import scipy.sparse as sp
+        from scipy.sparse.linalg import spsolve
+        import torch
+        S, nb = hub.S, hub.nb
+        R, C = hub._R.numpy(), hub._C.numpy()
+        blocks = [[None] * S for _ in range(S)]
+        for k in range(S):
+            blocks[k][k] = sp.csr_matrix(self.D0[k].numpy())
+            if k > 0:
+                B = np.zeros((nb, nb))
+                B[R[:, None], C[None, :]] = self.B0[k][:R.size, :C.size].numpy()
+                if np.any(B):
+                    blocks[k][k - 1] = sp.csr_matrix(B)
+                    blocks[k - 1][k] = sp.csr_matrix(B.T)
+        K = sp.bmat(blocks, format="csc")
+        return torch.as_tensor(spsolve(K, r.numpy()))

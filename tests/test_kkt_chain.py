@@ -87,6 +87,75 @@ def test_layout_picks_the_stencil_axis_and_refuses_oversized_blocks(built):
         ChainLayout(big.slabs, ob.nvar, ob.ncon, *ob.jac_structure())
 
 
+def _pandemic_system(nt, nxi):
+    from infiniteexamodels.jl_amd import transcribe, workloads
+    core = transcribe.exa_core(workloads.pandemic(nt, nxi))
+    om = OracleModel(core.to_blob())
+    x, y = cases.eval_point_for("pandemic_x", om, 5)
+    rng = np.random.default_rng(3)
+    sigma = 0.5 + rng.random(om.nvar)
+    K = host_kkt(om, x, y, sigma, 1e-2, 1e-6).tocsr()
+    K.sum_duplicates(); K.sort_indices()
+    return core, om, (x, y, sigma), K, rng.standard_normal(om.nvar + om.ncon)
+
+
+@pytest.mark.parametrize("nt,nxi", [(10, 4), (23, 3), (54, 5)])      # 20 / 33 / 64 time supports = time blocks per lane (padded to 32 / 64 / 64)
+def test_hub_border_pipeline_on_cpu(nt, nxi, built):
+    """kkt_chain.HubChainKKT (config 3's solver: one chain per scenario, u(t) as span-sparse hubs) with the chain levels done
+    by the dense restatement (chain_reference.HubLevels) instead of the device: the span bookkeeping of the hubs' columns, the
+    accumulation of their Schur complement, its block LDL' and the two-chain-solve substitution against scipy's sparse LU, and
+    the inertia against the eigenvalues."""
+    import types
+    import torch
+    from infiniteexamodels.jl_amd.kkt_chain import HubChainKKT
+    core, om, _, K, rhs = _pandemic_system(nt, nxi)
+    n = om.nvar + om.ncon
+    stub = types.SimpleNamespace(core=core, meta=types.SimpleNamespace(nvar=om.nvar, ncon=om.ncon), jac_structure=lambda base=0: om.jac_structure(), device="cpu")
+    kkt = types.SimpleNamespace(model=stub, n=n, rowptr=torch.as_tensor(K.indptr.astype(np.int32)), colind=torch.as_tensor(K.indices.astype(np.int32)),
+                                vals=torch.as_tensor(K.data))
+    hub = HubChainKKT(kkt, levels=ref.HubLevels(), device="cpu")
+    assert hub.lanes == nxi and hub.H == nt + 10 and hub.nb == 20 and hub.Tp & (hub.Tp - 1) == 0 and hub.Tp * hub.hw >= nt + 10 > (hub.Tp // 2) * hub.hw
+    hub.load().factor()
+    neg_ref = int((np.linalg.eigvalsh(K.toarray()) < 0).sum())
+    assert hub.inertia() == (n - neg_ref, neg_ref, 0)
+    sol = hub.solve(torch.as_tensor(rhs)).numpy()
+    sol = sol + hub.solve(torch.as_tensor(rhs - K @ sol)).numpy()
+    want = spsolve(K.tocsc(), rhs)
+    assert np.abs(K @ sol - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max())
+    np.testing.assert_allclose(sol, want, rtol=1e-7, atol=1e-9 * np.abs(want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nt,nxi", [(54, 5), (190, 24), (100, 7)])    # 64 / 200 (padded to 256) / 110 (padded to 128) time blocks per lane; 200 hubs = 3 pivot blocks
+def test_hub_border_chain_kkt_on_gpu(nt, nxi, built):
+    """The same through the device: iem_kkt_chain_level / iem_kkt_chain_solve for the lanes' chains, kkt_eliminate for the hubs'
+    pivot blocks (the C-ABI entries), torch for the span-sparse GEMMs between them."""
+    import torch
+    from infiniteexamodels.jl_amd.kkt import KKTSystem
+    from infiniteexamodels.jl_amd.kkt_chain import HubChainKKT
+    from infiniteexamodels.jl_amd.model import ExaModel
+    core, om, (x, y, sigma), K, rhs = _pandemic_system(nt, nxi)
+    n = om.nvar + om.ncon
+    gm = ExaModel(core, device=0)
+    kkt = KKTSystem(gm)
+    hub = HubChainKKT(kkt)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    for _ in range(2):                                                 # (twice: load() must restore everything factor() overwrote)
+        kkt.assemble(gm.hess_coord(xd, yd, obj_weight=1.0), gm.jac_coord(xd), torch.tensor(sigma, device="cuda"), 1e-2, 1e-6)
+        hub.load().factor()
+        pos, neg, doubtful = hub.inertia()
+        assert pos + neg == n and doubtful == 0 and neg >= om.ncon
+        if n <= 4000:
+            assert neg == int((np.linalg.eigvalsh(K.toarray()) < 0).sum())
+        r = torch.tensor(rhs, device="cuda")
+        sol = hub.solve(r).cpu().numpy()
+        sol = sol + hub.solve(torch.tensor(rhs - K @ sol, device="cuda")).cpu().numpy()
+        want = spsolve(K.tocsc(), rhs)
+        assert np.abs(K @ sol - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max())
+        np.testing.assert_allclose(sol, want, rtol=1e-6, atol=1e-8 * np.abs(want).max())
+    kkt.close(); gm.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", MODELS + ["quadrotor_1000", "opf_600", "farmer_1000"])
 def test_chain_kkt_on_gpu(name, built):
