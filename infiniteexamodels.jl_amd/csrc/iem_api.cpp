@@ -209,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr; };
+  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1863,13 +1863,14 @@ namespace {
 // chain's latency — beat one wave per tile row (quadrotor_oc3, 84 x 84 blocks: 11.6 ms with four waves, 10.3 with six, 5.8
 // with two; 40 x 40: 2.60 -> 2.40 with one).  With a border the products Z = D^-1 E and E' Z dominate and want the waves
 // (OPF, 60 + 52: 3.6 ms with four, 4.6 with two, 7.0 with one).  profiles/r03_kkt_shape_ab.txt
-struct KktKnobs { int wmax = -1, wpe = -1; std::string contract = "off", defs; };
+struct KktKnobs { int wmax = -1, wpe = -1, rowwise = -1; std::string contract = "off", defs; };
 KktKnobs kkt_knobs() {
   KktKnobs k;
   const char *on = getenv("IEM_KKT_EXPERIMENTS");
   if (!on || std::strcmp(on, "1") != 0) return k;     // production: the environment cannot change kernel shape, numerics or source
   if (const char *e = getenv("IEM_KKT_WMAX")) { const int v = atoi(e); if (v >= 1 && v <= 6) k.wmax = v; }
   if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) k.wpe = v; }
+  if (const char *e = getenv("IEM_KKT_ROWWISE")) { const int v = atoi(e); if (v == 0 || v == 1) k.rowwise = v; }
   if (const char *e = getenv("IEM_KKT_CONTRACT")) { if (!std::strcmp(e, "fast") || !std::strcmp(e, "on") || !std::strcmp(e, "off")) k.contract = e; }
   if (const char *e = getenv("IEM_KKT_DEFS")) {        // extra "#define NAME VALUE" lines only: [A-Za-z0-9_ #\n]
     bool ok = true;
@@ -1877,6 +1878,14 @@ KktKnobs kkt_knobs() {
     if (ok) k.defs = e;
   }
   return k;
+}
+// kkt_eliminate's other form (KKT_ROWWISE of csrc/iem_kkt_device.h): lane = row, 64 / nb blocks per one-wave workgroup — blocks
+// without a border that fit the lanes of a wave
+bool kkt_rowwise(int nb, int ne) {
+  static const KktKnobs knobs = kkt_knobs();
+  if (ne > 0 || nb > 48) return false;
+  if (knobs.rowwise >= 0) return knobs.rowwise == 1;
+  return nb <= 32;
 }
 void kkt_shape(int nb, int ne, int *wmax, int *wpe) {
   const int R = (nb + 15) / 16;
@@ -1902,6 +1911,7 @@ std::string kkt_source(int nb, int ne, int nc) {
   kkt_shape(nb, ne, &wmax, &wpe);
   if (wpe > 0) s += "#define KKT_WPE " + std::to_string(wpe) + "\n";
   if (wmax != 4) s += "#define KKT_WMAX " + std::to_string(wmax) + "\n";
+  if (kkt_rowwise(nb, ne)) s += "#define KKT_ROWWISE 1\n";
   if (!knobs.defs.empty()) s += knobs.defs + "\n";     // (experiments, IEM_KKT_EXPERIMENTS=1 only: extra #define lines)
   s += kKktSource;
   return s;
@@ -1922,6 +1932,10 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     int rc = load_source(m, kkt_source(nb, ne, nc), &km.mod);
     if (rc) return rc;
     HIP_TRY(hipModuleGetFunction(&km.elim, km.mod, "kkt_eliminate"));
+    int wmax, wpe_;
+    kkt_shape(nb, ne, &wmax, &wpe_);
+    km.elim_wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);   // KKT_T of csrc/iem_kkt_device.h
+    if (kkt_rowwise(nb, ne)) { km.elim_wg = 64; km.elim_bpw = 64 / nb; }
     HIP_TRY(hipModuleGetFunction(&km.upd, km.mod, "kkt_update"));
     HIP_TRY(hipModuleGetFunction(&km.fwd, km.mod, "kkt_forward"));
     HIP_TRY(hipModuleGetFunction(&km.bwd, km.mod, "kkt_backward"));
@@ -1943,6 +1957,10 @@ int kkt_launch_raw(iem_model *m, hipFunction_t fn, void *args, size_t sz, long l
 }
 int kkt_launch(iem_model *m, hipFunction_t fn, KktArgsH a, long long grid, unsigned block) { return kkt_launch_raw(m, fn, &a, sizeof a, grid, block); }
 int kkt_launch_solve(iem_model *m, hipFunction_t fn, KktSolveArgsH a, long long grid, unsigned block) { return kkt_launch_raw(m, fn, &a, sizeof a, grid, block); }
+// kkt_eliminate over `blocks` blocks of the level: a workgroup takes elim_bpw of them
+int kkt_launch_elim(iem_model *m, const iem_model::KktMod *km, KktArgsH a, long long blocks) {
+  return kkt_launch_raw(m, km->elim, &a, sizeof a, (blocks + km->elim_bpw - 1) / km->elim_bpw, km->elim_wg);
+}
 }  // namespace
 
 int iem_kkt_source(int nb, int ne, int nc, char **out_src, uint64_t *out_key) {
@@ -1961,22 +1979,19 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double
   int rc = kkt_module(m, nb, ne, nc, &km);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(d_info, 0, 24, m->stream));
-  int wmax, wpe_;
-  kkt_shape(nb, ne, &wmax, &wpe_);
-  const unsigned wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);   // KKT_T of csrc/iem_kkt_device.h
   KktArgsH A{d_D, d_Bt, d_BR, d_E, d_Z, d_Gp, d_rows, d_cols, (long long *)d_info, (long long)S, 1, 0, tiny};
   if (!chained) {   // one launch: every block against the border
     A.final_block = 2;
-    return kkt_launch(m, km->elim, A, S, wg);
+    return kkt_launch_elim(m, km, A, S);
   }
   for (long long s = 1; s < S; s *= 2) {   // level: eliminate the odd multiples of s, fold them into the even ones
     A.s = s;
     const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
-    if ((rc = kkt_launch(m, km->elim, A, n_elim, wg)) != IEM_OK) return rc;
+    if ((rc = kkt_launch_elim(m, km, A, n_elim)) != IEM_OK) return rc;
     if ((rc = kkt_launch(m, km->upd, A, n_surv, nc <= 8 ? 64u : nc <= 16 ? 128u : 256u)) != IEM_OK) return rc;   // KKT_TU
   }
   A.final_block = 1;
-  return kkt_launch(m, km->elim, A, 1, wg);
+  return kkt_launch_elim(m, km, A, 1);
 }
 
 /* ONE step of the same reduction, for a caller that interleaves work of its own between the levels (kkt_chain.HubChainKKT: the
@@ -1990,14 +2005,11 @@ int iem_kkt_chain_level(iem_model *m, int64_t S, int nb, int nc, double *d_D, do
   iem_model::KktMod *km = nullptr;
   int rc = kkt_module(m, nb, 0, nc, &km);
   if (rc) return rc;
-  int wmax, wpe_;
-  kkt_shape(nb, 0, &wmax, &wpe_);
-  const unsigned wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);
   KktArgsH A{d_D, d_Bt, d_BR, nullptr, nullptr, nullptr, d_rows, d_cols, (long long *)d_info, (long long)S, (long long)s, 0, tiny};
-  if (what == 2) { A.final_block = 1; A.s = 1; return kkt_launch(m, km->elim, A, 1, wg); }
+  if (what == 2) { A.final_block = 1; A.s = 1; return kkt_launch_elim(m, km, A, 1); }
   if (s >= S) return IEM_OK;
   const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
-  if (what == 0) return kkt_launch(m, km->elim, A, n_elim, wg);
+  if (what == 0) return kkt_launch_elim(m, km, A, n_elim);
   return kkt_launch(m, km->upd, A, n_surv, nc <= 8 ? 64u : nc <= 16 ? 128u : 256u);
 }
 

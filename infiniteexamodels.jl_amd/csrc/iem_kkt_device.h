@@ -324,6 +324,70 @@ __device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *
 #else
 #define KKT_OCC
 #endif
+#if defined(KKT_ROWWISE) && KKT_NE == 0
+// Blocks that fit the lanes of ONE wave (NB <= 48, no border): lane = row of the block, its NB entries in registers, and
+// 64 / NB blocks side by side in a wave (three 20 x 20 blocks, five 12 x 12 ones).  The in-place Gauss-Jordan inverse is then
+// the scalar algorithm itself — pivot k: the pivot row goes through LDS to every lane of its block (broadcast reads), each lane
+// does  m[j] -= (m[k] / p) r[j]  on its own row: NB fused multiply-adds per lane and step, no panel regrouping, no tile rim,
+// no transposes.  The matrix-core form above spends 590 instructions per 4 pivots around 9 MFMAs whatever the block size (a
+// 20 x 20 block costs what a 40 x 40 one does) and is bound by FP64 issue slots at these sizes; this one issues ~ 3 NB per pivot.
+// Same pivots in the same order, same pivot-sign count.
+#define KKT_BPW (64 / KKT_NB)
+// pivot K (a template parameter: every register index is a compile-time constant whatever the unroller's thresholds say)
+template <int K>
+__device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_NB], double (*rowbuf)[KKT_BPW * KKT_NB], int bs, int li, bool mine, double tiny, int &neg, int &bad) {
+  if constexpr (K < KKT_NB) {
+    double *rb = rowbuf[K & 1] + bs * KKT_NB;
+    if (li == K && mine) {
+#pragma unroll
+      for (int j = 0; j < KKT_NB; j += 2) *reinterpret_cast<double2 *>(rb + j) = double2{m[j], m[j + 1]};
+#pragma unroll
+      for (int j = 0; j < KKT_NB; ++j) m[j] = 0.0;
+    }
+    __syncthreads();       // (one wave: the barrier orders the LDS traffic; two buffers alternate, so one per pivot is enough)
+    double r[KKT_NB];
+#pragma unroll
+    for (int j = 0; j < KKT_NB; j += 2) { const double2 v = *reinterpret_cast<const double2 *>(rb + j); r[j] = v.x; r[j + 1] = v.y; }
+    double piv = r[K];
+    if (piv < 0.0) ++neg;
+    if (!(fabs(piv) >= tiny)) { ++bad; piv = piv < 0.0 ? -tiny : tiny; }
+    const double inv = kkt_rcp(piv);
+    const double g = li == K ? -inv : m[K] * inv;              // the pivot row's own lane restarts from zero: it becomes r / p, its pivot entry 1 / p
+#pragma unroll
+    for (int j = 0; j < KKT_NB; ++j) if (j != K) m[j] = __builtin_fma(-g, r[j], m[j]);
+    m[K] = -g;
+    kkt_row_steps<K + 1>(m, rowbuf, bs, li, mine, tiny, neg, bad);
+  }
+}
+extern "C" __global__ __launch_bounds__(64) void kkt_eliminate(const KktArgs A) {
+  __shared__ double rowbuf[2][KKT_BPW * KKT_NB];
+  __shared__ int cnt[2];
+  const int lane = (int)threadIdx.x, slot = lane / KKT_NB, li = lane - slot * KKT_NB;
+  const long long b = (long long)blockIdx.x * KKT_BPW + slot;
+  const long long i = A.final_block == 2 ? b : A.final_block ? (b == 0 ? 0 : A.S) : (2 * b + 1) * A.s;
+  const bool mine = slot < KKT_BPW, on = mine && i < A.S;      // (the lanes beyond the last whole block shadow slot 0: they read, never write)
+  const int bs = mine ? slot : 0;
+  if (lane < 2) cnt[lane] = 0;
+  double m[KKT_NB];
+  double *Di = A.D + (on ? i : 0) * KKT_NB * KKT_NB + li * KKT_NB;
+#pragma unroll
+  for (int j = 0; j < KKT_NB; j += 2) {
+    const double2 v = on ? *reinterpret_cast<const double2 *>(Di + j) : double2{j == li ? 1.0 : 0.0, j + 1 == li ? 1.0 : 0.0};
+    m[j] = v.x; m[j + 1] = v.y;
+  }
+  if (on && !A.final_block && i + A.s < A.S)
+    for (int e = li; e < KKT_NC * KKT_NC; e += KKT_NB) A.BR[i * KKT_NC * KKT_NC + e] = A.Bt[(i + A.s) * KKT_NC * KKT_NC + e];
+  int neg = 0, bad = 0;
+  kkt_row_steps<0>(m, rowbuf, bs, li, mine, A.tiny, neg, bad);
+  if (on && li == 0) { if (neg) atomicAdd(&cnt[0], neg); if (bad) atomicAdd(&cnt[1], bad); }
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < KKT_NB; j += 2) *reinterpret_cast<double2 *>(Di + j) = double2{m[j], m[j + 1]};
+  }
+  __syncthreads();
+  if (lane < 2 && cnt[lane]) atomicAdd((unsigned long long *)(A.info + lane), (unsigned long long)cnt[lane]);
+}
+#else
 extern "C" __global__ __launch_bounds__(KKT_T) KKT_OCC void kkt_eliminate(const KktArgs A) {
   __shared__ double panels[KKT_PANEL_DOUBLES + 2 * KKT_GJ_DOUBLES];
   double *cpb = panels, *rpb = panels + 2 * 16 * KKT_R * KKT_LC, *gjb = panels + KKT_PANEL_DOUBLES;
@@ -381,6 +445,7 @@ extern "C" __global__ __launch_bounds__(KKT_T) KKT_OCC void kkt_eliminate(const 
   }
 #endif
 }
+#endif   // KKT_ROWWISE
 
 // ---- level l, step 2: fold the eliminated neighbours p = j - s, q = j + s into the survivors j = 2 t s ----------------------
 // B_j = K[j, p] lives on the rows R of block j and the columns C of block p (KKT_NC x KKT_NC values, Bt[j]); with Dp, Dq the

@@ -655,41 +655,51 @@ class HubChainKKT:
     LEAF = 96
 
     def _dense_factor(self, Sd):
-        """``S = L D L'`` in place, right-looking, pivot blocks of 96: ``D_k^-1`` by ``kkt_eliminate`` (the Gauss-Jordan inverse
-        on the FP64 matrix cores that inverts the chain's blocks — it also counts the pivot signs: the hubs' inertia is
-        MEASURED, not inferred), panels ``P_k = A21 D_k^-1`` and trailing updates as library GEMMs.  (rocSOLVER's potrf takes
-        16.5 ms for 5 000 x 5 000 here — 2 us per column in its unblocked panel kernel whatever the blocking,
-        tools/probes/chol_probe.py; this form is bound by 52 pivot blocks of 40 us and 8e10 flops of GEMM.)"""
+        """``S = L D L'`` in place on the lower triangle, two levels of blocking: pivot blocks of 96 whose inverses come from
+        ``kkt_eliminate`` (the Gauss-Jordan inverse on the FP64 matrix cores that inverts the chain's blocks — it also counts
+        the pivot signs: the hubs' inertia is MEASURED, not inferred); inside a panel of 480 columns the pivot steps update the
+        panel's own columns only, and the rest of the matrix gets ONE update per panel (inner dimension 480, lower triangle in
+        column chunks) — library GEMMs.  (rocSOLVER's potrf takes 16.5 ms for 5 000 x 5 000 here — 2 us per column in its
+        unblocked panel kernel whatever the blocking, tools/probes/chol_probe.py.)"""
         t = self._torch
         n, NB = int(Sd.shape[0]), self.LEAF
+        PW, CH = 5 * NB, 10 * NB
         steps = (n + NB - 1) // NB
         dev = self.device
         self._Lfull = Sd                                            # unit lower block triangle below the pivot blocks, in place
         self._Dinv = t.zeros(steps, NB, NB, dtype=t.float64, device=dev)
         self._dinfo = t.zeros(steps, 3, dtype=t.int64, device=dev)
         eye = t.eye(NB, dtype=t.float64, device=dev)
+        Wbuf = t.empty(n, PW, dtype=t.float64, device=dev)          # L21 D of the current panel (= the columns before scaling)
         m = self.model
-        for ki, k in enumerate(range(0, n, NB)):
-            e = min(k + NB, n); w = e - k
-            blk = self._Dinv[ki]
-            blk.copy_(eye)
-            blk[:w, :w] = Sd[k:e, k:e]                               # (the last block is padded with a unit diagonal: positive pivots)
-            if self._levels is None:
-                p = lambda a: C.c_void_p(a.data_ptr())
-                _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, 0, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), 1e-30))
-            else:
-                M = blk.clone().numpy()
-                for j in range(NB):
-                    self._dinfo[ki, 0] += int(M[j, j] < 0)
-                    M[j + 1:, j + 1:] -= np.outer(M[j + 1:, j], M[j, j + 1:]) / M[j, j]
-                blk.copy_(t.linalg.inv(blk))
-            if e < n:
-                A21 = Sd[e:, k:e].clone()
-                P = A21 @ blk[:w, :w]
-                Sd[e:, e:] -= P @ A21.transpose(0, 1)
-                Sd[e:, k:e] = P
+        p = lambda a: C.c_void_p(a.data_ptr())
+        for p0 in range(0, n, PW):
+            p1 = min(p0 + PW, n)
+            for k in range(p0, p1, NB):
+                e = min(k + NB, p1); w = e - k; ki = k // NB
+                blk = self._Dinv[ki]
+                blk.copy_(eye)
+                blk[:w, :w] = Sd[k:e, k:e]                           # (the last block is padded with a unit diagonal: positive pivots)
+                if self._levels is None:
+                    _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, 0, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), 1e-30))
+                else:
+                    M = blk.clone().numpy()
+                    for j in range(NB):
+                        self._dinfo[ki, 0] += int(M[j, j] < 0)
+                        M[j + 1:, j + 1:] -= np.outer(M[j + 1:, j], M[j, j + 1:]) / M[j, j]
+                    blk.copy_(t.linalg.inv(blk))
+                if e < n:
+                    A21 = Wbuf[e:, k - p0:e - p0]
+                    A21.copy_(Sd[e:, k:e])
+                    P = A21 @ blk[:w, :w]
+                    if e < p1:
+                        Sd[e:, e:p1] -= P @ A21[:p1 - e].transpose(0, 1)
+                    Sd[e:, k:e] = P
+            for c0 in range(p1, n, CH):                              # the rest of the matrix, lower triangle only, once per panel
+                c1 = min(c0 + CH, n)
+                Sd[c0:, c0:c1] -= Sd[c0:, p0:p1] @ Wbuf[c0:c1, :p1 - p0].transpose(0, 1)
         self._dense_n, self._dense_steps = n, steps
-        self._chol_ok = True
+        self._Lclean = None
 
     def _dense_solve(self, b):
         t = self._torch
@@ -699,14 +709,19 @@ class HubChainKKT:
         w = t.bmm(self._Dinv, zp.view(steps, NB, 1)).reshape(-1)[:n]
         return t.linalg.solve_triangular(self._Lfull_unit().transpose(0, 1), w.unsqueeze(1), upper=True, unitriangular=True).squeeze(1)
 
+    def _leaf_mask(self, n):
+        """Flat positions of the pivot blocks' own squares in an n x n matrix (computed once per size)."""
+        if getattr(self, "_leafpos_n", None) != n:
+            pos = [(np.arange(k, min(k + self.LEAF, n))[:, None] * n + np.arange(k, min(k + self.LEAF, n))[None, :]).reshape(-1) for k in range(0, n, self.LEAF)]
+            self._leafpos = self._torch.as_tensor(np.concatenate(pos), device=self.device)
+            self._leafpos_n = n
+        return self._leafpos
+
     def _Lfull_unit(self):
         """The block unit-lower factor as a plain unit-lower matrix: inside a pivot block's own columns the entries below the
         diagonal belong to D_k (kept in ``_Dinv``), not to L — zeroed once after the factorisation."""
         if getattr(self, "_Lclean", None) is not self._Lfull:
-            n, NB = self._dense_n, self.LEAF
-            for k in range(0, n, NB):
-                e = min(k + NB, n)
-                self._Lfull[k:e, k:e] = 0.0
+            self._Lfull.view(-1)[self._leaf_mask(self._dense_n)] = 0.0
             self._Lclean = self._Lfull
         return self._Lfull
 
