@@ -291,13 +291,19 @@ int iem_csr_spmv(iem_model *m, int64_t n, const int32_t *d_rowptr, const int32_t
 int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
                          const int32_t *d_cols, double *d_E, double *d_Z, double *d_Gp, int64_t *d_info, double tiny);
 /* ONE step of that reduction (no border), for a caller that interleaves work of its own between the levels — the span-sparse
- * border of a laned 2-D grid, kkt_chain.HubChainKKT: what = 0 eliminate the blocks (2t+1)s, 1 fold them into the survivors 2ts,
- * 2 the last remaining block, 3 clear the pivot counters (d_info). */
-int iem_kkt_chain_level(iem_model *m, int64_t S, int nb, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
+ * border of a laned 2-D grid, kkt_chain.HubChainKKT.  The chain is cut into LANES of lane_len blocks each (S = lanes x lane_len;
+ * 0: one chain), every lane reduced by the same levels (block t of a lane leaves at the level s with t mod 2s == s):
+ * what = 0 eliminate the blocks t = (2k+1)s of every lane, 1 fold them into the survivors t = 2ks, 2 the last remaining block
+ * of every lane (t = 0), 3 clear the pivot counters (d_info).  Levels: s = 1, 2, 4, ... < lane_len. */
+int iem_kkt_chain_level(iem_model *m, int64_t S, int64_t lane_len, int nb, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
                         const int32_t *d_cols, int64_t *d_info, double tiny, int64_t s, int what);
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
                         const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
                         const double *d_xB, int phase);
+/* ... for factors made lane by lane (iem_kkt_chain_level with lane_len; ne must be 0 when lane_len != S) */
+int iem_kkt_chain_solve_lanes(iem_model *m, int64_t S, int64_t lane_len, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt,
+                              const double *d_BR, const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z,
+                              double *d_rBp, const double *d_xB, int phase);
 /* The same solver as ONE object — what a host without the Python layer (a Julia MadNLP linear-solver wrapper) binds.
  * iem_kkt_create analyses the model once on the host: grouping of the unknowns (variable u, then the multiplier of row
  * u - nvar) into chain blocks + border from the slab table and the Jacobian / Hessian structure, the narrow coupling, and a

@@ -1947,8 +1947,8 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
   *out = &it->second;
   return IEM_OK;
 }
-struct KktArgsH { double *D, *Bt, *BR, *E, *Z, *Gp; const int *rows, *cols; long long *info; long long S, s; int final_block; double tiny; };
-struct KktSolveArgsH { const double *D, *Bt, *BR, *Z; const int *rows, *cols; double *r, *z, *rBp; const double *xB; long long S, s; int final_block; };
+struct KktArgsH { double *D, *Bt, *BR, *E, *Z, *Gp; const int *rows, *cols; long long *info; long long S, s; int final_block; double tiny; long long T = 0; };
+struct KktSolveArgsH { const double *D, *Bt, *BR, *Z; const int *rows, *cols; double *r, *z, *rBp; const double *xB; long long S, s; int final_block; long long T = 0; };
 int kkt_launch_raw(iem_model *m, hipFunction_t fn, void *args, size_t sz, long long grid, unsigned block) {
   if (grid <= 0) return IEM_OK;
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -1997,18 +1997,20 @@ int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double
 /* ONE step of the same reduction, for a caller that interleaves work of its own between the levels (kkt_chain.HubChainKKT: the
  * span-sparse border of a laned 2-D grid).  what = 0: eliminate the blocks (2t+1)s (in-place inverses, BR kept), 1: fold them
  * into the survivors 2ts, 2: the last remaining block (index 0), 3: clear the pivot counters.  No border (ne = 0 module). */
-int iem_kkt_chain_level(iem_model *m, int64_t S, int nb, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows, const int32_t *d_cols,
-                        int64_t *d_info, double tiny, int64_t s, int what) {
-  if (!m || S < 1 || !d_D || !d_Bt || !d_BR || !d_rows || !d_cols || !d_info || s < 1 || what < 0 || what > 3) return fail(IEM_E_ARG, "bad argument");
+int iem_kkt_chain_level(iem_model *m, int64_t S, int64_t lane_len, int nb, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
+                        const int32_t *d_cols, int64_t *d_info, double tiny, int64_t s, int what) {
+  const long long T = lane_len > 0 ? lane_len : S;
+  if (!m || S < 1 || S % T || !d_D || !d_Bt || !d_BR || !d_rows || !d_cols || !d_info || s < 1 || what < 0 || what > 3) return fail(IEM_E_ARG, "bad argument");
   DevGuard dg_(m->device);
   if (what == 3) { HIP_TRY(hipMemsetAsync(d_info, 0, 24, m->stream)); return IEM_OK; }
   iem_model::KktMod *km = nullptr;
   int rc = kkt_module(m, nb, 0, nc, &km);
   if (rc) return rc;
-  KktArgsH A{d_D, d_Bt, d_BR, nullptr, nullptr, nullptr, d_rows, d_cols, (long long *)d_info, (long long)S, (long long)s, 0, tiny};
-  if (what == 2) { A.final_block = 1; A.s = 1; return kkt_launch_elim(m, km, A, 1); }
-  if (s >= S) return IEM_OK;
-  const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
+  const long long lanes = S / T;
+  KktArgsH A{d_D, d_Bt, d_BR, nullptr, nullptr, nullptr, d_rows, d_cols, (long long *)d_info, (long long)S, (long long)s, 0, tiny, T};
+  if (what == 2) { A.final_block = 1; A.s = 1; return kkt_launch_elim(m, km, A, lanes); }
+  if (s >= T) return IEM_OK;
+  const long long n_elim = lanes * ((T - s + 2 * s - 1) / (2 * s)), n_surv = lanes * ((T + 2 * s - 1) / (2 * s));
   if (what == 0) return kkt_launch_elim(m, km, A, n_elim);
   return kkt_launch(m, km->upd, A, n_surv, nc <= 8 ? 64u : nc <= 16 ? 128u : 256u);
 }
@@ -2016,13 +2018,21 @@ int iem_kkt_chain_level(iem_model *m, int64_t S, int nb, int nc, double *d_D, do
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
                         const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
                         const double *d_xB, int phase) {
+  return iem_kkt_chain_solve_lanes(m, S, S, nb, ne, nc, d_Dinv, d_Bt, d_BR, d_rows, d_cols, d_Z, d_r, d_z, d_rBp, d_xB, phase);
+}
+
+int iem_kkt_chain_solve_lanes(iem_model *m, int64_t S, int64_t lane_len, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
+                              const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
+                              const double *d_xB, int phase) {
   const bool chained = d_Bt != nullptr;   // as in iem_kkt_chain_factor
-  if (!m || S < 1 || !d_Dinv || (chained && (!d_BR || !d_rows || !d_cols || !d_z)) || !d_r || (ne > 0 && (!d_Z || (phase == 0 && !d_rBp) || (phase == 1 && !d_xB)))) return fail(IEM_E_ARG, "bad argument");
+  const long long T = lane_len > 0 ? lane_len : S;
+  if (!m || S < 1 || S % T || (T != S && ne > 0) || !d_Dinv || (chained && (!d_BR || !d_rows || !d_cols || !d_z)) || !d_r || (ne > 0 && (!d_Z || (phase == 0 && !d_rBp) || (phase == 1 && !d_xB)))) return fail(IEM_E_ARG, "bad argument");
   DevGuard dg_(m->device);
   iem_model::KktMod *km = nullptr;
   int rc = kkt_module(m, nb, ne, nc, &km);
   if (rc) return rc;
-  KktSolveArgsH A{d_Dinv, d_Bt, d_BR, d_Z, d_rows, d_cols, d_r, d_z, d_rBp, d_xB, (long long)S, 1, 0};
+  const long long lanes = S / T;
+  KktSolveArgsH A{d_Dinv, d_Bt, d_BR, d_Z, d_rows, d_cols, d_r, d_z, d_rBp, d_xB, (long long)S, 1, 0, T};
   if (!chained) {            // independent blocks: the border terms of all blocks (forward), every block's own solve (backward)
     if (phase != 0 && phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
     A.final_block = 2;
@@ -2030,24 +2040,24 @@ int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const d
     return kkt_launch_solve(m, km->bwd, A, S, 64);
   }
   if (phase == 0) {          // forward: levels up, then the last block's border contribution
-    for (long long s = 1; s < S; s *= 2) {
+    for (long long s = 1; s < T; s *= 2) {
       A.s = s;
-      const long long n_elim = (S - s + 2 * s - 1) / (2 * s), n_surv = (S + 2 * s - 1) / (2 * s);
+      const long long n_elim = lanes * ((T - s + 2 * s - 1) / (2 * s)), n_surv = lanes * ((T + 2 * s - 1) / (2 * s));
       if ((rc = kkt_launch_solve(m, km->fwd, A, n_surv + n_elim, 64)) != IEM_OK) return rc;
     }
     A.final_block = 1;
-    return ne > 0 ? kkt_launch_solve(m, km->fwd, A, 1, 64) : IEM_OK;
+    return ne > 0 ? kkt_launch_solve(m, km->fwd, A, lanes, 64) : IEM_OK;
   }
   if (phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
   A.final_block = 1;
-  if ((rc = kkt_launch_solve(m, km->bwd, A, 1, 64)) != IEM_OK) return rc;
+  if ((rc = kkt_launch_solve(m, km->bwd, A, lanes, 64)) != IEM_OK) return rc;
   A.final_block = 0;
   long long top = 1;
-  while (top * 2 < S) top *= 2;
+  while (top * 2 < T) top *= 2;
   for (long long s = top; s >= 1; s /= 2) {
-    if (s >= S) continue;
+    if (s >= T) continue;
     A.s = s;
-    const long long n_elim = (S - s + 2 * s - 1) / (2 * s);
+    const long long n_elim = lanes * ((T - s + 2 * s - 1) / (2 * s));
     if ((rc = kkt_launch_solve(m, km->bwd, A, n_elim, 64)) != IEM_OK) return rc;
   }
   return IEM_OK;

@@ -169,9 +169,27 @@ struct KktArgs {
   const int *rows, *cols;   // KKT_NC each: local rows / columns of the coupling (-1: padding)
   long long *info;          // [0] negative pivots, [1] pivots below the threshold (replaced by +-tiny: the factorisation is not to be trusted)
   long long S, s;           // blocks, stride of this level
-  int final_block;          // 1: the last remaining block (index 0), no chain neighbours
+  int final_block;          // 1: the last remaining block of every lane (index 0 of the lane), no chain neighbours
   double tiny;              // pivot threshold
+  long long T;              // blocks per LANE (0: one chain of S blocks) — see kkt_eliminated / kkt_survivor
 };
+
+// The chain may be cut into LANES of T blocks each (S = lanes x T; kkt_chain.HubChainKKT: one chain per scenario of a 2-D support
+// grid), every lane reduced by the same levels: block t of a lane is eliminated at the level s with t mod 2s == s, whatever T
+// is — the level structure is the same in every lane, which the span bookkeeping of the hubs relies on.  (One chain with zero
+// couplings at the seams, T = S, reduces to the same thing only when T is a power of two.)
+struct KktIdx { long long i; bool left, right, valid; };
+__device__ __forceinline__ KktIdx kkt_eliminated(long long b, long long s, long long S, long long T_) {   // b-th eliminated block of level s
+  const long long T = T_ > 0 ? T_ : S, ne = (T - s + 2 * s - 1) / (2 * s);
+  const long long lane = ne > 0 ? b / ne : 0, t = (2 * (b - lane * ne) + 1) * s;
+  return KktIdx{lane * T + t, true, t + s < T, ne > 0 && t < T && lane * T + t < S};
+}
+__device__ __forceinline__ KktIdx kkt_survivor(long long b, long long s, long long S, long long T_) {     // b-th surviving block of level s
+  const long long T = T_ > 0 ? T_ : S, ns = (T + 2 * s - 1) / (2 * s);
+  const long long lane = b / ns, t = 2 * (b - lane * ns) * s;
+  return KktIdx{lane * T + t, t > 0, t + s < T, lane * T + t < S};
+}
+__device__ __forceinline__ long long kkt_lane_first(long long b, long long S, long long T_) { return b * (T_ > 0 ? T_ : S); }   // final_block 1: block 0 of lane b
 
 // Panel P (rows / columns 4P .. 4P + 3) of the in-place Gauss-Jordan inverse of the matrix held in the accumulator layout.
 // The four pivot steps of the panel are REGROUPED, not reformulated: with c_i(k) the entry of row i in pivot column k at
@@ -364,8 +382,9 @@ extern "C" __global__ __launch_bounds__(64) void kkt_eliminate(const KktArgs A) 
   __shared__ int cnt[2];
   const int lane = (int)threadIdx.x, slot = lane / KKT_NB, li = lane - slot * KKT_NB;
   const long long b = (long long)blockIdx.x * KKT_BPW + slot;
-  const long long i = A.final_block == 2 ? b : A.final_block ? (b == 0 ? 0 : A.S) : (2 * b + 1) * A.s;
-  const bool mine = slot < KKT_BPW, on = mine && i < A.S;      // (the lanes beyond the last whole block shadow slot 0: they read, never write)
+  const KktIdx ix = kkt_eliminated(b, A.s, A.S, A.T);
+  const long long i = A.final_block == 2 ? b : A.final_block ? kkt_lane_first(b, A.S, A.T) : ix.i;
+  const bool mine = slot < KKT_BPW, on = mine && i < A.S && (A.final_block || ix.valid);      // (the lanes beyond the last whole block shadow slot 0: they read, never write)
   const int bs = mine ? slot : 0;
   if (lane < 2) cnt[lane] = 0;
   double m[KKT_NB];
@@ -375,7 +394,7 @@ extern "C" __global__ __launch_bounds__(64) void kkt_eliminate(const KktArgs A) 
     const double2 v = on ? *reinterpret_cast<const double2 *>(Di + j) : double2{j == li ? 1.0 : 0.0, j + 1 == li ? 1.0 : 0.0};
     m[j] = v.x; m[j + 1] = v.y;
   }
-  if (on && !A.final_block && i + A.s < A.S)
+  if (on && !A.final_block && ix.right)
     for (int e = li; e < KKT_NC * KKT_NC; e += KKT_NB) A.BR[i * KKT_NC * KKT_NC + e] = A.Bt[(i + A.s) * KKT_NC * KKT_NC + e];
   int neg = 0, bad = 0;
   kkt_row_steps<0>(m, rowbuf, bs, li, mine, A.tiny, neg, bad);
@@ -394,9 +413,10 @@ extern "C" __global__ __launch_bounds__(KKT_T) KKT_OCC void kkt_eliminate(const 
   __shared__ int neg_, bad_;
   // final_block: 0 = level of the chain; 1 = the last remaining block (index 0); 2 = NO chain coupling at all (scenario
   // blocks of a two-stage problem): every block is eliminated in this one launch, against the border only
-  const long long i = A.final_block == 2 ? (long long)blockIdx.x : A.final_block ? 0 : (2 * (long long)blockIdx.x + 1) * A.s;
-  if (i >= A.S) return;
-  const bool has_right = !A.final_block && i + A.s < A.S;
+  const KktIdx ix = kkt_eliminated((long long)blockIdx.x, A.s, A.S, A.T);
+  const long long i = A.final_block == 2 ? (long long)blockIdx.x : A.final_block ? kkt_lane_first((long long)blockIdx.x, A.S, A.T) : ix.i;
+  if (i >= A.S || (!A.final_block && !ix.valid)) return;
+  const bool has_right = !A.final_block && ix.right;
   double *Di = A.D + i * KKT_NB * KKT_NB;
   const int l = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6, li = l & 15, lk = l >> 4;
   // D_i in the accumulator layout (rim tiles padded with zeros: the padding never mixes with the matrix — its operand
@@ -458,10 +478,11 @@ extern "C" __global__ __launch_bounds__(KKT_TU) void kkt_update(const KktArgs A)
   __shared__ double Bj[KKT_NC * KKT_LN], Bo[KKT_NC * KKT_LN], G1[KKT_NC * KKT_LN], G2[KKT_NC * KKT_LN], T1[KKT_NC * KKT_LN], T2[KKT_NC * KKT_LN],
       BN[KKT_NC * KKT_LN];
   __shared__ int rr[KKT_NC], cc[KKT_NC];
-  const long long j = 2 * (long long)blockIdx.x * A.s;
-  if (j >= A.S) return;
+  const KktIdx jx = kkt_survivor((long long)blockIdx.x, A.s, A.S, A.T);
+  const long long j = jx.i;
+  if (!jx.valid) return;
   const long long p = j - A.s, q = j + A.s;
-  const bool hp = j > 0, hq = q < A.S;
+  const bool hp = jx.left, hq = jx.right;
   if (!hp && !hq) return;
   const int t = (int)threadIdx.x;
   constexpr int NN = KKT_NC * KKT_NC;
@@ -550,6 +571,7 @@ struct KktSolveArgs {
   const double *xB;              // NE: the border's solution (backward)
   long long S, s;
   int final_block;
+  long long T;                   // blocks per lane (0: one chain), as in KktArgs
 };
 // y[c] = sum_k M[k][c] * v[k]   (M row-major NB x cols: coalesced down the rows)
 __device__ __forceinline__ double kkt_tdot(const double *__restrict__ M, const double *v, int cols, int c) {
@@ -562,13 +584,16 @@ __device__ __forceinline__ double kkt_tdot(const double *__restrict__ M, const d
 extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs A) {
   __shared__ double v[KKT_NB], zc[KKT_NC], zr[KKT_NC];
   __shared__ int rr[KKT_NC], cc[KKT_NC];
-  const long long n_surv = A.final_block ? 0 : (A.S + 2 * A.s - 1) / (2 * A.s);   // (final_block 1 / 2: only the border terms below)
+  const long long T_ = A.T > 0 ? A.T : A.S;
+  const long long n_surv = A.final_block ? 0 : (A.S / T_) * ((T_ + 2 * A.s - 1) / (2 * A.s));   // (final_block 1 / 2: only the border terms below)
   const int t = (int)threadIdx.x;
   constexpr int NN = KKT_NC * KKT_NC;
   if ((long long)blockIdx.x < n_surv) {
-    const long long j = 2 * (long long)blockIdx.x * A.s, p = j - A.s, q = j + A.s;
+    const KktIdx jx = kkt_survivor((long long)blockIdx.x, A.s, A.S, A.T);
+    const long long j = jx.i, p = j - A.s, q = j + A.s;
+    const bool hp = jx.left, hq = jx.right;
     for (int e = t; e < KKT_NC; e += 64) { rr[e] = A.rows[e]; cc[e] = A.cols[e]; zc[e] = 0.0; zr[e] = 0.0; }
-    if (j > 0) {
+    if (hp) {
       for (int e = t; e < KKT_NB; e += 64) v[e] = A.r[p * KKT_NB + e];
       __syncthreads();
       // row cc[a] of the (symmetric) inverse: four lanes per row, 16 rows per pass
@@ -581,7 +606,7 @@ extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs 
       }
       __syncthreads();
     }
-    if (q < A.S) {
+    if (hq) {
       for (int e = t; e < KKT_NB; e += 64) v[e] = A.r[q * KKT_NB + e];
       __syncthreads();
       for (int a0 = 0; a0 < KKT_NC; a0 += 16) {
@@ -593,7 +618,7 @@ extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs 
       }
     }
     __syncthreads();
-    if (j > 0)
+    if (hp)
       for (int a = t; a < KKT_NC; a += 64) {
         if (rr[a] < 0) continue;
         double acc = 0.0;
@@ -602,7 +627,7 @@ extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs 
       }
     __threadfence_block();
     __syncthreads();
-    if (q < A.S)
+    if (hq)
       for (int a = t; a < KKT_NC; a += 64) {
         if (cc[a] < 0) continue;
         double acc = 0.0;
@@ -612,8 +637,9 @@ extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs 
     return;
   }
   const long long e_idx = (long long)blockIdx.x - n_surv;
-  const long long i = A.final_block == 2 ? e_idx : A.final_block ? 0 : (2 * e_idx + 1) * A.s;
-  if (i >= A.S) return;
+  const KktIdx ix = kkt_eliminated(e_idx, A.s, A.S, A.T);
+  const long long i = A.final_block == 2 ? e_idx : A.final_block ? kkt_lane_first(e_idx, A.S, A.T) : ix.i;
+  if (i >= A.S || (!A.final_block && !ix.valid)) return;
   for (int e = t; e < KKT_NB; e += 64) v[e] = A.r[i * KKT_NB + e];
   __syncthreads();
   if (!A.final_block)
@@ -626,11 +652,12 @@ extern "C" __global__ __launch_bounds__(64) void kkt_forward(const KktSolveArgs 
 extern "C" __global__ __launch_bounds__(64) void kkt_backward(const KktSolveArgs A) {
   __shared__ double ri[KKT_NB], xc[KKT_NC], xr[KKT_NC], t1[KKT_NC], t2[KKT_NC], xb[KKT_NE > 0 ? KKT_NE : 1];
   __shared__ int rr[KKT_NC], cc[KKT_NC];
-  const long long i = A.final_block == 2 ? (long long)blockIdx.x : A.final_block ? 0 : (2 * (long long)blockIdx.x + 1) * A.s;
-  if (i >= A.S) return;
+  const KktIdx ix = kkt_eliminated((long long)blockIdx.x, A.s, A.S, A.T);
+  const long long i = A.final_block == 2 ? (long long)blockIdx.x : A.final_block ? kkt_lane_first((long long)blockIdx.x, A.S, A.T) : ix.i;
+  if (i >= A.S || (!A.final_block && !ix.valid)) return;
   const int t = (int)threadIdx.x;
   constexpr int NN = KKT_NC * KKT_NC;
-  const bool hp = !A.final_block, hq = !A.final_block && i + A.s < A.S;
+  const bool hp = !A.final_block, hq = !A.final_block && ix.right;
   for (int e = t; e < KKT_NC; e += 64) {      // (no coupling tables without a chain: final_block 1 / 2 never read them)
     const int re = hp ? A.rows[e] : -1, ce = hp ? A.cols[e] : -1;
     rr[e] = re; cc[e] = ce;

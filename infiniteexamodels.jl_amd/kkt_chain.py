@@ -54,8 +54,8 @@ class ChainLayout:
 
     def __init__(self, slabs, nvar: int, ncon: int, jac_rows, jac_cols, group: Optional[int] = None,
                  max_nb: int = MAX_NB, max_ne: int = MAX_NE, hubs: bool = False):
-        """``hubs``: the layout :class:`HubChainKKT` works on — always one chain per lane, every lane padded to a power of two
-        of time blocks, and NO limit on the border (the chain parameter's own variables, ``u(t)``: handled as span-sparse
+        """``hubs``: the layout :class:`HubChainKKT` works on — always one chain per lane (reduced lane by lane:
+        ``iem_kkt_chain_level``'s ``lane_len``), and NO limit on the border (the chain parameter's own variables, ``u(t)``: handled as span-sparse
         border columns outside the chain kernels)."""
         import torch
         jr = torch.as_tensor(np.asarray(jac_rows, dtype=np.int64))
@@ -155,8 +155,6 @@ class ChainLayout:
                 shifting the others: the coupling then lives on the same few local rows / columns in every block."""
                 tb = np.where(on, (chain + phase) // R, -1)
                 Sb = int(tb.max()) + 1 if on.any() else 0
-                if hubs and Sb > 1:
-                    Sb = 1 << (Sb - 1).bit_length()        # every lane a power of two of blocks: a reduction level never pairs two lanes
                 blk = np.where(on, lane * Sb + tb, -1)
                 off = np.where(on, (chain + phase) % R, 0)
                 S = lanes * Sb
@@ -477,7 +475,8 @@ class HubChainKKT:
         self.hub_of = np.full(n, -1, dtype=np.int64)
         self.hub_of[border] = tb * hw + ordinal
         self.T = int(tb.max()) + 1                      # time blocks that own a hub
-        self.H, self.Hp = self.T * hw, Tp * hw
+        self.P = P = 1 << max(Tp - 1, 0).bit_length()   # the spans of the last levels reach up to the next power of two of time blocks
+        self.H, self.Hp = self.T * hw, P * hw
         # where the entries of K go: D | Bt through the layout's own plan (it may widen the coupling), E0 and S here
         rowptr = kkt.rowptr.cpu().numpy().astype(np.int64)
         rows = np.repeat(np.arange(kkt.n), np.diff(rowptr))
@@ -567,7 +566,7 @@ class HubChainKKT:
             return self._levels(self, s, what)
         m = self.model
         p = lambda a: C.c_void_p(a.data_ptr())
-        _lib.check(m._L.iem_kkt_chain_level(m._h, self.S, self.nb, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols),
+        _lib.check(m._L.iem_kkt_chain_level(m._h, self.S, self.Tp, self.nb, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols),
                                            p(self.info), float(tiny), int(s), int(what)))
 
     def factor(self, clip_levels: int = 16, profile: Optional[dict] = None):
@@ -599,8 +598,9 @@ class HubChainKKT:
             self._level(s, 0)                                   # D of the blocks t = (2m+1)s now holds their inverses
             tick("chain eliminate")
             W = (2 * s - 1) * hw
-            te = t.arange(s, Tp, 2 * s, device=self.device)
-            n_e = int(te.numel())
+            te = t.arange(s, Tp, 2 * s, device=self.device)      # eliminated: the odd ones of the blocks still alive ...
+            ts_ = t.arange(0, Tp, 2 * s, device=self.device)      # ... survivors: the even ones (one more than eliminated when their count is odd)
+            n_e, n_s = int(te.numel()), int(ts_.numel())
             Ee = E[1::2]                                        # [n_e, lanes, nQ, W]
             Dq = D[:, te][:, :, Q[:, None], Q[None, :]].permute(1, 0, 2, 3)
             Z = t.matmul(Dq, Ee)                                # (D_i^-1 E_i) on the rows Q
@@ -620,29 +620,24 @@ class HubChainKKT:
                     Sv -= A2[mi][:, :w].transpose(0, 1) @ Z2[mi][:, :w]
             tick(f"S accumulate (levels of {'many' if n_e > clip_levels else 'few'} intervals)")
             # the survivors t = 2ms: their border columns widen to the hubs of both neighbours
-            n_s = n_e
             En = t.zeros(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device=self.device)
             En[..., s * hw: s * hw + W] = E[0::2]
-            ts_ = te - s
             if n_s > 1:                                         # left neighbour p = j - s (the block eliminated just before j)
                 Bj = Bt[:, ts_[1:]].permute(1, 0, 2, 3)[:, :, :nR, :nC]
                 upd = t.matmul(Bj, Z[:n_s - 1][:, :, Cc, :])    # Bt_j Z_p[C, :]
                 En[1:, :, R, 0:W] = En[1:, :, R, 0:W] - upd
             Bq = Bt[:, te].permute(1, 0, 2, 3)[:, :, :nR, :nC]  # K[q, j] on rows R of q = j + s, columns C of j
             updr = t.matmul(Bq.transpose(-1, -2), Z[:, :, R, :])
-            En[:, :, Cc, 2 * s * hw: 2 * s * hw + W] = En[:, :, Cc, 2 * s * hw: 2 * s * hw + W] - updr
+            En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] = En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] - updr
             E = En
             tick("E update")
             self._level(s, 1)                                   # fold the inverses into the survivors' blocks and couplings
             tick("chain update")
             s *= 2
-        # one block per lane is left (t = 0), coupled to every hub; the lanes do not couple: the remaining levels only invert them
-        Ef = E[0][:, :, (Tp - 1) * hw: (Tp - 1) * hw + H] if Tp > 1 else E[0][:, :, :H]
-        while s < self.S:
-            self._level(s, 0); self._level(s, 1)
-            s *= 2
+        # one block per lane is left (t = 0), coupled to every hub (s is the power of two the levels stopped at)
+        Ef = E[0][:, :, (s - 1) * hw: (s - 1) * hw + H]
         self._level(1, 2)
-        tick("chain lane-final levels")
+        tick("chain lane-final blocks")
         Zf = t.matmul(D[:, 0][:, Q[:, None], Q[None, :]], Ef)   # [lanes, nQ, H]
         Sv = t.as_strided(self.Sbig, (H, H), (Hp, 1), 0)
         Sv -= Ef.reshape(lanes * nQ, H).transpose(0, 1) @ Zf.reshape(lanes * nQ, H)
@@ -740,9 +735,9 @@ class HubChainKKT:
             return self._levels(self, r, "solve")
         m = self.model
         p = lambda a: C.c_void_p(a.data_ptr())
-        args = (m._h, self.S, self.nb, 0, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols), None, p(r), p(self._z), None)
-        _lib.check(m._L.iem_kkt_chain_solve(*args, None, 0))
-        _lib.check(m._L.iem_kkt_chain_solve(*args, None, 1))
+        args = (m._h, self.S, self.Tp, self.nb, 0, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols), None, p(r), p(self._z), None)
+        _lib.check(m._L.iem_kkt_chain_solve_lanes(*args, None, 0))
+        _lib.check(m._L.iem_kkt_chain_solve_lanes(*args, None, 1))
         return r
 
     def solve(self, rhs):
@@ -756,11 +751,11 @@ class HubChainKKT:
         r.zero_(); r[self._pos] = rhs[self._on]
         y = self._chain_solve(r.clone())
         yb = y.view(lanes, Tp, nb)[:, :, Q].permute(1, 0, 2)                          # [Tp, lanes, nQ]
-        rB = t.zeros(self.Hp, dtype=t.float64, device=self.device)
+        rB = t.zeros(Tp * hw, dtype=t.float64, device=self.device)
         rB[self._hub] = rhs[self._border]
         rB = rB - (E0 * yb.unsqueeze(-1)).sum((1, 2)).reshape(-1)                     # E' y: hub (t, k) collects its time support's blocks
         xB = self._dense_solve(rB[:H])
-        xBp = t.zeros(self.Hp, dtype=t.float64, device=self.device); xBp[:H] = xB
+        xBp = t.zeros(Tp * hw, dtype=t.float64, device=self.device); xBp[:H] = xB
         corr = (E0 * xBp.view(Tp, 1, 1, hw)).sum(-1)                                  # E x_B: [Tp, lanes, nQ]
         r2 = r.clone()
         r2v = r2.view(lanes, Tp, nb)

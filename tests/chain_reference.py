@@ -122,25 +122,30 @@ class HubLevels:
                 hub.info[0] += int(M[k, k] < 0)
                 M[k + 1:, k + 1:] -= np.outer(M[k + 1:, k], M[k, k + 1:]) / M[k, k]
             D[i] = torch.linalg.inv(D[i])
+        T = hub.Tp                                   # every lane of T blocks is reduced by itself (iem_kkt_chain_level's lane_len)
         if what == 2:
-            invert(0)
+            for lane in range(S // T):
+                invert(lane * T)
         elif what == 0:
-            for i in range(s, S, 2 * s):
-                if i + s < S:
-                    BR[i] = Bt[i + s]
-                invert(i)
+            for lane in range(S // T):
+                for tt in range(s, T, 2 * s):
+                    i = lane * T + tt
+                    if tt + s < T:
+                        BR[i] = Bt[i + s]
+                    invert(i)
         else:
             new = {}
-            for j in range(0, S, 2 * s):
+            for j in (lane * T + tt for lane in range(S // T) for tt in range(0, T, 2 * s)):
                 p, q = j - s, j + s
-                if j > 0:
+                tt = j % T
+                if tt > 0:
                     Bj = Bt[j][:nR, :nC]
                     D[j][R[:, None], R[None, :]] -= Bj @ D[p][C[:, None], C[None, :]] @ Bj.T
                     nb_ = torch.zeros(nc, nc, dtype=torch.float64)
-                    if p - s >= 0:
+                    if tt - 2 * s >= 0:
                         nb_[:nR, :nC] = -Bj @ D[p][C[:, None], R[None, :]] @ Bt[p][:nR, :nC]
                     new[j] = nb_
-                if q < S:
+                if tt + s < T:
                     Bq = Bt[q][:nR, :nC]
                     D[j][C[:, None], C[None, :]] -= Bq.T @ D[q][R[:, None], R[None, :]] @ Bq
             for j, v in new.items():
