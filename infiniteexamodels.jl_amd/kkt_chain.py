@@ -586,9 +586,10 @@ class HubChainKKT:
             now = _time.perf_counter()
             profile[name] = profile.get(name, 0.0) + (now - _t0[0]) * 1e3
             _t0[0] = now
-        D = self.D.view(lanes, Tp, nb, nb)
+        D4 = self.D.view(lanes, Tp, nb * nb)
         Bt = self.Bt.view(lanes, Tp, nc, nc)
         R, Cc, Q = self._qR, self._qC, self._Q              # positions of the coupling rows / columns inside Q
+        qq = (Q[:, None] * nb + Q[None, :]).reshape(-1)
         nR, nC, nQ = int(R.numel()), int(Cc.numel()), self.nQ
         E = self.E0.view(Tp, lanes, nQ, hw).clone()
         self._level(1, 3)
@@ -602,7 +603,7 @@ class HubChainKKT:
             ts_ = t.arange(0, Tp, 2 * s, device=self.device)      # ... survivors: the even ones (one more than eliminated when their count is odd)
             n_e, n_s = int(te.numel()), int(ts_.numel())
             Ee = E[1::2]                                        # [n_e, lanes, nQ, W]
-            Dq = D[:, te][:, :, Q[:, None], Q[None, :]].permute(1, 0, 2, 3)
+            Dq = D4[:, s::2 * s][:, :, qq].permute(1, 0, 2).reshape(n_e, lanes, nQ, nQ)    # (a strided view, then only the Q x Q entries are read)
             Z = t.matmul(Dq, Ee)                                # (D_i^-1 E_i) on the rows Q
             A2, Z2 = Ee.reshape(n_e, lanes * nQ, W), Z.reshape(n_e, lanes * nQ, W)
             tick("Z = Dinv E")
@@ -616,17 +617,16 @@ class HubChainKKT:
                     w = min(W, H - h0)
                     if w <= 0:
                         continue
-                    Sv = t.as_strided(self.Sbig, (w, w), (Hp, 1), h0 * (Hp + 1))
-                    Sv -= A2[mi][:, :w].transpose(0, 1) @ Z2[mi][:, :w]
+                    self._sub_lower(t.as_strided(self.Sbig, (w, w), (Hp, 1), h0 * (Hp + 1)), A2[mi][:, :w], Z2[mi][:, :w], h0)
             tick(f"S accumulate (levels of {'many' if n_e > clip_levels else 'few'} intervals)")
             # the survivors t = 2ms: their border columns widen to the hubs of both neighbours
             En = t.zeros(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device=self.device)
             En[..., s * hw: s * hw + W] = E[0::2]
             if n_s > 1:                                         # left neighbour p = j - s (the block eliminated just before j)
-                Bj = Bt[:, ts_[1:]].permute(1, 0, 2, 3)[:, :, :nR, :nC]
+                Bj = Bt[:, 2 * s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC]
                 upd = t.matmul(Bj, Z[:n_s - 1][:, :, Cc, :])    # Bt_j Z_p[C, :]
                 En[1:, :, R, 0:W] = En[1:, :, R, 0:W] - upd
-            Bq = Bt[:, te].permute(1, 0, 2, 3)[:, :, :nR, :nC]  # K[q, j] on rows R of q = j + s, columns C of j
+            Bq = Bt[:, s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC]  # K[q, j] on rows R of q = j + s, columns C of j
             updr = t.matmul(Bq.transpose(-1, -2), Z[:, :, R, :])
             En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] = En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] - updr
             E = En
@@ -638,13 +638,25 @@ class HubChainKKT:
         Ef = E[0][:, :, (s - 1) * hw: (s - 1) * hw + H]
         self._level(1, 2)
         tick("chain lane-final blocks")
-        Zf = t.matmul(D[:, 0][:, Q[:, None], Q[None, :]], Ef)   # [lanes, nQ, H]
+        Zf = t.matmul(D4[:, 0][:, qq].reshape(lanes, nQ, nQ), Ef)   # [lanes, nQ, H]
         Sv = t.as_strided(self.Sbig, (H, H), (Hp, 1), 0)
-        Sv -= Ef.reshape(lanes * nQ, H).transpose(0, 1) @ Zf.reshape(lanes * nQ, H)
+        self._sub_lower(Sv, Ef.reshape(lanes * nQ, H), Zf.reshape(lanes * nQ, H), 0)
         tick("S lane-final product")
         self._dense_factor(Sv.contiguous())
         tick("dense block LDL' of the hubs")
         return self
+
+    def _sub_lower(self, Sv, A, Z, h0: int, chunk: int = 960):
+        """``Sv -= A' Z`` (symmetric) for the view of ``S`` that starts at hub ``h0``: wide products only into the block lower
+        triangle — column chunks cut at the multiples of ``chunk`` hubs, which the pivot blocks of the hubs' LDL' (96) never
+        straddle: it reads the lower triangle and the pivot blocks' own squares, nothing else."""
+        w = int(Sv.shape[0])
+        if w <= 2 * chunk:
+            Sv -= A.transpose(0, 1) @ Z
+            return
+        cuts = [0] + [b - h0 for b in range((h0 // chunk + 1) * chunk, h0 + w, chunk)] + [w]
+        for c0, c1 in zip(cuts[:-1], cuts[1:]):
+            Sv[c0:, c0:c1] -= A[:, c0:].transpose(0, 1) @ Z[:, c0:c1]
 
     # -- the hubs' Schur complement: block LDL' with 96 x 96 pivot blocks inverted by the chain solver's own kernel ------------
     LEAF = 96
@@ -666,6 +678,8 @@ class HubChainKKT:
         self._dinfo = t.zeros(steps, 3, dtype=t.int64, device=dev)
         eye = t.eye(NB, dtype=t.float64, device=dev)
         Wbuf = t.empty(n, PW, dtype=t.float64, device=dev)          # L21 D of the current panel (= the columns before scaling)
+        self._Linv, self._panel = [], PW
+        eyeP = t.eye(PW, dtype=t.float64, device=dev)
         m = self.model
         p = lambda a: C.c_void_p(a.data_ptr())
         for p0 in range(0, n, PW):
@@ -690,35 +704,44 @@ class HubChainKKT:
                     if e < p1:
                         Sd[e:, e:p1] -= P @ A21[:p1 - e].transpose(0, 1)
                     Sd[e:, k:e] = P
+            # the panel's own unit lower triangle, inverted once: a solve is then two matrix-vector products per panel instead of a
+            # triangular solve over 5 000 dependent rows (1.4 ms each way in the library)
+            pw = p1 - p0
+            N = Sd[p0:p1, p0:p1] * self._panel_mask(PW)[:pw, :pw]     # L_pp = I + N, N strictly BLOCK lower (its pivot blocks are unit): N^5 = 0
+            X = eyeP[:pw, :pw] - N
+            for _ in range((pw - 1) // NB - 1):                      # (I + N)^-1 = I - N (I - N (I - N (...)))
+                X = eyeP[:pw, :pw] - N @ X
+            self._Linv.append(X)
             for c0 in range(p1, n, CH):                              # the rest of the matrix, lower triangle only, once per panel
                 c1 = min(c0 + CH, n)
                 Sd[c0:, c0:c1] -= Sd[c0:, p0:p1] @ Wbuf[c0:c1, :p1 - p0].transpose(0, 1)
         self._dense_n, self._dense_steps = n, steps
-        self._Lclean = None
+
+    def _panel_mask(self, PW):
+        """1 below the pivot blocks' own squares of a panel (those hold D_k before its inversion, not L), 0 elsewhere."""
+        if getattr(self, "_pmask", None) is None or self._pmask.shape[0] != PW:
+            i = np.arange(PW)
+            self._pmask = self._torch.as_tensor(((i[:, None] // self.LEAF) > (i[None, :] // self.LEAF)).astype(np.float64), device=self.device)
+        return self._pmask
 
     def _dense_solve(self, b):
         t = self._torch
-        n, NB, steps = self._dense_n, self.LEAF, self._dense_steps
-        z = t.linalg.solve_triangular(self._Lfull_unit(), b.unsqueeze(1), upper=False, unitriangular=True).squeeze(1)
-        zp = t.zeros(steps * NB, dtype=t.float64, device=self.device); zp[:n] = z
-        w = t.bmm(self._Dinv, zp.view(steps, NB, 1)).reshape(-1)[:n]
-        return t.linalg.solve_triangular(self._Lfull_unit().transpose(0, 1), w.unsqueeze(1), upper=True, unitriangular=True).squeeze(1)
-
-    def _leaf_mask(self, n):
-        """Flat positions of the pivot blocks' own squares in an n x n matrix (computed once per size)."""
-        if getattr(self, "_leafpos_n", None) != n:
-            pos = [(np.arange(k, min(k + self.LEAF, n))[:, None] * n + np.arange(k, min(k + self.LEAF, n))[None, :]).reshape(-1) for k in range(0, n, self.LEAF)]
-            self._leafpos = self._torch.as_tensor(np.concatenate(pos), device=self.device)
-            self._leafpos_n = n
-        return self._leafpos
-
-    def _Lfull_unit(self):
-        """The block unit-lower factor as a plain unit-lower matrix: inside a pivot block's own columns the entries below the
-        diagonal belong to D_k (kept in ``_Dinv``), not to L — zeroed once after the factorisation."""
-        if getattr(self, "_Lclean", None) is not self._Lfull:
-            self._Lfull.view(-1)[self._leaf_mask(self._dense_n)] = 0.0
-            self._Lclean = self._Lfull
-        return self._Lfull
+        n, NB, steps, PW, Sd = self._dense_n, self.LEAF, self._dense_steps, self._panel, self._Lfull
+        x = b.clone()
+        for pi, p0 in enumerate(range(0, n, PW)):                    # L z = b
+            p1 = min(p0 + PW, n)
+            xp = self._Linv[pi] @ x[p0:p1]
+            x[p0:p1] = xp
+            if p1 < n:
+                x[p1:].addmv_(Sd[p1:, p0:p1], xp, alpha=-1.0)
+        zp = t.zeros(steps * NB, dtype=t.float64, device=self.device); zp[:n] = x
+        w = t.bmm(self._Dinv, zp.view(steps, NB, 1)).reshape(-1)[:n].clone()       # D^-1
+        for pi, p0 in reversed(list(enumerate(range(0, n, PW)))):    # L' x = w
+            p1 = min(p0 + PW, n)
+            if p1 < n:
+                w[p0:p1].addmv_(Sd[p1:, p0:p1].transpose(0, 1), w[p1:], alpha=-1.0)
+            w[p0:p1] = self._Linv[pi].transpose(0, 1) @ w[p0:p1]
+        return w
 
     def inertia(self):
         """``(positive, negative, doubtful)``: the blocks' pivot signs; the hubs' Schur complement counts as all positive when its
@@ -740,28 +763,46 @@ class HubChainKKT:
         _lib.check(m._L.iem_kkt_chain_solve_lanes(*args, None, 1))
         return r
 
-    def solve(self, rhs):
+    def solve(self, rhs, profile: Optional[dict] = None):
         t = self._torch
         if self._levels is None:
             self.model._sync_stream()
+        import time as _time
+        _t0 = [_time.perf_counter()]
+
+        def tick(name):
+            if profile is None:
+                return
+            if self.device != "cpu":
+                t.cuda.synchronize()
+            now = _time.perf_counter()
+            profile[name] = profile.get(name, 0.0) + (now - _t0[0]) * 1e3
+            _t0[0] = now
         lanes, Tp, nb, hw, H = self.lanes, self.Tp, self.nb, self.hw, self.H
         Q = self._Q
         E0 = self.E0.view(Tp, lanes, self.nQ, hw)
         r = self._r
         r.zero_(); r[self._pos] = rhs[self._on]
+        tick("scatter the right-hand side")
         y = self._chain_solve(r.clone())
+        tick("chain solve 1")
         yb = y.view(lanes, Tp, nb)[:, :, Q].permute(1, 0, 2)                          # [Tp, lanes, nQ]
         rB = t.zeros(Tp * hw, dtype=t.float64, device=self.device)
         rB[self._hub] = rhs[self._border]
         rB = rB - (E0 * yb.unsqueeze(-1)).sum((1, 2)).reshape(-1)                     # E' y: hub (t, k) collects its time support's blocks
+        tick("E' y")
         xB = self._dense_solve(rB[:H])
+        tick("dense solve of the hubs")
         xBp = t.zeros(Tp * hw, dtype=t.float64, device=self.device); xBp[:H] = xB
         corr = (E0 * xBp.view(Tp, 1, 1, hw)).sum(-1)                                  # E x_B: [Tp, lanes, nQ]
         r2 = r.clone()
         r2v = r2.view(lanes, Tp, nb)
         r2v[:, :, Q] = r2v[:, :, Q] - corr.permute(1, 0, 2)
+        tick("E x_B")
         x = self._chain_solve(r2)
+        tick("chain solve 2")
         out = t.empty_like(rhs)
         out[self._on] = x[self._pos]
         out[self._border] = xBp[self._hub]
+        tick("gather the solution")
         return out

@@ -62,11 +62,12 @@ res0 = float((matvec(sol) - rhs).abs().max().item())
 sol = sol + hub.solve(rhs - matvec(sol))
 res1 = float((matvec(sol) - rhs).abs().max().item())
 pos, neg, doubtful = hub.inertia()
-prof = {}
+prof, sprof = {}, {}
 hub.load().factor(profile=prof)
+hub.solve(rhs, profile=sprof)
 out = {"workload": f"pandemic SIR, {args.nt + 10} x {args.nxi} supports", "n": n, "nnz_K": kkt.nnz,
        "hub_layout": {"lanes": hub.lanes, "blocks_per_lane": hub.Tp, "S": hub.S, "nb": hub.nb, "nc": hub.nc, "hubs": hub.H, "hubs_per_time_block": hub.hw},
-       "setup_s": {"model_and_csr_plan": t1 - t0, "hub_layout_and_plan": t2 - t1}, "ms": ms, "factor_phases_ms_synchronised": prof,
+       "setup_s": {"model_and_csr_plan": t1 - t0, "hub_layout_and_plan": t2 - t1}, "ms": ms, "factor_phases_ms_synchronised": prof, "solve_phases_ms_synchronised": sprof,
        "abs_residual": {"no_refinement": res0, "one_refinement": res1}, "inertia": [pos, neg, doubtful], "ncon": gm.meta.ncon}
 if args.check:
     import scipy.sparse as sp
