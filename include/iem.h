@@ -300,6 +300,15 @@ int iem_kkt_chain_level(iem_model *m, int64_t S, int64_t lane_len, int nb, int n
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,
                         const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z, double *d_rBp,
                         const double *d_xB, int phase);
+/* Between two levels of that reduction: the SPAN-SPARSE border columns of the blocks still alive (kkt_chain.HubChainKKT).  A block
+ * alive at level s (time block t = a s, a its index among the alive) carries columns for the hubs t - (s - 1) .. t + (s - 1):
+ * d_E is [alive][lanes][nq][W], W = (2 s - 1) hw, on the nq local rows d_q that ever hold a border entry (d_qr / d_qc: the
+ * positions of the coupling rows / columns inside d_q).  After iem_kkt_chain_level(what = 0) and BEFORE (what = 1):
+ * d_Z [eliminated][lanes][nq][W] = D_i^-1[Q, Q] E_i of the blocks just eliminated, d_En [survivors][lanes][nq][(4 s - 1) hw] = the
+ * survivors' columns widened by their neighbours' terms.  last != 0: only d_Z for block 0 of every lane (d_E [1][lanes][nq][W]). */
+int iem_kkt_hub_level(iem_model *m, int64_t S, int64_t lane_len, int nb, int nc, const double *d_Dinv, const double *d_Bt, const int32_t *d_q, int nq,
+                      const int32_t *d_qr, int nr, const int32_t *d_qc, int ncq, int hw, int64_t s, const double *d_E, double *d_Z, double *d_En,
+                      int last);
 /* ... for factors made lane by lane (iem_kkt_chain_level with lane_len; ne must be 0 when lane_len != S) */
 int iem_kkt_chain_solve_lanes(iem_model *m, int64_t S, int64_t lane_len, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt,
                               const double *d_BR, const int32_t *d_rows, const int32_t *d_cols, const double *d_Z, double *d_r, double *d_z,

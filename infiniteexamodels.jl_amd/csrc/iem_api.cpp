@@ -209,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr; };
+  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1942,6 +1942,8 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.gather, km.mod, "kkt_gather"));
     HIP_TRY(hipModuleGetFunction(&km.move, km.mod, "kkt_move"));
     HIP_TRY(hipModuleGetFunction(&km.colsum, km.mod, "kkt_colsum"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_z, km.mod, "kkt_hub_z"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_widen, km.mod, "kkt_hub_widen"));
     it = m->kkt_mods.emplace(std::make_pair(nb, ne * 64 + nc), km).first;
   }
   *out = &it->second;
@@ -2013,6 +2015,27 @@ int iem_kkt_chain_level(iem_model *m, int64_t S, int64_t lane_len, int nb, int n
   const long long n_elim = lanes * ((T - s + 2 * s - 1) / (2 * s)), n_surv = lanes * ((T + 2 * s - 1) / (2 * s));
   if (what == 0) return kkt_launch_elim(m, km, A, n_elim);
   return kkt_launch(m, km->upd, A, n_surv, nc <= 8 ? 64u : nc <= 16 ? 128u : 256u);
+}
+
+/* The span-sparse border columns of HubChainKKT between two levels (csrc/iem_kkt_device.h: kkt_hub_z, kkt_hub_widen). */
+int iem_kkt_hub_level(iem_model *m, int64_t S, int64_t lane_len, int nb, int nc, const double *d_Dinv, const double *d_Bt, const int32_t *d_q, int nq,
+                      const int32_t *d_qr, int nr, const int32_t *d_qc, int ncq, int hw, int64_t s, const double *d_E, double *d_Z, double *d_En, int last) {
+  const long long T = lane_len > 0 ? lane_len : S;
+  if (!m || S < 1 || S % T || !d_Dinv || !d_Bt || !d_q || !d_qr || !d_qc || nq < 1 || nq > 24 || nr < 0 || ncq < 0 || nr > nc || ncq > nc || hw < 1 || s < 1 || !d_E || !d_Z ||
+      (!last && (!d_En || s >= T)))
+    return fail(IEM_E_ARG, "bad argument");
+  DevGuard dg_(m->device);
+  iem_model::KktMod *km = nullptr;
+  int rc = kkt_module(m, nb, 0, nc, &km);
+  if (rc) return rc;
+  struct { const double *D, *Bt, *E, *Z; double *out; const int *q, *qr, *qc; long long T, lanes, s, n_e, n_s; int nb, nc, nq, nr, ncq, hw, last; } A{
+      d_Dinv, d_Bt, d_E, nullptr, d_Z, d_q, d_qr, d_qc, T, S / T, (long long)s, 0, 0, nb, nc, nq, nr, ncq, hw, last ? 1 : 0};
+  const long long alive = (T + s - 1) / s, W = (2 * s - 1) * hw, W2 = (4 * s - 1) * hw;
+  A.n_e = alive / 2; A.n_s = alive - A.n_e;
+  const long long nz = (last ? 1 : A.n_e) * A.lanes * W;
+  if ((rc = kkt_launch_raw(m, km->hub_z, &A, sizeof A, (nz + 255) / 256, 256)) != IEM_OK || last) return rc;
+  A.Z = d_Z; A.out = d_En;
+  return kkt_launch_raw(m, km->hub_widen, &A, sizeof A, (A.n_s * A.lanes * W2 + 255) / 256, 256);
 }
 
 int iem_kkt_chain_solve(iem_model *m, int64_t S, int nb, int ne, int nc, const double *d_Dinv, const double *d_Bt, const double *d_BR,

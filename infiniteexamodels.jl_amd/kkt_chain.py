@@ -511,6 +511,7 @@ class HubChainKKT:
         self.E0 = t.zeros(Tp * self.lanes * nQ * hw, **f64)
         self._Q = as_t(Q)
         self._qR, self._qC = as_t(qidx[L.rowsR]), as_t(qidx[L.colsC])
+        self._q32, self._qR32, self._qC32 = (t.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev) for a in (Q, qidx[L.rowsR], qidx[L.colsC]))
         self.Sbig = t.zeros(self.Hp * self.Hp, **f64)
         pd = L.pad_positions()
         self._pad = as_t(pd[pd < self.S * self.nb * self.nb])          # the unit diagonal of the padding places (chain part)
@@ -569,6 +570,12 @@ class HubChainKKT:
         _lib.check(m._L.iem_kkt_chain_level(m._h, self.S, self.Tp, self.nb, self.nc, p(self.D), p(self.Bt), p(self.BR), p(self._rows), p(self._cols),
                                            p(self.info), float(tiny), int(s), int(what)))
 
+    def _hub_level(self, s, E, Z, En, last):
+        m = self.model
+        p = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
+        _lib.check(m._L.iem_kkt_hub_level(m._h, self.S, self.Tp, self.nb, self.nc, p(self.D), p(self.Bt), p(self._q32), self.nQ, p(self._qR32), int(self._qR32.numel()),
+                                         p(self._qC32), int(self._qC32.numel()), self.hw, int(s), p(E), p(Z), p(En), int(last)))
+
     def factor(self, clip_levels: int = 16, profile: Optional[dict] = None):
         """``profile``: a dict that receives the milliseconds spent per phase (synchronising: diagnosis only)."""
         t = self._torch
@@ -603,10 +610,15 @@ class HubChainKKT:
             ts_ = t.arange(0, Tp, 2 * s, device=self.device)      # ... survivors: the even ones (one more than eliminated when their count is odd)
             n_e, n_s = int(te.numel()), int(ts_.numel())
             Ee = E[1::2]                                        # [n_e, lanes, nQ, W]
-            Dq = D4[:, s::2 * s][:, :, qq].permute(1, 0, 2).reshape(n_e, lanes, nQ, nQ)    # (a strided view, then only the Q x Q entries are read)
-            Z = t.matmul(Dq, Ee)                                # (D_i^-1 E_i) on the rows Q
+            if self._levels is None:                            # Z = D_i^-1 E_i on the rows Q and the survivors' widened columns: two streaming kernels
+                Z = t.empty(n_e, lanes, nQ, W, dtype=t.float64, device=self.device)
+                En = t.empty(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device=self.device)
+                self._hub_level(s, E, Z, En, 0)
+            else:                                               # (the same in library calls: what the tests check the kernels' pipeline against)
+                Dq = D4[:, s::2 * s][:, :, qq].permute(1, 0, 2).reshape(n_e, lanes, nQ, nQ)
+                Z = t.matmul(Dq, Ee)
             A2, Z2 = Ee.reshape(n_e, lanes * nQ, W), Z.reshape(n_e, lanes * nQ, W)
-            tick("Z = Dinv E")
+            tick("Z = Dinv E, E widened" if self._levels is None else "Z = Dinv E")
             if n_e > clip_levels:                               # many small intervals: one batched product, written onto the diagonal blocks of S
                 Cm = t.bmm(A2.transpose(1, 2), Z2)
                 Sv = t.as_strided(self.Sbig, (n_e, W, W), (2 * s * hw * (Hp + 1), Hp, 1), hw * (Hp + 1))
@@ -619,16 +631,17 @@ class HubChainKKT:
                         continue
                     self._sub_lower(t.as_strided(self.Sbig, (w, w), (Hp, 1), h0 * (Hp + 1)), A2[mi][:, :w], Z2[mi][:, :w], h0)
             tick(f"S accumulate (levels of {'many' if n_e > clip_levels else 'few'} intervals)")
-            # the survivors t = 2ms: their border columns widen to the hubs of both neighbours
-            En = t.zeros(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device=self.device)
-            En[..., s * hw: s * hw + W] = E[0::2]
-            if n_s > 1:                                         # left neighbour p = j - s (the block eliminated just before j)
-                Bj = Bt[:, 2 * s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC]
-                upd = t.matmul(Bj, Z[:n_s - 1][:, :, Cc, :])    # Bt_j Z_p[C, :]
-                En[1:, :, R, 0:W] = En[1:, :, R, 0:W] - upd
-            Bq = Bt[:, s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC]  # K[q, j] on rows R of q = j + s, columns C of j
-            updr = t.matmul(Bq.transpose(-1, -2), Z[:, :, R, :])
-            En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] = En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] - updr
+            if self._levels is not None:
+                # the survivors t = 2ms: their border columns widen to the hubs of both neighbours
+                En = t.zeros(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device=self.device)
+                En[..., s * hw: s * hw + W] = E[0::2]
+                if n_s > 1:                                         # left neighbour p = j - s (the block eliminated just before j)
+                    Bj = Bt[:, 2 * s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC]
+                    upd = t.matmul(Bj, Z[:n_s - 1][:, :, Cc, :])    # Bt_j Z_p[C, :]
+                    En[1:, :, R, 0:W] = En[1:, :, R, 0:W] - upd
+                Bq = Bt[:, s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC]  # K[q, j] on rows R of q = j + s, columns C of j
+                updr = t.matmul(Bq.transpose(-1, -2), Z[:, :, R, :])
+                En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] = En[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] - updr
             E = En
             tick("E update")
             self._level(s, 1)                                   # fold the inverses into the survivors' blocks and couplings
@@ -638,7 +651,12 @@ class HubChainKKT:
         Ef = E[0][:, :, (s - 1) * hw: (s - 1) * hw + H]
         self._level(1, 2)
         tick("chain lane-final blocks")
-        Zf = t.matmul(D4[:, 0][:, qq].reshape(lanes, nQ, nQ), Ef)   # [lanes, nQ, H]
+        if self._levels is None:
+            Zfull = t.empty_like(E)
+            self._hub_level(s, E, Zfull, None, 1)
+            Zf = Zfull[0][:, :, (s - 1) * hw: (s - 1) * hw + H]
+        else:
+            Zf = t.matmul(D4[:, 0][:, qq].reshape(lanes, nQ, nQ), Ef)   # [lanes, nQ, H]
         Sv = t.as_strided(self.Sbig, (H, H), (Hp, 1), 0)
         self._sub_lower(Sv, Ef.reshape(lanes * nQ, H), Zf.reshape(lanes * nQ, H), 0)
         tick("S lane-final product")
@@ -652,11 +670,11 @@ class HubChainKKT:
         straddle: it reads the lower triangle and the pivot blocks' own squares, nothing else."""
         w = int(Sv.shape[0])
         if w <= 2 * chunk:
-            Sv -= A.transpose(0, 1) @ Z
+            Sv.addmm_(A.transpose(0, 1), Z, alpha=-1.0)
             return
         cuts = [0] + [b - h0 for b in range((h0 // chunk + 1) * chunk, h0 + w, chunk)] + [w]
         for c0, c1 in zip(cuts[:-1], cuts[1:]):
-            Sv[c0:, c0:c1] -= A[:, c0:].transpose(0, 1) @ Z[:, c0:c1]
+            Sv[c0:, c0:c1].addmm_(A[:, c0:].transpose(0, 1), Z[:, c0:c1], alpha=-1.0)
 
     # -- the hubs' Schur complement: block LDL' with 96 x 96 pivot blocks inverted by the chain solver's own kernel ------------
     LEAF = 96
@@ -702,7 +720,7 @@ class HubChainKKT:
                     A21.copy_(Sd[e:, k:e])
                     P = A21 @ blk[:w, :w]
                     if e < p1:
-                        Sd[e:, e:p1] -= P @ A21[:p1 - e].transpose(0, 1)
+                        Sd[e:, e:p1].addmm_(P, A21[:p1 - e].transpose(0, 1), alpha=-1.0)
                     Sd[e:, k:e] = P
             # the panel's own unit lower triangle, inverted once: a solve is then two matrix-vector products per panel instead of a
             # triangular solve over 5 000 dependent rows (1.4 ms each way in the library)
@@ -714,7 +732,7 @@ class HubChainKKT:
             self._Linv.append(X)
             for c0 in range(p1, n, CH):                              # the rest of the matrix, lower triangle only, once per panel
                 c1 = min(c0 + CH, n)
-                Sd[c0:, c0:c1] -= Sd[c0:, p0:p1] @ Wbuf[c0:c1, :p1 - p0].transpose(0, 1)
+                Sd[c0:, c0:c1].addmm_(Sd[c0:, p0:p1], Wbuf[c0:c1, :p1 - p0].transpose(0, 1), alpha=-1.0)
         self._dense_n, self._dense_steps = n, steps
 
     def _panel_mask(self, PW):

@@ -85,7 +85,7 @@ SYMBOLS = ["iem_create", "iem_create_opts", "iem_create_sharded", "iem_shard_inf
            "iem_destroy", "iem_meta", "iem_template_info", "iem_kernel_info", "iem_get_host", "iem_set_stream",
            "iem_synchronize", "iem_set_parameter", "iem_obj", "iem_obj_device", "iem_obj_begin", "iem_obj_end", "iem_grad", "iem_cons",
            "iem_jac_coord", "iem_hess_coord", "iem_jac_hess_coord", "iem_eval_trial", "iem_eval_accepted", "iem_eval_all", "iem_jprod", "iem_jtprod", "iem_hprod", "iem_jac_structure", "iem_hess_structure",
-           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_csr_spmv", "iem_kkt_chain_factor", "iem_kkt_chain_level", "iem_kkt_chain_solve", "iem_kkt_chain_solve_lanes", "iem_kkt_source", "iem_kkt_create", "iem_kkt_destroy", "iem_kkt_info", "iem_kkt_layout", "iem_kkt_analyse_blob", "iem_kkt_assemble", "iem_kkt_factor", "iem_kkt_solve", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
+           "iem_jac_structure_device", "iem_hess_structure_device", "iem_csr_values", "iem_csr_values32", "iem_csr_spmv", "iem_kkt_chain_factor", "iem_kkt_chain_level", "iem_kkt_hub_level", "iem_kkt_chain_solve", "iem_kkt_chain_solve_lanes", "iem_kkt_source", "iem_kkt_create", "iem_kkt_destroy", "iem_kkt_info", "iem_kkt_layout", "iem_kkt_analyse_blob", "iem_kkt_assemble", "iem_kkt_factor", "iem_kkt_solve", "iem_emit_source", "iem_emit_launch_plan", "iem_blob_hess_structure", "iem_blob_array", "iem_free",
            "iem_set_option", "iem_time_kernels", "iem_tuner_choice", "iem_tune", "iem_last_error", "iem_version"]
 
 
@@ -167,6 +167,7 @@ def lib():
     L.iem_csr_spmv.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64, vp]
     L.iem_kkt_chain_factor.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, dbl]
     L.iem_kkt_chain_level.argtypes = [vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp, dbl, i64, i32]
+    L.iem_kkt_hub_level.argtypes = [vp, i64, i64, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, i32]
     L.iem_kkt_chain_solve.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     L.iem_kkt_chain_solve_lanes.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     L.iem_kkt_source.argtypes = [i32, i32, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
