@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process A/B of generator knobs for ONE evaluation kind (cons, grad, jac, hess): every variant built in this process,
+"""In-process A/B of generator knobs for ONE evaluation kind (obj, cons, grad, jac, hess): every variant built in this process,
 timed in blocks of back-to-back launches between one event pair, alternating, three rounds.
 
   python tools/kind_ab.py cons "block=0" "block=256" "lds_slots=48" ...      (IEM_AB_WORKLOAD / IEM_AB_SUPPORTS as ab_inproc.py)
@@ -30,14 +30,14 @@ if WL == "pandemic":
     x = np.abs(x) + 0.05
 y = np.random.default_rng(1).standard_normal(gm.meta.ncon)
 xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
-n_out = {"cons": gm.meta.ncon, "grad": gm.meta.nvar, "jac": gm.meta.nnzj, "hess": gm.meta.nnzh}[kind]
+n_out = {"cons": gm.meta.ncon, "grad": gm.meta.nvar, "jac": gm.meta.nnzj, "hess": gm.meta.nnzh, "obj": 1}[kind]
 bufs = [torch.empty(n_out, dtype=torch.float64, device="cuda") for _ in range(3)]
 p = lambda a: C.c_void_p(a.data_ptr())
 
 
 def call(m, out):
     L, h = m._L, m._h
-    return {"cons": lambda: L.iem_cons(h, p(xd), p(out)), "grad": lambda: L.iem_grad(h, p(xd), p(out)), "jac": lambda: L.iem_jac_coord(h, p(xd), p(out)),
+    return {"obj": lambda: L.iem_obj_device(h, p(xd), p(out)), "cons": lambda: L.iem_cons(h, p(xd), p(out)), "grad": lambda: L.iem_grad(h, p(xd), p(out)), "jac": lambda: L.iem_jac_coord(h, p(xd), p(out)),
             "hess": lambda: L.iem_hess_coord(h, p(xd), p(yd), 1.0, p(out))}[kind]
 
 
