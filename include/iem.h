@@ -332,6 +332,11 @@ typedef struct iem_kkt iem_kkt;
 typedef struct {
   int64_t S, n, n_border, block_doubles;   /* blocks, unknowns, border unknowns, doubles of the block buffer D | Bt | E | G */
   int32_t nb, ne, nc, reach, group, phase;
+  /* 2-D support grids: lanes > 1 = one chain per point of the other parameter; hubs != 0 = the border (n_border unknowns, ne = 0
+   * for the kernels) is kept as span-sparse hub columns: hubs_per_block of them per time block, hub_rows local rows of a block
+   * ever hold a border entry, the hubs' Schur complement is a dense matrix with rows of hub_ld doubles */
+  int64_t lanes, hub_ld;
+  int32_t hubs, hub_rows, hubs_per_block, reserved_;
 } iem_kkt_info_t;
 int iem_kkt_create(iem_model *m, int group /* 0: the parameter group the stencil runs along */, iem_kkt **out);
 int iem_kkt_destroy(iem_kkt *k);

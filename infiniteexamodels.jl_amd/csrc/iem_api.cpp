@@ -209,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr; };
+  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1944,6 +1944,9 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.colsum, km.mod, "kkt_colsum"));
     HIP_TRY(hipModuleGetFunction(&km.hub_z, km.mod, "kkt_hub_z"));
     HIP_TRY(hipModuleGetFunction(&km.hub_widen, km.mod, "kkt_hub_widen"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_mask, km.mod, "kkt_hub_mask"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_ety, km.mod, "kkt_hub_ety"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_ex, km.mod, "kkt_hub_ex"));
     it = m->kkt_mods.emplace(std::make_pair(nb, ne * 64 + nc), km).first;
   }
   *out = &it->second;
@@ -2098,6 +2101,28 @@ struct iem_kkt {
   int64_t n_dest = 0, n_on = 0, n_h = 0, n_j = 0;
   std::vector<double> Gs;        // the border's Schur complement (host), set by iem_kkt_factor
   bool factored = false;
+  struct KktHub *hub = nullptr;  // hub mode (L.hubs): the span-sparse border's buffers and the library handle of its GEMMs
+};
+
+// rocBLAS for the plain library GEMMs / GEMVs of the hubs' Schur complement — loaded on first use (dlopen), so that the library
+// does not depend on it for anything else
+struct RocBlas {
+  void *lib = nullptr, *handle = nullptr;
+  int (*create)(void **) = nullptr;
+  int (*destroy)(void *) = nullptr;
+  int (*set_stream)(void *, hipStream_t) = nullptr;
+  int (*dgemm)(void *, int, int, int, int, int, const double *, const double *, int, const double *, int, const double *, double *, int) = nullptr;
+  int (*dgemm_sb)(void *, int, int, int, int, int, const double *, const double *, int, long long, const double *, int, long long, const double *, double *, int, long long, int) = nullptr;
+  int (*dgemv)(void *, int, int, int, const double *, const double *, int, const double *, int, const double *, double *, int) = nullptr;
+  int (*dgemv_sb)(void *, int, int, int, const double *, const double *, int, long long, const double *, int, long long, const double *, double *, int, long long, int) = nullptr;
+};
+struct KktHub {
+  RocBlas bl;
+  int32_t *d_q = nullptr, *d_qr = nullptr, *d_qc = nullptr;
+  double *E[2] = {nullptr, nullptr}, *Z = nullptr, *Sd = nullptr, *Wbuf = nullptr, *Dinv = nullptr, *Linv = nullptr, *Nmat = nullptr, *X[2] = {nullptr, nullptr}, *eye96 = nullptr,
+         *eyeP = nullptr, *x = nullptr, *w = nullptr, *tmp = nullptr, *r2 = nullptr;
+  long long *d_dinfo = nullptr;
+  int64_t e_cap = 0, steps = 0, npanels = 0;
 };
 
 namespace {
@@ -2127,6 +2152,279 @@ int kkt_colsum_host(iem_kkt *k, const double *d_in, int64_t rows, int64_t w, std
 }
 }  // namespace
 
+
+/* ---- hub mode of the KKT object: a laned 2-D grid whose border is kept as span-sparse hub columns (kkt_chain.HubChainKKT is the
+ * Python-held form of the same pipeline; tests compare the two) ---------------------------------------------------------------- */
+namespace {
+constexpr int HUB_LEAF = 96, HUB_PW = 5 * HUB_LEAF, HUB_CH = 10 * HUB_LEAF, HUB_CLIP = 16;
+constexpr int RB_N = 111, RB_T = 112;      // rocblas_operation_none / _transpose
+int hub_blas_load(iem_kkt *k) {
+  RocBlas &b = k->hub->bl;
+  if (b.handle) return IEM_OK;
+  b.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!b.lib) b.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!b.lib) return fail(IEM_E_HIP, std::string("chain KKT (hub border): cannot load librocblas.so (") + dlerror() + ")");
+  auto sym = [&](const char *n) { return dlsym(b.lib, n); };
+  b.create = (decltype(b.create))sym("rocblas_create_handle");
+  b.destroy = (decltype(b.destroy))sym("rocblas_destroy_handle");
+  b.set_stream = (decltype(b.set_stream))sym("rocblas_set_stream");
+  b.dgemm = (decltype(b.dgemm))sym("rocblas_dgemm");
+  b.dgemm_sb = (decltype(b.dgemm_sb))sym("rocblas_dgemm_strided_batched");
+  b.dgemv = (decltype(b.dgemv))sym("rocblas_dgemv");
+  b.dgemv_sb = (decltype(b.dgemv_sb))sym("rocblas_dgemv_strided_batched");
+  if (!b.create || !b.destroy || !b.set_stream || !b.dgemm || !b.dgemm_sb || !b.dgemv || !b.dgemv_sb) return fail(IEM_E_HIP, "chain KKT (hub border): librocblas.so lacks an entry point");
+  if (b.create(&b.handle) != 0) return fail(IEM_E_HIP, "rocblas_create_handle");
+  if (b.set_stream(b.handle, k->m->stream) != 0) return fail(IEM_E_HIP, "rocblas_set_stream");
+  return IEM_OK;
+}
+#define RB_TRY(call) do { if ((call) != 0) return fail(IEM_E_HIP, "rocBLAS call failed: " #call); } while (0)
+// ROW-MAJOR  C[m x n] = alpha op(A) op(B) + beta C   through the column-major library (C' = op(B)' op(A)')
+int gemm_rm(iem_kkt *k, bool ta, bool tb, int64_t m, int64_t n, int64_t kk, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc) {
+  if (m <= 0 || n <= 0) return IEM_OK;
+  RB_TRY(k->hub->bl.dgemm(k->hub->bl.handle, tb ? RB_T : RB_N, ta ? RB_T : RB_N, (int)n, (int)m, (int)kk, &alpha, B, (int)ldb, A, (int)lda, &beta, C, (int)ldc));
+  return IEM_OK;
+}
+// ROW-MAJOR  y = alpha op(A) x + beta y,  A [m x n]
+int gemv_rm(iem_kkt *k, bool ta, int64_t m, int64_t n, double alpha, const double *A, int64_t lda, const double *x, double beta, double *y) {
+  if (m <= 0 || n <= 0) return IEM_OK;
+  RB_TRY(k->hub->bl.dgemv(k->hub->bl.handle, ta ? RB_N : RB_T, (int)n, (int)m, &alpha, A, (int)lda, x, 1, &beta, y, 1));
+  return IEM_OK;
+}
+int copy2d(iem_kkt *k, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return IEM_OK;
+  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)lds * 8, (size_t)cols * 8, (size_t)rows, hipMemcpyDeviceToDevice, k->m->stream));
+  return IEM_OK;
+}
+// Sv -= A' Z  (symmetric; Sv: w x w at hub h0 of the Schur complement, row length ld; A, Z: K x w, row length ldw): wide products only
+// into the block lower triangle, column chunks cut at the multiples of HUB_CH hubs (the pivot blocks of the LDL' never straddle them)
+int hub_sub_lower(iem_kkt *k, double *Sv, int64_t ld, const double *A, const double *Z, int64_t ldw, int64_t K, int64_t w, int64_t h0) {
+  if (w <= 2 * HUB_CH) return gemm_rm(k, true, false, w, w, K, -1.0, A, ldw, Z, ldw, 1.0, Sv, ld);
+  int64_t c0 = 0;
+  while (c0 < w) {
+    const int64_t c1 = std::min<int64_t>(w, ((h0 + c0) / HUB_CH + 1) * HUB_CH - h0);
+    int rc = gemm_rm(k, true, false, w - c0, c1 - c0, K, -1.0, A + c0, ldw, Z + c0, ldw, 1.0, Sv + c0 * ld + c0, ld);
+    if (rc) return rc;
+    c0 = c1;
+  }
+  return IEM_OK;
+}
+int hub_level_launch(iem_kkt *k, int64_t s, const double *E, double *Z, double *En, int last) {
+  const iem::KktLayout &L = k->L;
+  return iem_kkt_hub_level(k->m, L.S, L.Tp, L.nb, L.nc, k->d_flat + L.oD(), k->d_flat + L.oB(), k->hub->d_q, L.nq, k->hub->d_qr, L.nr, k->hub->d_qc, L.ncq, (int)L.hw, s, E, Z, En, last);
+}
+int hub_alloc(iem_kkt *k) {
+  const iem::KktLayout &L = k->L;
+  KktHub *h = k->hub = new KktHub;
+  int rc;
+  if ((rc = kkt_upload(&h->d_q, L.Q)) || (rc = kkt_upload(&h->d_qr, L.qR)) || (rc = kkt_upload(&h->d_qc, L.qC))) return rc;
+  const int64_t per = L.lanes * L.nq;
+  int64_t cap = L.Tp * L.hw, P = 1;
+  for (int64_t s = 1; s < L.Tp; s *= 2) {
+    const int64_t alive = (L.Tp + s - 1) / s, ns = alive - alive / 2;
+    cap = std::max(cap, std::max(alive * (2 * s - 1), ns * (4 * s - 1)) * L.hw);
+    P = 2 * s;
+  }
+  cap = std::max(cap, (2 * P - 1) * L.hw);
+  h->e_cap = cap * per;
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&h->E[i], (size_t)h->e_cap * 8));
+  HIP_TRY(hipMalloc((void **)&h->Z, (size_t)h->e_cap * 8));
+  const int64_t H = L.H;
+  h->steps = (H + HUB_LEAF - 1) / HUB_LEAF; h->npanels = (H + HUB_PW - 1) / HUB_PW;
+  HIP_TRY(hipMalloc((void **)&h->Sd, (size_t)(H * H) * 8));
+  HIP_TRY(hipMalloc((void **)&h->Wbuf, (size_t)(H * HUB_PW) * 8));
+  HIP_TRY(hipMalloc((void **)&h->Dinv, (size_t)(h->steps * HUB_LEAF * HUB_LEAF) * 8));
+  HIP_TRY(hipMalloc((void **)&h->Linv, (size_t)(h->npanels * HUB_PW * HUB_PW) * 8));
+  HIP_TRY(hipMalloc((void **)&h->Nmat, (size_t)(HUB_PW * HUB_PW) * 8));
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&h->X[i], (size_t)(HUB_PW * HUB_PW) * 8));
+  std::vector<double> eye((size_t)(HUB_PW * HUB_PW), 0.0), eye96((size_t)(HUB_LEAF * HUB_LEAF), 0.0);
+  for (int i = 0; i < HUB_PW; ++i) eye[(size_t)(i * HUB_PW + i)] = 1.0;
+  for (int i = 0; i < HUB_LEAF; ++i) eye96[(size_t)(i * HUB_LEAF + i)] = 1.0;
+  if ((rc = kkt_upload(&h->eyeP, eye)) || (rc = kkt_upload(&h->eye96, eye96))) return rc;
+  const int64_t hv = std::max<int64_t>(h->steps * HUB_LEAF, L.Tp * L.hw);
+  HIP_TRY(hipMalloc((void **)&h->x, (size_t)hv * 8));
+  HIP_TRY(hipMalloc((void **)&h->w, (size_t)hv * 8));
+  HIP_TRY(hipMalloc((void **)&h->tmp, (size_t)HUB_PW * 8));
+  HIP_TRY(hipMalloc((void **)&h->r2, (size_t)(L.S * L.nb) * 8));
+  HIP_TRY(hipMalloc((void **)&h->d_dinfo, (size_t)(h->steps * 3) * 8));
+  return IEM_OK;
+}
+void hub_free(iem_kkt *k) {
+  KktHub *h = k->hub;
+  if (!h) return;
+  for (void *p : {(void *)h->d_q, (void *)h->d_qr, (void *)h->d_qc, (void *)h->E[0], (void *)h->E[1], (void *)h->Z, (void *)h->Sd, (void *)h->Wbuf, (void *)h->Dinv, (void *)h->Linv,
+                  (void *)h->Nmat, (void *)h->X[0], (void *)h->X[1], (void *)h->eye96, (void *)h->eyeP, (void *)h->x, (void *)h->w, (void *)h->tmp, (void *)h->r2, (void *)h->d_dinfo})
+    if (p) hipFree(p);
+  if (h->bl.handle && h->bl.destroy) h->bl.destroy(h->bl.handle);
+  delete h;
+  k->hub = nullptr;
+}
+// the hubs' Schur complement Sd (H x H, row-major, lower triangle + the pivot blocks' squares valid): block LDL' in panels of HUB_PW,
+// pivot blocks of HUB_LEAF inverted by kkt_eliminate (which counts their pivot signs)
+int hub_dense_factor(iem_kkt *k) {
+  const iem::KktLayout &L = k->L;
+  KktHub *h = k->hub;
+  iem_model *m = k->m;
+  const int64_t n = L.H;
+  double *Sd = h->Sd;
+  int rc;
+  HIP_TRY(hipMemsetAsync(h->d_dinfo, 0, (size_t)(h->steps * 3) * 8, m->stream));
+  for (int64_t p0 = 0, pi = 0; p0 < n; p0 += HUB_PW, ++pi) {
+    const int64_t p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
+    for (int64_t kk = p0; kk < p1; kk += HUB_LEAF) {
+      const int64_t e = std::min<int64_t>(kk + HUB_LEAF, p1), w = e - kk, ki = kk / HUB_LEAF;
+      double *blk = h->Dinv + ki * HUB_LEAF * HUB_LEAF;
+      HIP_TRY(hipMemcpyAsync(blk, h->eye96, (size_t)(HUB_LEAF * HUB_LEAF) * 8, hipMemcpyDeviceToDevice, m->stream));     // (a short last block: unit diagonal, positive pivots)
+      if ((rc = copy2d(k, blk, HUB_LEAF, Sd + kk * n + kk, n, w, w))) return rc;
+      {   // in-place inverse + pivot signs: one block, no chain, no border (iem_kkt_chain_factor's S = 1 case without its memset of all counters)
+        iem_model::KktMod *km = nullptr;
+        if ((rc = kkt_module(m, HUB_LEAF, 0, 4, &km))) return rc;
+        KktArgsH A{blk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->d_dinfo + 3 * ki, 1, 1, 2, 1e-30};
+        if ((rc = kkt_launch_elim(m, km, A, 1))) return rc;
+      }
+      if (e < n) {
+        double *A21 = h->Wbuf + e * HUB_PW + (kk - p0);      // rows e.., the block's columns: L21 D (the columns before scaling)
+        if ((rc = copy2d(k, A21, HUB_PW, Sd + e * n + kk, n, n - e, w))) return rc;
+        if ((rc = gemm_rm(k, false, false, n - e, w, w, 1.0, A21, HUB_PW, blk, HUB_LEAF, 0.0, Sd + e * n + kk, n))) return rc;                       // P = A21 D^-1
+        if (e < p1 && (rc = gemm_rm(k, false, true, n - e, p1 - e, w, -1.0, Sd + e * n + kk, n, A21, HUB_PW, 1.0, Sd + e * n + e, n))) return rc;    // the panel's own columns
+      }
+    }
+    {   // the panel's unit lower triangle L_pp = I + N (N strictly block lower: N^5 = 0), inverted once: (I + N)^-1 = I - N (I - N (I - ...))
+      struct { const double *src; double *N, *X; long long ld; int pw, ldp, leaf; } A{Sd + p0 * n + p0, h->Nmat, h->X[0], (long long)n, (int)pw, HUB_PW, HUB_LEAF};
+      if ((rc = kkt_launch_raw(m, k->km->hub_mask, &A, sizeof A, (pw * pw + 255) / 256, 256))) return rc;
+      int cur = 0;
+      for (int64_t it = 0; it < (pw - 1) / HUB_LEAF - 1; ++it) {
+        HIP_TRY(hipMemcpyAsync(h->X[1 - cur], h->eyeP, (size_t)(HUB_PW * HUB_PW) * 8, hipMemcpyDeviceToDevice, m->stream));
+        if ((rc = gemm_rm(k, false, false, pw, pw, pw, -1.0, h->Nmat, HUB_PW, h->X[cur], HUB_PW, 1.0, h->X[1 - cur], HUB_PW))) return rc;
+        cur = 1 - cur;
+      }
+      HIP_TRY(hipMemcpyAsync(h->Linv + pi * HUB_PW * HUB_PW, h->X[cur], (size_t)(HUB_PW * HUB_PW) * 8, hipMemcpyDeviceToDevice, m->stream));
+    }
+    for (int64_t c0 = p1; c0 < n; c0 += HUB_CH) {   // the rest of the matrix, lower triangle only, once per panel (inner dimension = the panel's width)
+      const int64_t c1 = std::min<int64_t>(c0 + HUB_CH, n);
+      if ((rc = gemm_rm(k, false, true, n - c0, c1 - c0, pw, -1.0, Sd + c0 * n + p0, n, h->Wbuf + c0 * HUB_PW, HUB_PW, 1.0, Sd + c0 * n + c0, n))) return rc;
+    }
+  }
+  return IEM_OK;
+}
+// x (H) in place: S x = b with the factors above
+int hub_dense_solve(iem_kkt *k, double *x) {
+  const iem::KktLayout &L = k->L;
+  KktHub *h = k->hub;
+  iem_model *m = k->m;
+  const int64_t n = L.H;
+  int rc;
+  for (int64_t p0 = 0, pi = 0; p0 < n; p0 += HUB_PW, ++pi) {       // L z = b
+    const int64_t p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
+    if ((rc = gemv_rm(k, false, pw, pw, 1.0, h->Linv + pi * HUB_PW * HUB_PW, HUB_PW, x + p0, 0.0, h->tmp))) return rc;
+    HIP_TRY(hipMemcpyAsync(x + p0, h->tmp, (size_t)pw * 8, hipMemcpyDeviceToDevice, m->stream));
+    if (p1 < n && (rc = gemv_rm(k, false, n - p1, pw, -1.0, h->Sd + p1 * n + p0, n, x + p0, 1.0, x + p1))) return rc;
+  }
+  {   // D^-1: one 96 x 96 product per pivot block (x is padded up to the last whole block with zeros)
+    const double one = 1.0, zero = 0.0;
+    if (h->steps * HUB_LEAF > n) HIP_TRY(hipMemsetAsync(x + n, 0, (size_t)(h->steps * HUB_LEAF - n) * 8, m->stream));
+    RB_TRY(h->bl.dgemv_sb(h->bl.handle, RB_T, HUB_LEAF, HUB_LEAF, &one, h->Dinv, HUB_LEAF, (long long)HUB_LEAF * HUB_LEAF, x, 1, HUB_LEAF, &zero, h->w, 1, HUB_LEAF, (int)h->steps));
+  }
+  double *w = h->w;
+  for (int64_t pi = h->npanels - 1; pi >= 0; --pi) {               // L' x = w
+    const int64_t p0 = pi * HUB_PW, p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
+    if (p1 < n && (rc = gemv_rm(k, true, n - p1, pw, -1.0, h->Sd + p1 * n + p0, n, w + p1, 1.0, w + p0))) return rc;
+    if ((rc = gemv_rm(k, true, pw, pw, 1.0, h->Linv + pi * HUB_PW * HUB_PW, HUB_PW, w + p0, 0.0, h->tmp))) return rc;
+    HIP_TRY(hipMemcpyAsync(w + p0, h->tmp, (size_t)pw * 8, hipMemcpyDeviceToDevice, m->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(x, w, (size_t)n * 8, hipMemcpyDeviceToDevice, m->stream));
+  return IEM_OK;
+}
+int hub_factor(iem_kkt *k, int64_t *out_inertia) {
+  const iem::KktLayout &L = k->L;
+  KktHub *h = k->hub;
+  iem_model *m = k->m;
+  int rc;
+  if ((rc = hub_blas_load(k))) return rc;
+  double *D = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB(), *E0 = k->d_flat + L.oE(), *Sbig = k->d_flat + L.oG();
+  const int64_t Tp = L.Tp, hw = L.hw, Hp = L.Hp, H = L.H, K = L.lanes * L.nq;
+  auto level = [&](int64_t s, int what) { return iem_kkt_chain_level(m, L.S, Tp, L.nb, L.nc, D, Bt, k->d_BR, k->d_rows, k->d_cols, (int64_t *)k->d_info, 1e-30, s, what); };
+  if ((rc = level(1, 3))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->E[0], E0, (size_t)(Tp * K * hw) * 8, hipMemcpyDeviceToDevice, m->stream));
+  int cur = 0;
+  int64_t s = 1;
+  for (; s < Tp; s *= 2) {
+    if ((rc = level(s, 0))) return rc;                                      // D of the blocks t = (2a+1)s now holds their inverses
+    const int64_t alive = (Tp + s - 1) / s, n_e = alive / 2, W = (2 * s - 1) * hw;
+    const double *E = h->E[cur];
+    if ((rc = hub_level_launch(k, s, E, h->Z, h->E[1 - cur], 0))) return rc;   // Z = D^-1[Q, Q] E of the eliminated, the survivors' widened columns
+    if (n_e > HUB_CLIP) {                                                     // many small intervals: one batched product onto disjoint diagonal blocks of S
+      const double alpha = -1.0, beta = 1.0;
+      // row-major C_i -= A_i' Z_i  ==  column-major  C_i' -= Z_i(c) A_i(c)'   with X(c) = X' (W x K, leading dimension W)
+      RB_TRY(h->bl.dgemm_sb(h->bl.handle, RB_N, RB_T, (int)W, (int)W, (int)K, &alpha, h->Z, (int)W, (long long)(K * W), E + K * W, (int)W, (long long)(2 * K * W), &beta,
+                            Sbig + hw * (Hp + 1), (int)Hp, (long long)(2 * s * hw * (Hp + 1)), (int)n_e));
+    } else {                                                                  // few wide ones: clipped to the hubs that exist
+      for (int64_t mi = 0; mi < n_e; ++mi) {
+        const int64_t te = (2 * mi + 1) * s, h0 = (te - s + 1) * hw, w = std::min<int64_t>(W, H - h0);
+        if (w <= 0) continue;
+        if ((rc = hub_sub_lower(k, Sbig + h0 * (Hp + 1), Hp, E + (2 * mi + 1) * K * W, h->Z + mi * K * W, W, K, w, h0))) return rc;
+      }
+    }
+    cur = 1 - cur;
+    if ((rc = level(s, 1))) return rc;                                      // fold the inverses into the survivors' blocks and couplings
+  }
+  // one block per lane is left (t = 0), coupled to every hub (s is the power of two the levels stopped at)
+  if ((rc = level(1, 2))) return rc;
+  {
+    const int64_t W = (2 * s - 1) * hw;
+    if ((rc = hub_level_launch(k, s, h->E[cur], h->Z, nullptr, 1))) return rc;
+    if ((rc = hub_sub_lower(k, Sbig, Hp, h->E[cur] + (s - 1) * hw, h->Z + (s - 1) * hw, W, K, H, 0))) return rc;
+  }
+  if ((rc = copy2d(k, h->Sd, H, Sbig, Hp, H, H))) return rc;
+  if ((rc = hub_dense_factor(k))) return rc;
+  long long info[3] = {0, 0, 0};
+  std::vector<long long> dinfo((size_t)(h->steps * 3));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipMemcpy(info, k->d_info, 24, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dinfo.data(), h->d_dinfo, dinfo.size() * 8, hipMemcpyDeviceToHost));
+  int64_t neg = info[0], doubtful = info[1];
+  for (int64_t i = 0; i < h->steps; ++i) { neg += dinfo[(size_t)(3 * i)]; doubtful += dinfo[(size_t)(3 * i + 1)]; }
+  k->factored = true;
+  if (out_inertia) { out_inertia[0] = L.nvar + L.ncon - neg; out_inertia[1] = neg; out_inertia[2] = doubtful; }
+  return IEM_OK;
+}
+int hub_solve(iem_kkt *k, const double *d_rhs, double *d_sol) {
+  const iem::KktLayout &L = k->L;
+  KktHub *h = k->hub;
+  iem_model *m = k->m;
+  int rc;
+  const double *Dinv = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB(), *E0 = k->d_flat + L.oE();
+  struct Mv { double *dst; const double *src; const long long *di, *si; long long n; };
+  struct Vec { const double *E0, *v; double *out; const int *q; long long T, lanes; int nb, nq, hw; };
+  const size_t rbytes = (size_t)(L.S * L.nb) * 8;
+  auto chain = [&](double *r) {
+    int e = iem_kkt_chain_solve_lanes(m, L.S, L.Tp, L.nb, 0, L.nc, Dinv, Bt, k->d_BR, k->d_rows, k->d_cols, nullptr, r, k->d_z, nullptr, nullptr, 0);
+    return e ? e : iem_kkt_chain_solve_lanes(m, L.S, L.Tp, L.nb, 0, L.nc, Dinv, Bt, k->d_BR, k->d_rows, k->d_cols, nullptr, r, k->d_z, nullptr, nullptr, 1);
+  };
+  HIP_TRY(hipMemsetAsync(h->r2, 0, rbytes, m->stream));
+  { Mv A{h->r2, d_rhs, k->d_pos, k->d_on, (long long)k->n_on}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (k->n_on + 255) / 256, 256))) return rc; }
+  HIP_TRY(hipMemcpyAsync(k->d_r, h->r2, rbytes, hipMemcpyDeviceToDevice, m->stream));
+  if ((rc = chain(k->d_r))) return rc;                                       // y = K_c^-1 r_c
+  // r_B - E' y on the hubs, the dense solve, then x_c = K_c^-1 (r_c - E x_B)
+  HIP_TRY(hipMemsetAsync(h->x, 0, (size_t)std::max<int64_t>(h->steps * HUB_LEAF, L.Tp * L.hw) * 8, m->stream));
+  { Mv A{h->x, d_rhs, k->d_bloc, k->d_border, (long long)L.n_border}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (L.n_border + 255) / 256, 256))) return rc; }
+  { Vec A{E0, k->d_r, h->x, h->d_q, (long long)L.Tp, (long long)L.lanes, L.nb, L.nq, (int)L.hw}; if ((rc = kkt_launch_raw(m, k->km->hub_ety, &A, sizeof A, L.Tp, 64))) return rc; }
+  if ((rc = hub_dense_solve(k, h->x))) return rc;
+  if (L.Tp * L.hw > L.H) HIP_TRY(hipMemsetAsync(h->x + L.H, 0, (size_t)(L.Tp * L.hw - L.H) * 8, m->stream));
+  { Vec A{E0, h->x, h->r2, h->d_q, (long long)L.Tp, (long long)L.lanes, L.nb, L.nq, (int)L.hw};
+    if ((rc = kkt_launch_raw(m, k->km->hub_ex, &A, sizeof A, (L.Tp * L.lanes * L.nq + 255) / 256, 256))) return rc; }
+  if ((rc = chain(h->r2))) return rc;
+  { Mv A{d_sol, h->r2, k->d_on, k->d_pos, (long long)k->n_on}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (k->n_on + 255) / 256, 256))) return rc; }
+  { Mv A{d_sol, h->x, k->d_border, k->d_bloc, (long long)L.n_border}; if ((rc = kkt_launch_raw(m, k->km->move, &A, sizeof A, (L.n_border + 255) / 256, 256))) return rc; }
+  return IEM_OK;
+}
+}  // namespace
+
+static void kkt_fill_info(const iem::KktLayout &L, iem_kkt_info_t *out) {
+  out->S = L.S; out->n = L.nvar + L.ncon; out->n_border = L.n_border; out->nb = L.nb; out->ne = L.ne; out->nc = L.nc;
+  out->reach = L.reach; out->group = L.group; out->phase = L.phase; out->block_doubles = L.total();
+  out->lanes = L.lanes; out->hub_ld = L.Hp; out->hubs = L.hubs ? 1 : 0; out->hub_rows = L.nq; out->hubs_per_block = (int32_t)L.hw; out->reserved_ = 0;
+}
+
 int iem_kkt_analyse_blob(const void *blob, size_t nbytes, int group, iem_kkt_info_t *info, int64_t **out_blk, int64_t **out_loc, int32_t **out_rows,
                          int32_t **out_cols, int64_t **out_dest, uint32_t **out_seg, uint32_t **out_perm, int64_t *out_n_dest, int64_t *out_n_perm) {
   if (!blob || !info) return fail(IEM_E_ARG, "null argument");
@@ -2136,10 +2434,9 @@ int iem_kkt_analyse_blob(const void *blob, size_t nbytes, int group, iem_kkt_inf
     std::vector<int64_t> jr((size_t)M.nnzj), jc((size_t)M.nnzj), hr((size_t)M.nnzh), hc((size_t)M.nnzh);
     jac_structure_host(M, jr.data(), jc.data(), 0);
     hess_structure_host(M, hr.data(), hc.data(), 0);
-    iem::KktLayout L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 128, 48);
+    iem::KktLayout L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 128, 48, true);
     iem::KktPlan P = iem::kkt_plan(L, hr, hc, jr, jc);
-    info->S = L.S; info->n = L.nvar + L.ncon; info->n_border = L.n_border; info->nb = L.nb; info->ne = L.ne; info->nc = L.nc;
-    info->reach = L.reach; info->group = L.group; info->phase = L.phase; info->block_doubles = L.total();
+    kkt_fill_info(L, info);
     auto dup = [](const void *src, size_t bytes) { void *p = std::malloc(std::max<size_t>(bytes, 8)); if (bytes) std::memcpy(p, src, bytes); return p; };
     if (out_blk) *out_blk = (int64_t *)dup(L.blk.data(), L.blk.size() * 8);
     if (out_loc) *out_loc = (int64_t *)dup(L.loc.data(), L.loc.size() * 8);
@@ -2169,7 +2466,7 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
     jac_structure_host(M, jr.data(), jc.data(), 0);
     if (m->opt.hess_merge) return fail(IEM_E_ARG, "iem_kkt_create: the merged Hessian layout is not supported here");
     hess_structure_host(M, hr.data(), hc.data(), 0);
-    k->L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 128, 48);
+    k->L = iem::kkt_layout(M, jr, jc, hr, hc, group, 96, 128, 48, true);
     if (!kkt_fits(k->L.nb, k->L.ne, k->L.nc)) return fail(IEM_E_ARG, "chain KKT: the tiles of a block do not fit the LDS of a CU");
     iem::KktPlan P = iem::kkt_plan(k->L, hr, hc, jr, jc);
     k->n_dest = (int64_t)P.dest.size(); k->n_h = P.n_h; k->n_j = P.n_j;
@@ -2179,7 +2476,7 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
     std::vector<long long> dest(P.dest.begin(), P.dest.end()), on, pos, border, bloc;
     for (int64_t u = 0; u < L.nvar + L.ncon; ++u) {
       if (L.blk[(size_t)u] >= 0) { on.push_back(u); pos.push_back(L.blk[(size_t)u] * L.nb + L.loc[(size_t)u]); }
-      else { border.push_back(u); bloc.push_back(L.loc[(size_t)u]); }
+      else { border.push_back(u); bloc.push_back(L.hubs ? L.hub_of[(size_t)u] : L.loc[(size_t)u]); }
     }
     k->n_on = (int64_t)on.size();
     if ((rc = kkt_upload(&k->d_dest, dest)) || (rc = kkt_upload(&k->d_seg, P.seg)) || (rc = kkt_upload(&k->d_perm, P.perm)) || (rc = kkt_upload(&k->d_on, on)) ||
@@ -2197,6 +2494,7 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
     HIP_TRY(hipMalloc((void **)&k->d_xB, (size_t)std::max<int64_t>(ne, 1) * 8));
     HIP_TRY(hipMalloc((void **)&k->d_part, (size_t)(513 * std::max<int64_t>(ne * ne, 1)) * 8));      // kkt_colsum_host: 512 partial rows + the result
     HIP_TRY(hipMalloc((void **)&k->d_info, 32));
+    if (L.hubs && (rc = hub_alloc(k.get()))) return rc;
   } catch (const std::exception &e) {
     return fail(IEM_E_ARG, e.what());
   }
@@ -2207,6 +2505,7 @@ int iem_kkt_create(iem_model *m, int group, iem_kkt **out) {
 int iem_kkt_destroy(iem_kkt *k) {
   if (!k) return IEM_OK;
   DevGuard dg_(k->m->device);
+  hub_free(k);
   for (void *p : {(void *)k->d_flat, (void *)k->d_BR, (void *)k->d_Z, (void *)k->d_Gp, (void *)k->d_r, (void *)k->d_z, (void *)k->d_rBp, (void *)k->d_xB, (void *)k->d_part,
                   (void *)k->d_rows, (void *)k->d_cols, (void *)k->d_dest, (void *)k->d_on, (void *)k->d_pos, (void *)k->d_border, (void *)k->d_bloc, (void *)k->d_info,
                   (void *)k->d_seg, (void *)k->d_perm})
@@ -2218,8 +2517,7 @@ int iem_kkt_destroy(iem_kkt *k) {
 int iem_kkt_info(const iem_kkt *k, iem_kkt_info_t *out) {
   if (!k || !out) return fail(IEM_E_ARG, "null argument");
   const iem::KktLayout &L = k->L;
-  out->S = L.S; out->n = L.nvar + L.ncon; out->n_border = L.n_border; out->nb = L.nb; out->ne = L.ne; out->nc = L.nc;
-  out->reach = L.reach; out->group = L.group; out->phase = L.phase; out->block_doubles = L.total();
+  kkt_fill_info(L, out);
   return IEM_OK;
 }
 
@@ -2251,6 +2549,7 @@ int iem_kkt_factor(iem_kkt *k, int64_t *out_inertia) {
   iem_model *m = k->m;
   DevGuard dg_(m->device);
   const iem::KktLayout &L = k->L;
+  if (L.hubs) return hub_factor(k, out_inertia);
   const bool chained = L.reach > 0;
   double *D = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB(), *E = k->d_flat + L.oE();
   int rc = iem_kkt_chain_factor(m, L.S, L.nb, L.ne, L.nc, D, chained ? Bt : nullptr, chained ? k->d_BR : nullptr, chained ? k->d_rows : nullptr,
@@ -2296,6 +2595,7 @@ int iem_kkt_solve(iem_kkt *k, const double *d_rhs, double *d_sol) {
   iem_model *m = k->m;
   DevGuard dg_(m->device);
   const iem::KktLayout &L = k->L;
+  if (L.hubs) return hub_solve(k, d_rhs, d_sol);
   const bool chained = L.reach > 0;
   const double *Dinv = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB();
   HIP_TRY(hipMemsetAsync(k->d_r, 0, (size_t)(L.S * L.nb) * 8, m->stream));

@@ -821,4 +821,42 @@ extern "C" __global__ __launch_bounds__(256) void kkt_hub_widen(const KktHubArgs
   for (int k = 0; k < KKT_HUB_MAXQ; ++k) if (k < A.nq) o[k * W2] = v[k];
 }
 
+// ---- the hubs' side of iem_kkt_factor / iem_kkt_solve in hub mode (csrc/iem_api.cpp: the GEMMs in between are rocBLAS's) ----------
+// N = the part of a panel of the hubs' LDL' factor below its pivot blocks' own squares (those hold D_k, not L), X = I - N
+struct KktHubMaskArgs { const double *src; double *N, *X; long long ld; int pw, ldp, leaf; };
+extern "C" __global__ __launch_bounds__(256) void kkt_hub_mask(const KktHubMaskArgs A) {
+  const int g = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (g >= A.pw * A.pw) return;
+  const int r = g / A.pw, c = g - r * A.pw;
+  const double v = (r / A.leaf > c / A.leaf) ? A.src[(long long)r * A.ld + c] : 0.0;
+  A.N[r * A.ldp + c] = v;
+  A.X[r * A.ldp + c] = (r == c ? 1.0 : 0.0) - v;
+}
+// out[t hw + k] -= sum over lanes and rows of Q of E0[t][lane][q][k] y[block (lane, t)][Q[q]]      (one wave per time block)
+struct KktHubVecArgs { const double *E0, *v; double *out; const int *q; long long T, lanes; int nb, nq, hw; };
+extern "C" __global__ __launch_bounds__(64) void kkt_hub_ety(const KktHubVecArgs A) {
+  const long long t = blockIdx.x;
+  const long long n = A.lanes * A.nq;
+  for (int k = 0; k < A.hw; ++k) {
+    double acc = 0.0;
+    for (long long e = threadIdx.x; e < n; e += 64) {
+      const long long lane = e / A.nq; const int qi = (int)(e - lane * A.nq);
+      acc += A.E0[((t * A.lanes + lane) * A.nq + qi) * A.hw + k] * A.v[(lane * A.T + t) * A.nb + A.q[qi]];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) A.out[t * A.hw + k] -= acc;
+  }
+}
+// r[block (lane, t)][Q[q]] -= sum_k E0[t][lane][q][k] x_B[t hw + k]
+extern "C" __global__ __launch_bounds__(256) void kkt_hub_ex(const KktHubVecArgs A) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= A.T * A.lanes * A.nq) return;
+  const long long tl = g / A.nq; const int qi = (int)(g - tl * A.nq);
+  const long long t = tl / A.lanes, lane = tl - t * A.lanes;
+  double acc = 0.0;
+  for (int k = 0; k < A.hw; ++k) acc += A.E0[g * A.hw + k] * A.v[t * A.hw + k];
+  A.out[(lane * A.T + t) * A.nb + A.q[qi]] -= acc;
+}
+
 #endif  // IEM_KKT_DEVICE_H

@@ -38,8 +38,19 @@ struct KktLayout {
   int64_t oD() const { return 0; }
   int64_t oB() const { return S * (int64_t)nb * nb; }
   int64_t oE() const { return oB() + S * (int64_t)nc * nc; }
-  int64_t oG() const { return oE() + S * (int64_t)nb * ne; }
-  int64_t total() const { return oG() + (int64_t)ne * ne; }
+  int64_t oG() const { return oE() + e_doubles(); }
+  int64_t total() const { return oG() + g_doubles(); }
+  // HUBS (BASELINE config 3, pandemic 5 000 x 100): a laned grid whose border is too large for the dense-border kernels — the
+  // border unknowns u(t) become hubs, each owned by one time block; the blocks keep SPAN-SPARSE border columns between the
+  // reduction levels (csrc/iem_kkt_device.h: kkt_hub_z / kkt_hub_widen) and the hubs' Schur complement is a dense Hp x Hp matrix.
+  // The kernels see ne = 0.  E: [Tp][lanes][nq][hw] on the nq local rows Q that ever hold a border entry; G: [Hp][Hp].
+  bool hubs = false;
+  int64_t Tp = 0, hw = 0, H = 0, Hp = 0;   // blocks per lane, hubs per time block, hubs (time blocks that own one x hw), row length of G
+  int nq = 0, nr = 0, ncq = 0;
+  std::vector<int64_t> hub_of;            // per unknown: hub index (time block * hw + ordinal), -1 for the chain's unknowns
+  std::vector<int32_t> Q, qR, qC;         // local rows of Q; positions of the coupling rows / columns inside Q
+  int64_t e_doubles() const { return hubs ? Tp * lanes * (int64_t)nq * hw : S * (int64_t)nb * ne; }
+  int64_t g_doubles() const { return hubs ? Hp * Hp : (int64_t)ne * ne; }
 };
 
 inline int64_t ceil4(int64_t n) { return (n + 3) / 4 * 4; }
@@ -54,7 +65,7 @@ struct KktPlan {
 
 // (hr, hc: the Hessian's structure — an entry across two supports would widen the coupling; none of the reference's models has one)
 inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, const std::vector<int64_t> &jc, const std::vector<int64_t> &hr,
-                            const std::vector<int64_t> &hc, int want_group, int max_nb, int max_ne, int max_nc) {
+                            const std::vector<int64_t> &hc, int want_group, int max_nb, int max_ne, int max_nc, bool allow_hubs = false) {
   KktLayout L;
   L.nvar = m.nvar; L.ncon = m.ncon;
   const int64_t nvar = m.nvar, ncon = m.ncon, n = nvar + ncon, nj = (int64_t)jr.size();
@@ -121,7 +132,7 @@ inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, cons
     }
   struct Cand { std::vector<int64_t> blk, loc, counts; int nb = 0; std::vector<int64_t> rows, cols; int64_t S = 0; };
   // `use_lanes`: one chain per lane, lane-less chain variables to the border
-  auto build = [&](bool use_lanes) {
+  auto build = [&](bool use_lanes, bool hub_mode = false) {
     KktLayout B = L;
     std::vector<int64_t> chain((size_t)n, -1), lane((size_t)n, 0);
     std::vector<int64_t> rhi(hi), rlo(lo);
@@ -203,8 +214,8 @@ inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, cons
     if (best.S < 1) throw std::runtime_error("chain KKT: no unknown lies on the chain");
     B.S = best.S; B.blk.swap(best.blk); B.loc.swap(best.loc); B.counts.swap(best.counts);
     B.n_border = (int64_t)border.size();
-    B.nb = best.nb; B.ne = (int)ceil4((int64_t)border.size());
-    if (B.nb > max_nb || B.ne > max_ne)
+    B.nb = best.nb; B.ne = hub_mode ? 0 : (int)ceil4((int64_t)border.size());
+    if (B.nb > max_nb || (!hub_mode && B.ne > max_ne))
       throw std::runtime_error("chain KKT: blocks of " + std::to_string(*std::max_element(B.counts.begin(), B.counts.end())) + " unknowns / a border of " +
                                std::to_string(border.size()) + " exceed the dense-block solver's limits (" + std::to_string(max_nb) + " / " + std::to_string(max_ne) + ")");
     B.nc = (int)std::max<int64_t>(ceil4((int64_t)std::max(best.rows.size(), best.cols.size())), 4);
@@ -214,6 +225,49 @@ inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, cons
     B.rowsR.assign((size_t)B.nc, -1); B.colsC.assign((size_t)B.nc, -1);
     for (size_t i = 0; i < best.rows.size(); ++i) B.rowsR[i] = (int32_t)best.rows[i];
     for (size_t i = 0; i < best.cols.size(); ++i) B.colsC[i] = (int32_t)best.cols[i];
+    if (hub_mode) {
+      if (B.reach != 1) throw std::runtime_error("chain KKT (hub border): only stencils of reach 1 (backward differences) are handled");
+      B.hubs = true;
+      B.Tp = B.S / B.lanes;
+      // every border unknown belongs to the time block of its own support (a row: of the last support it touches)
+      std::vector<int64_t> tb(border.size()), cnt((size_t)B.Tp, 0);
+      B.hub_of.assign((size_t)n, -1);
+      for (size_t i = 0; i < border.size(); ++i) {
+        const int64_t u = border[i], c = u < nvar ? vc[(size_t)u] : hi[(size_t)(u - nvar)];
+        if (c < 0) throw std::runtime_error("chain KKT (hub border): a border unknown has no place on the chain's axis (finite variables are not handled here)");
+        tb[i] = c + B.phase;      // (R = 1)
+        if (tb[i] >= B.Tp) throw std::runtime_error("chain KKT (hub border): a border unknown lies beyond the chain's last block");
+      }
+      int64_t tmax = -1;
+      for (size_t i = 0; i < border.size(); ++i) { B.hub_of[(size_t)border[i]] = cnt[(size_t)tb[i]]++; tmax = std::max(tmax, tb[i]); }   // ordinal first ...
+      B.hw = 0;
+      for (int64_t c : cnt) B.hw = std::max(B.hw, c);
+      for (size_t i = 0; i < border.size(); ++i) B.hub_of[(size_t)border[i]] += tb[i] * B.hw;                                          // ... then the time block's base
+      B.H = (tmax + 1) * B.hw;
+      int64_t P = 1;
+      while (P < B.Tp) P *= 2;
+      B.Hp = P * B.hw;          // the spans of the last levels reach up to the next power of two of time blocks
+      // Q: the local rows a border entry sits on (J, J', H across chain / border), and the coupling rows / columns
+      std::set<int32_t> q;
+      auto see = [&](int64_t ua, int64_t ub) {
+        if (B.blk[(size_t)ua] >= 0 && B.blk[(size_t)ub] < 0) {
+          if (B.hub_of[(size_t)ub] / B.hw != B.blk[(size_t)ua] % B.Tp) throw std::runtime_error("chain KKT (hub border): a border unknown couples to a block of another time support");
+          q.insert((int32_t)B.loc[(size_t)ua]);
+        }
+      };
+      for (int64_t k = 0; k < nj; ++k) { see(nvar + jr[(size_t)k], jc[(size_t)k]); see(jc[(size_t)k], nvar + jr[(size_t)k]); }
+      for (size_t k = 0; k < hr.size(); ++k) { see(hr[k], hc[k]); see(hc[k], hr[k]); }
+      for (int32_t r : B.rowsR) if (r >= 0) q.insert(r);
+      for (int32_t c : B.colsC) if (c >= 0) q.insert(c);
+      B.Q.assign(q.begin(), q.end());
+      B.nq = (int)B.Q.size();
+      if (B.nq > 24) throw std::runtime_error("chain KKT (hub border): " + std::to_string(B.nq) + " local rows hold border entries (limit 24)");
+      std::vector<int32_t> qidx((size_t)B.nb, -1);
+      for (int i = 0; i < B.nq; ++i) qidx[(size_t)B.Q[(size_t)i]] = i;
+      for (int32_t r : B.rowsR) if (r >= 0) B.qR.push_back(qidx[(size_t)r]);
+      for (int32_t c : B.colsC) if (c >= 0) B.qC.push_back(qidx[(size_t)c]);
+      B.nr = (int)B.qR.size(); B.ncq = (int)B.qC.size();
+    }
     return B;
   };
   // the plain chain first (every model it fits keeps its layout); a 2-D grid whose time blocks are too large gets lanes
@@ -224,6 +278,14 @@ inline KktLayout kkt_layout(const Model &m, const std::vector<int64_t> &jr, cons
     try {
       return build(true);
     } catch (const std::runtime_error &laned) {
+      if (allow_hubs) {
+        try {
+          return build(true, true);
+        } catch (const std::runtime_error &hub) {
+          throw std::runtime_error(std::string(plain.what()) + "; one chain per lane of the support grid (" + std::to_string(nlanes) + " lanes): " + laned.what() +
+                                   "; with the border as hubs: " + hub.what());
+        }
+      }
       throw std::runtime_error(std::string(plain.what()) + "; one chain per lane of the support grid (" + std::to_string(nlanes) + " lanes): " + laned.what());
     }
   }
@@ -241,6 +303,16 @@ inline int64_t kkt_dest(const KktLayout &L, const std::vector<int32_t> &ridx, co
     }
     if (kc == kr + 1) return -1;
     throw std::runtime_error("chain KKT: an entry couples blocks that are not neighbours (the chain grouping does not fit this model)");
+  }
+  if (L.hubs) {
+    if (kr >= 0 && kc < 0) {      // E0[time block][lane][row in Q][hub of the time block]
+      int q = -1;
+      for (int i = 0; i < L.nq; ++i) if (L.Q[(size_t)i] == lr) q = i;
+      const int64_t hub = L.hub_of[(size_t)uc];
+      return L.oE() + (((kr % L.Tp) * L.lanes + kr / L.Tp) * L.nq + q) * L.hw + hub % L.hw;
+    }
+    if (kr < 0 && kc < 0) return L.oG() + L.hub_of[(size_t)ur] * L.Hp + L.hub_of[(size_t)uc];
+    return -1;
   }
   if (kr >= 0 && kc < 0) return L.oE() + (kr * L.nb + lr) * L.ne + lc;
   if (kr < 0 && kc < 0) return L.oG() + lr * L.ne + lc;
@@ -275,11 +347,16 @@ inline KktPlan kkt_plan(const KktLayout &L, const std::vector<int64_t> &hr, cons
     for (int64_t u = 0; u < nvar + ncon; ++u) if (L.blk[(size_t)u] >= 0) used[(size_t)(L.blk[(size_t)u] * L.nb + L.loc[(size_t)u])] = 1;
     for (int64_t s = 0; s < L.S * L.nb; ++s) if (!used[(size_t)s]) { const int64_t k = s / L.nb, l = s % L.nb; pairs.emplace_back(L.oD() + (k * L.nb + l) * L.nb + l, one); }
     for (int64_t l = L.n_border; l < L.ne; ++l) pairs.emplace_back(L.oG() + l * L.ne + l, one);
+    if (L.hubs) {               // hubs nobody owns (time blocks with fewer than hw of them, the tail up to Hp)
+      std::vector<char> owned((size_t)L.Hp, 0);
+      for (int64_t h : L.hub_of) if (h >= 0) owned[(size_t)h] = 1;
+      for (int64_t h = 0; h < L.Hp; ++h) if (!owned[(size_t)h]) pairs.emplace_back(L.oG() + h * L.Hp + h, one);
+    }
   }
   // by destination, sources of one destination in the order above: the regions D | Bt | E are block-major, so a counting
   // sort over (region, block) followed by a sort inside each bucket (a few hundred entries) is the global order
   {
-    const int64_t S = L.S, wD = (int64_t)L.nb * L.nb, wB = (int64_t)L.nc * L.nc, wE = (int64_t)L.nb * L.ne;
+    const int64_t S = L.S, wD = (int64_t)L.nb * L.nb, wB = (int64_t)L.nc * L.nc, wE = std::max<int64_t>(L.hubs ? (int64_t)L.nq * L.hw : (int64_t)L.nb * L.ne, 1);
     auto bucket = [&](int64_t d) -> int64_t {
       if (d < L.oB()) return (d - L.oD()) / wD;
       if (d < L.oE()) return S + (d - L.oB()) / wB;

@@ -71,7 +71,8 @@ COMM_HANDLE_BYTES = 128
 
 class KktInfo(C.Structure):
     _fields_ = [("S", C.c_int64), ("n", C.c_int64), ("n_border", C.c_int64), ("block_doubles", C.c_int64),
-                ("nb", C.c_int32), ("ne", C.c_int32), ("nc", C.c_int32), ("reach", C.c_int32), ("group", C.c_int32), ("phase", C.c_int32)]
+                ("nb", C.c_int32), ("ne", C.c_int32), ("nc", C.c_int32), ("reach", C.c_int32), ("group", C.c_int32), ("phase", C.c_int32),
+                ("lanes", C.c_int64), ("hub_ld", C.c_int64), ("hubs", C.c_int32), ("hub_rows", C.c_int32), ("hubs_per_block", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class KernelInfo(C.Structure):

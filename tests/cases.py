@@ -226,6 +226,8 @@ def extra_cases():
         # a 2-D support grid whose time blocks are too large for one chain (17 N_xi + 1 unknowns): the chain KKT solver runs one
         # chain per scenario (lanes) with u(t) in the border — the shape of the reference's own ladder, ESCAPE34/run_cases_gpu.jl:99-102
         "pandemic_100x7": lambda: workloads.pandemic(90, 7),
+        # ... and with more time supports than a dense border holds (128): u(t) as span-sparse hubs (BASELINE config 3's shape)
+        "pandemic_200x24": lambda: workloads.pandemic(190, 24),
     }
 
 

@@ -54,6 +54,40 @@ def test_host_analysis_matches_the_python_layout(name, built):
     assert np.allclose(flat[oG:total].reshape(L.ne, L.ne), G, rtol=0, atol=1e-12 * max(1.0, np.abs(G).max() if G.size else 1.0))
 
 
+@pytest.mark.parametrize("name", ["pandemic_300x7", "pandemic_200x24"])
+def test_host_analysis_of_a_hub_border_matches_the_python_one(name, built):
+    """A border beyond 128 unknowns on a laned grid: iem_kkt_create keeps it as span-sparse hubs.  The C++ analysis (grouping, hub
+    order, the rows Q, the gather plan into D | Bt | E0 | S) against kkt_chain.HubChainKKT's, entry for entry."""
+    import types
+    import torch
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.kkt_chain import HubChainKKT
+    core = cases.build_core(name)
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    info, blk, loc, rows, cols, dest, seg, perm = iemlib.kkt_analyse_blob(blob)
+    x, y = cases.eval_point_for(name, om, 5)
+    sigma = 0.5 + np.random.default_rng(3).random(om.nvar)
+    dw, dc = 1e-2, 1e-6
+    K = host_kkt(om, x, y, sigma, dw, dc).tocsr()
+    K.sum_duplicates(); K.sort_indices()
+    n = om.nvar + om.ncon
+    stub = types.SimpleNamespace(core=core, meta=types.SimpleNamespace(nvar=om.nvar, ncon=om.ncon), jac_structure=lambda base=0: om.jac_structure(), device="cpu")
+    kkt = types.SimpleNamespace(model=stub, n=n, rowptr=torch.as_tensor(K.indptr.astype(np.int32)), colind=torch.as_tensor(K.indices.astype(np.int32)), vals=torch.as_tensor(K.data))
+    hub = HubChainKKT(kkt, levels=ref.HubLevels(), device="cpu").load()
+    L = hub.layout
+    assert info["hubs"] == 1 and info["ne"] == 0 and (info["S"], info["lanes"], info["nb"], info["nc"], info["n_border"]) == (L.S, L.lanes, L.nb, L.nc, L.n_border)
+    assert (info["hub_rows"], info["hubs_per_block"], info["hub_ld"]) == (hub.nQ, hub.hw, hub.Hp)
+    chain = L.blk >= 0
+    assert np.array_equal(blk, L.blk) and np.array_equal(loc[chain], L.loc[chain])
+    src = np.concatenate([om.hess_coord(x, y, 1.0), om.jac_coord(x), sigma + dw, np.full(om.ncon, -dc), [1.0]])
+    flat = np.zeros(info["block_doubles"])
+    assert np.unique(dest).size == dest.size
+    flat[dest] = np.add.reduceat(src[perm], seg[:-1].astype(np.int64))
+    want = np.concatenate([hub.flat.numpy(), hub.E0.numpy(), hub.Sbig.numpy()])
+    assert flat.size == want.size and np.abs(flat - want).max() <= 1e-12 * np.abs(want).max()
+
+
 def test_host_analysis_agrees_on_every_small_case(built):
     """grouping, coupling width, block phase — or the refusal — for every model of tests/cases.py"""
     import warnings
@@ -86,9 +120,9 @@ def test_host_analysis_agrees_on_every_small_case(built):
 
 def test_analysis_refuses_what_the_solver_cannot_hold(built):
     from infiniteexamodels.jl_amd import lib as iemlib, transcribe, workloads
-    big = transcribe.exa_core(workloads.pandemic(290, 40)).to_blob()     # 40 scenarios x 17 unknowns per time support; as lanes: a border of 300
-    with pytest.raises(iemlib.IemError, match="exceed the dense-block solver's limits.*one chain per lane"):
-        iemlib.kkt_analyse_blob(big)
+    big = transcribe.exa_core(workloads.pandemic(290, 40)).to_blob()     # 40 scenarios x 17 unknowns per time support; as lanes: a border of 300 —
+    info = iemlib.kkt_analyse_blob(big)[0]                                # beyond the dense-border kernels (128): kept as span-sparse HUBS, ne = 0 for the kernels
+    assert (info["hubs"], info["lanes"], info["S"], info["nb"], info["ne"], info["n_border"], info["hubs_per_block"], info["hub_ld"]) == (1, 40, 40 * 300, 20, 0, 300, 1, 512)
     # ... while the same model on the reference's ladder grid (ESCAPE34/run_cases_gpu.jl:99-102: 100 + 10 supports) runs as lanes
     info = iemlib.kkt_analyse_blob(transcribe.exa_core(workloads.pandemic(100, 40)).to_blob())[0]
     assert (info["S"], info["nb"], info["ne"], info["n_border"], info["nc"]) == (40 * 110, 20, 112, 110, 4)
@@ -98,7 +132,7 @@ def test_analysis_refuses_what_the_solver_cannot_hold(built):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["quadrotor_100", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "kinetic_20", "quadrotor_1000", "opf_600", "farmer_1000",
-                                  "pandemic_100x7"])
+                                  "pandemic_100x7", "pandemic_300x7", "pandemic_200x24"])      # (the last two: 300 / 200 border unknowns -> HUB mode)
 def test_assemble_factor_solve_through_the_c_abi(name, built):
     import torch
     from infiniteexamodels.jl_amd import lib as iemlib
@@ -113,7 +147,7 @@ def test_assemble_factor_solve_through_the_c_abi(name, built):
     info = iemlib.KktInfo()
     iemlib.check(L_.iem_kkt_info(k, C.byref(info)))
     n = om.nvar + om.ncon
-    assert info.n == n
+    assert info.n == n and bool(info.hubs) == (name in ("pandemic_300x7", "pandemic_200x24"))
     rng = np.random.default_rng(3)
     p = lambda t: C.c_void_p(t.data_ptr())
     for seed in (5, 9):
@@ -129,6 +163,13 @@ def test_assemble_factor_solve_through_the_c_abi(name, built):
         neg_ref = int((np.linalg.eigvalsh(Kh.toarray()) < 0).sum()) if n <= 4000 else None
         if neg_ref is not None:
             assert (inertia[0], inertia[1], inertia[2]) == (n - neg_ref, neg_ref, 0)
+        if info.hubs:            # too large for dense eigenvalues: the Python-held form of the same pipeline (checked against them at small sizes) as the witness
+            from infiniteexamodels.jl_amd.kkt import KKTSystem
+            from infiniteexamodels.jl_amd.kkt_chain import HubChainKKT
+            kk = KKTSystem(gm)
+            kk.assemble(hv, jv, sd, 1e-2, 1e-6)
+            assert tuple(inertia) == HubChainKKT(kk).load().factor().inertia() and inertia[1] >= om.ncon and inertia[2] == 0
+            kk.close()
         rhs = rng.standard_normal(n)
         rd, sol = torch.tensor(rhs, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
         iemlib.check(L_.iem_kkt_solve(k, p(rd), p(sol)))

@@ -69,6 +69,29 @@ out = {"workload": f"pandemic SIR, {args.nt + 10} x {args.nxi} supports", "n": n
        "hub_layout": {"lanes": hub.lanes, "blocks_per_lane": hub.Tp, "S": hub.S, "nb": hub.nb, "nc": hub.nc, "hubs": hub.H, "hubs_per_time_block": hub.hw},
        "setup_s": {"model_and_csr_plan": t1 - t0, "hub_layout_and_plan": t2 - t1}, "ms": ms, "factor_phases_ms_synchronised": prof, "solve_phases_ms_synchronised": sprof,
        "abs_residual": {"no_refinement": res0, "one_refinement": res1}, "inertia": [pos, neg, doubtful], "ncon": gm.meta.ncon}
+# the same pipeline as ONE object behind the C-ABI (iem_kkt_create in hub mode: analysis and level loop in C++, GEMMs by rocBLAS)
+L = gm._L
+k = C.c_void_p()
+tc = time.perf_counter()
+iemlib.check(L.iem_kkt_create(gm._h, 0, C.byref(k)))
+create_s = time.perf_counter() - tc
+p = lambda a: C.c_void_p(a.data_ptr())
+gm._sync_stream()
+inertia = (C.c_int64 * 3)()
+sol2 = torch.empty_like(rhs)
+asm = lambda: iemlib.check(L.iem_kkt_assemble(k, p(hv), p(jv), p(sigma), 1e-2, 1e-6))
+cms = {"assemble": timed(asm)}
+cms["assemble_factor"] = timed(lambda: (asm(), iemlib.check(L.iem_kkt_factor(k, inertia))))
+cms["solve"] = timed(lambda: iemlib.check(L.iem_kkt_solve(k, p(rhs), p(sol2))))
+asm(); iemlib.check(L.iem_kkt_factor(k, inertia)); iemlib.check(L.iem_kkt_solve(k, p(rhs), p(sol2)))
+cres0 = float((matvec(sol2) - rhs).abs().max().item())
+r2 = rhs - matvec(sol2)
+d2 = torch.empty_like(rhs)
+iemlib.check(L.iem_kkt_solve(k, p(r2), p(d2)))
+cres1 = float((matvec(sol2 + d2) - rhs).abs().max().item())
+out["c_abi_object"] = {"create_s": create_s, "ms": cms, "assemble_factor_solve_ms": cms["assemble_factor"] + cms["solve"], "inertia": list(inertia),
+                       "abs_residual": {"no_refinement": cres0, "one_refinement": cres1}, "max_abs_difference_to_the_python_held_solution": float((sol2 + d2 - sol).abs().max().item())}
+iemlib.check(L.iem_kkt_destroy(k))
 if args.check:
     import scipy.sparse as sp
     from scipy.sparse.linalg import spsolve
