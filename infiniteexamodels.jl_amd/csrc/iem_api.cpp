@@ -209,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr; };
+  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr, fz = nullptr, fs = nullptr, bw = nullptr; int solve_bpw = 0; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1947,6 +1947,13 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.hub_mask, km.mod, "kkt_hub_mask"));
     HIP_TRY(hipModuleGetFunction(&km.hub_ety, km.mod, "kkt_hub_ety"));
     HIP_TRY(hipModuleGetFunction(&km.hub_ex, km.mod, "kkt_hub_ex"));
+    if (kkt_rowwise(nb, ne)) {      // the lane-per-row solves (csrc/iem_kkt_device.h: kkt_fz / kkt_fs / kkt_bw) for the shapes whose eliminate is lane-per-row too:
+                                    // at 40 x 40 they lose 12 % to the 64-thread kernels (two launches per level, 40 of 64 lanes), at 20 x 20 they win 30 %
+      HIP_TRY(hipModuleGetFunction(&km.fz, km.mod, "kkt_fz"));
+      HIP_TRY(hipModuleGetFunction(&km.fs, km.mod, "kkt_fs"));
+      HIP_TRY(hipModuleGetFunction(&km.bw, km.mod, "kkt_bw"));
+      km.solve_bpw = 64 / nb;
+    }
     it = m->kkt_mods.emplace(std::make_pair(nb, ne * 64 + nc), km).first;
   }
   *out = &it->second;
@@ -2059,11 +2066,23 @@ int iem_kkt_chain_solve_lanes(iem_model *m, int64_t S, int64_t lane_len, int nb,
   if (rc) return rc;
   const long long lanes = S / T;
   KktSolveArgsH A{d_Dinv, d_Bt, d_BR, d_Z, d_rows, d_cols, d_r, d_z, d_rBp, d_xB, (long long)S, 1, 0, T};
+  static const bool old_solves = [] { const char *e = getenv("IEM_KKT_EXPERIMENTS"), *o = getenv("IEM_KKT_OLD_SOLVES"); return e && !std::strcmp(e, "1") && o && !std::strcmp(o, "1"); }();
+  const bool rowwise = km->fz && !old_solves;        // no border, blocks that fit a wave: a lane per row
+  const long long bpw = rowwise ? km->solve_bpw : 1;
   if (!chained) {            // independent blocks: the border terms of all blocks (forward), every block's own solve (backward)
     if (phase != 0 && phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
     A.final_block = 2;
     if (phase == 0) return ne > 0 ? kkt_launch_solve(m, km->fwd, A, S, 64) : IEM_OK;
-    return kkt_launch_solve(m, km->bwd, A, S, 64);
+    return rowwise ? kkt_launch_solve(m, km->fz, A, (S + bpw - 1) / bpw, 64) : kkt_launch_solve(m, km->bwd, A, S, 64);
+  }
+  if (phase == 0 && rowwise) {
+    for (long long s = 1; s < T; s *= 2) {
+      A.s = s;
+      const long long n_elim = lanes * ((T - s + 2 * s - 1) / (2 * s)), n_surv = lanes * ((T + 2 * s - 1) / (2 * s));
+      if ((rc = kkt_launch_solve(m, km->fz, A, (n_elim + bpw - 1) / bpw, 64)) != IEM_OK) return rc;      // z of the level's eliminated blocks ...
+      if ((rc = kkt_launch_solve(m, km->fs, A, (n_surv + 63) / 64, 64)) != IEM_OK) return rc;            // ... folded into the survivors' right-hand sides
+    }
+    return IEM_OK;
   }
   if (phase == 0) {          // forward: levels up, then the last block's border contribution
     for (long long s = 1; s < T; s *= 2) {
@@ -2076,7 +2095,7 @@ int iem_kkt_chain_solve_lanes(iem_model *m, int64_t S, int64_t lane_len, int nb,
   }
   if (phase != 1) return fail(IEM_E_ARG, "phase must be 0 (forward) or 1 (backward)");
   A.final_block = 1;
-  if ((rc = kkt_launch_solve(m, km->bwd, A, lanes, 64)) != IEM_OK) return rc;
+  if ((rc = rowwise ? kkt_launch_solve(m, km->fz, A, (lanes + bpw - 1) / bpw, 64) : kkt_launch_solve(m, km->bwd, A, lanes, 64)) != IEM_OK) return rc;
   A.final_block = 0;
   long long top = 1;
   while (top * 2 < T) top *= 2;
@@ -2084,7 +2103,7 @@ int iem_kkt_chain_solve_lanes(iem_model *m, int64_t S, int64_t lane_len, int nb,
     if (s >= T) continue;
     A.s = s;
     const long long n_elim = lanes * ((T - s + 2 * s - 1) / (2 * s));
-    if ((rc = kkt_launch_solve(m, km->bwd, A, n_elim, 64)) != IEM_OK) return rc;
+    if ((rc = rowwise ? kkt_launch_solve(m, km->bw, A, (n_elim + bpw - 1) / bpw, 64) : kkt_launch_solve(m, km->bwd, A, n_elim, 64)) != IEM_OK) return rc;
   }
   return IEM_OK;
 }

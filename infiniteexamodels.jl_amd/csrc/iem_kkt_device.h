@@ -700,6 +700,98 @@ extern "C" __global__ __launch_bounds__(64) void kkt_backward(const KktSolveArgs
   }
 }
 
+#if KKT_NE == 0 && KKT_NB <= 64
+// ---- the same solves with a LANE PER ROW (no border, blocks that fit a wave: 64 / NB blocks side by side) --------------------------
+// kkt_forward / kkt_backward give a block 64 threads and a handful of barriers whatever its size, and their survivors recompute
+// rows of D_p^-1 r_p that the eliminated blocks' part of the same launch computes in full.  Split by what a thread owns:
+//   kkt_fz   z_i = D_i^-1 r_i of the level's eliminated blocks — lane c sums column c of the inverse (a row per load, coalesced), r_i through LDS
+//   kkt_fs   the survivors: r_j[R] -= BR_p z_p[C],  r_j[C] -= Bt_q' z_q[R]  from the stored z — a thread per survivor, NC x NC each
+//   kkt_bw   x_i = z_i - D_i^-1[:, R] (Bt_i x_p[C]) - D_i^-1[:, C] (BR_i' x_q[R]): the two NC-vectors through LDS, then a lane per entry
+// Every block inverse is read once per solve on the way up (3.2 KB for 20 x 20) and on 2 NC of its columns on the way down.
+#define KKT_SBPW (64 / KKT_NB)
+extern "C" __global__ __launch_bounds__(64) void kkt_fz(const KktSolveArgs A) {
+  __shared__ double rv[KKT_SBPW * KKT_NB];
+  const int lane = (int)threadIdx.x, slot = lane / KKT_NB, li = lane - slot * KKT_NB;
+  const long long b = (long long)blockIdx.x * KKT_SBPW + slot;
+  const KktIdx ix = kkt_eliminated(b, A.s, A.S, A.T);
+  const long long i = A.final_block == 2 ? b : A.final_block ? kkt_lane_first(b, A.S, A.T) : ix.i;
+  const bool on = slot < KKT_SBPW && i < A.S && (A.final_block || ix.valid);
+  if (slot < KKT_SBPW) rv[slot * KKT_NB + li] = on ? A.r[i * KKT_NB + li] : 0.0;
+  __syncthreads();
+  if (!on) return;
+  // y[c] = sum_k M[k][c] v[k] with c = this lane: every load takes one ROW of the inverse across the block's lanes (coalesced), and the
+  // orientation is the one kkt_backward uses (the inverse is symmetric up to rounding only: the two passes must read it the same way)
+  const double *col = A.D + i * KKT_NB * KKT_NB + li, *v = rv + slot * KKT_NB;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int kk = 0; kk < KKT_NB; ++kk) acc += col[kk * KKT_NB] * v[kk];
+  if (A.final_block) A.r[i * KKT_NB + li] = acc; else A.z[i * KKT_NB + li] = acc;
+}
+extern "C" __global__ __launch_bounds__(64) void kkt_fs(const KktSolveArgs A) {
+  const long long T_ = A.T > 0 ? A.T : A.S, n_surv = (A.S / T_) * ((T_ + 2 * A.s - 1) / (2 * A.s));
+  const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (g >= n_surv) return;
+  const KktIdx jx = kkt_survivor(g, A.s, A.S, A.T);
+  if (!jx.valid) return;
+  const long long j = jx.i, p = j - A.s, q = j + A.s;
+  constexpr int NN = KKT_NC * KKT_NC;
+  double zv[KKT_NC];
+  if (jx.left) {
+#pragma unroll
+    for (int c = 0; c < KKT_NC; ++c) { const int cc = A.cols[c]; zv[c] = cc >= 0 ? A.z[p * KKT_NB + cc] : 0.0; }
+    for (int a = 0; a < KKT_NC; ++a) {
+      const int ra = A.rows[a];
+      if (ra < 0) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < KKT_NC; ++c) acc += A.BR[p * NN + a * KKT_NC + c] * zv[c];
+      A.r[j * KKT_NB + ra] -= acc;
+    }
+  }
+  if (jx.right) {      // (after the left half: R and C may share an entry of r_j)
+#pragma unroll
+    for (int c = 0; c < KKT_NC; ++c) { const int rr = A.rows[c]; zv[c] = rr >= 0 ? A.z[q * KKT_NB + rr] : 0.0; }
+    for (int a = 0; a < KKT_NC; ++a) {
+      const int ca = A.cols[a];
+      if (ca < 0) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < KKT_NC; ++kk) acc += A.Bt[q * NN + kk * KKT_NC + a] * zv[kk];
+      A.r[j * KKT_NB + ca] -= acc;
+    }
+  }
+}
+extern "C" __global__ __launch_bounds__(64) void kkt_bw(const KktSolveArgs A) {
+  __shared__ double t1s[KKT_SBPW * KKT_NC], t2s[KKT_SBPW * KKT_NC];
+  const int lane = (int)threadIdx.x, slot = lane / KKT_NB, li = lane - slot * KKT_NB;
+  const long long b = (long long)blockIdx.x * KKT_SBPW + slot;
+  const KktIdx ix = kkt_eliminated(b, A.s, A.S, A.T);
+  const long long i = ix.i;
+  const bool on = slot < KKT_SBPW && ix.valid && i < A.S;
+  constexpr int NN = KKT_NC * KKT_NC;
+  if (on && li < KKT_NC) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < KKT_NC; ++c) {
+      const int cc = A.cols[c], rr = A.rows[c];
+      if (cc >= 0) s1 += A.Bt[i * NN + li * KKT_NC + c] * A.r[(i - A.s) * KKT_NB + cc];
+      if (ix.right && rr >= 0) s2 += A.BR[i * NN + c * KKT_NC + li] * A.r[(i + A.s) * KKT_NB + rr];
+    }
+    t1s[slot * KKT_NC + li] = s1; t2s[slot * KKT_NC + li] = s2;
+  }
+  __syncthreads();
+  if (!on) return;
+  const double *col = A.D + i * KKT_NB * KKT_NB + li;      // D^-1 is symmetric: its rows R / C are the columns the formula asks for (coalesced over the lanes)
+  double acc = A.z[i * KKT_NB + li];
+#pragma unroll
+  for (int a = 0; a < KKT_NC; ++a) {
+    const int ra = A.rows[a], ca = A.cols[a];
+    if (ra >= 0) acc -= col[ra * KKT_NB] * t1s[slot * KKT_NC + a];
+    if (ca >= 0) acc -= col[ca * KKT_NB] * t2s[slot * KKT_NC + a];
+  }
+  A.r[i * KKT_NB + li] = acc;
+}
+#endif
+
 // ---- the solver-facing entry points (iem_kkt_assemble / _solve): blocks from the COO values, right-hand sides in and out ----
 // flat[dest[i]] = sum over k in [seg[i], seg[i + 1]) of the source perm[k] — an index into the virtual array
 //   hess values | jac values | (sigma + delta_w) per variable | -delta_c per row | 1.0 (the padding's unit diagonal)
