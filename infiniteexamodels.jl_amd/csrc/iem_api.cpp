@@ -209,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr, fz = nullptr, fs = nullptr, bw = nullptr; int solve_bpw = 0; };
+  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr, hub_leaf = nullptr, fz = nullptr, fs = nullptr, bw = nullptr; int solve_bpw = 0; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1947,6 +1947,7 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.hub_mask, km.mod, "kkt_hub_mask"));
     HIP_TRY(hipModuleGetFunction(&km.hub_ety, km.mod, "kkt_hub_ety"));
     HIP_TRY(hipModuleGetFunction(&km.hub_ex, km.mod, "kkt_hub_ex"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_leaf, km.mod, "kkt_hub_leaf"));
     if (kkt_rowwise(nb, ne)) {      // the lane-per-row solves (csrc/iem_kkt_device.h: kkt_fz / kkt_fs / kkt_bw) for the shapes whose eliminate is lane-per-row too:
                                     // at 40 x 40 they lose 12 % to the 64-thread kernels (two launches per level, 40 of 64 lanes), at 20 x 20 they win 30 %
       HIP_TRY(hipModuleGetFunction(&km.fz, km.mod, "kkt_fz"));
@@ -2134,11 +2135,12 @@ struct RocBlas {
   int (*dgemm_sb)(void *, int, int, int, int, int, const double *, const double *, int, long long, const double *, int, long long, const double *, double *, int, long long, int) = nullptr;
   int (*dgemv)(void *, int, int, int, const double *, const double *, int, const double *, int, const double *, double *, int) = nullptr;
   int (*dgemv_sb)(void *, int, int, int, const double *, const double *, int, long long, const double *, int, long long, const double *, double *, int, long long, int) = nullptr;
+  int (*dgeam)(void *, int, int, int, int, const double *, const double *, int, const double *, const double *, int, double *, int) = nullptr;
 };
 struct KktHub {
   RocBlas bl;
   int32_t *d_q = nullptr, *d_qr = nullptr, *d_qc = nullptr;
-  double *E[2] = {nullptr, nullptr}, *Z = nullptr, *Sd = nullptr, *Wbuf = nullptr, *Dinv = nullptr, *Linv = nullptr, *Nmat = nullptr, *X[2] = {nullptr, nullptr}, *eye96 = nullptr,
+  double *E[2] = {nullptr, nullptr}, *Z = nullptr, *Sd = nullptr, *Lmat = nullptr, *LT = nullptr, *Dinv = nullptr, *Linv = nullptr, *Nmat = nullptr, *X[2] = {nullptr, nullptr}, *eye96 = nullptr,
          *eyeP = nullptr, *x = nullptr, *w = nullptr, *tmp = nullptr, *r2 = nullptr;
   long long *d_dinfo = nullptr;
   int64_t e_cap = 0, steps = 0, npanels = 0;
@@ -2191,7 +2193,8 @@ int hub_blas_load(iem_kkt *k) {
   b.dgemm_sb = (decltype(b.dgemm_sb))sym("rocblas_dgemm_strided_batched");
   b.dgemv = (decltype(b.dgemv))sym("rocblas_dgemv");
   b.dgemv_sb = (decltype(b.dgemv_sb))sym("rocblas_dgemv_strided_batched");
-  if (!b.create || !b.destroy || !b.set_stream || !b.dgemm || !b.dgemm_sb || !b.dgemv || !b.dgemv_sb) return fail(IEM_E_HIP, "chain KKT (hub border): librocblas.so lacks an entry point");
+  b.dgeam = (decltype(b.dgeam))sym("rocblas_dgeam");
+  if (!b.create || !b.destroy || !b.set_stream || !b.dgemm || !b.dgemm_sb || !b.dgemv || !b.dgemv_sb || !b.dgeam) return fail(IEM_E_HIP, "chain KKT (hub border): librocblas.so lacks an entry point");
   if (b.create(&b.handle) != 0) return fail(IEM_E_HIP, "rocblas_create_handle");
   if (b.set_stream(b.handle, k->m->stream) != 0) return fail(IEM_E_HIP, "rocblas_set_stream");
   return IEM_OK;
@@ -2250,7 +2253,8 @@ int hub_alloc(iem_kkt *k) {
   const int64_t H = L.H;
   h->steps = (H + HUB_LEAF - 1) / HUB_LEAF; h->npanels = (H + HUB_PW - 1) / HUB_PW;
   HIP_TRY(hipMalloc((void **)&h->Sd, (size_t)(H * H) * 8));
-  HIP_TRY(hipMalloc((void **)&h->Wbuf, (size_t)(H * HUB_PW) * 8));
+  HIP_TRY(hipMalloc((void **)&h->Lmat, (size_t)(H * H) * 8));      // L (the scaled columns); Sd keeps L D, the columns before scaling
+  HIP_TRY(hipMalloc((void **)&h->LT, (size_t)(H * H) * 8));        // L' panel by panel: the backward substitution reads rows, like the forward one
   HIP_TRY(hipMalloc((void **)&h->Dinv, (size_t)(h->steps * HUB_LEAF * HUB_LEAF) * 8));
   HIP_TRY(hipMalloc((void **)&h->Linv, (size_t)(h->npanels * HUB_PW * HUB_PW) * 8));
   HIP_TRY(hipMalloc((void **)&h->Nmat, (size_t)(HUB_PW * HUB_PW) * 8));
@@ -2270,7 +2274,7 @@ int hub_alloc(iem_kkt *k) {
 void hub_free(iem_kkt *k) {
   KktHub *h = k->hub;
   if (!h) return;
-  for (void *p : {(void *)h->d_q, (void *)h->d_qr, (void *)h->d_qc, (void *)h->E[0], (void *)h->E[1], (void *)h->Z, (void *)h->Sd, (void *)h->Wbuf, (void *)h->Dinv, (void *)h->Linv,
+  for (void *p : {(void *)h->d_q, (void *)h->d_qr, (void *)h->d_qc, (void *)h->E[0], (void *)h->E[1], (void *)h->Z, (void *)h->Sd, (void *)h->Lmat, (void *)h->LT, (void *)h->Dinv, (void *)h->Linv,
                   (void *)h->Nmat, (void *)h->X[0], (void *)h->X[1], (void *)h->eye96, (void *)h->eyeP, (void *)h->x, (void *)h->w, (void *)h->tmp, (void *)h->r2, (void *)h->d_dinfo})
     if (p) hipFree(p);
   if (h->bl.handle && h->bl.destroy) h->bl.destroy(h->bl.handle);
@@ -2278,37 +2282,36 @@ void hub_free(iem_kkt *k) {
   k->hub = nullptr;
 }
 // the hubs' Schur complement Sd (H x H, row-major, lower triangle + the pivot blocks' squares valid): block LDL' in panels of HUB_PW,
-// pivot blocks of HUB_LEAF inverted by kkt_eliminate (which counts their pivot signs)
+// pivot blocks of HUB_LEAF inverted by kkt_eliminate (which counts their pivot signs).  Sd keeps the columns BEFORE scaling (L D),
+// Lmat receives L = (L D) D^-1 — the updates are L (L D)': no copy of a panel is ever needed — and LT its transpose, panel by panel.
 int hub_dense_factor(iem_kkt *k) {
   const iem::KktLayout &L = k->L;
   KktHub *h = k->hub;
   iem_model *m = k->m;
   const int64_t n = L.H;
-  double *Sd = h->Sd;
+  double *Sd = h->Sd, *Lm = h->Lmat;
   int rc;
+  iem_model::KktMod *leaf = nullptr;
+  if ((rc = kkt_module(m, HUB_LEAF, 0, 4, &leaf))) return rc;
   HIP_TRY(hipMemsetAsync(h->d_dinfo, 0, (size_t)(h->steps * 3) * 8, m->stream));
   for (int64_t p0 = 0, pi = 0; p0 < n; p0 += HUB_PW, ++pi) {
     const int64_t p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
     for (int64_t kk = p0; kk < p1; kk += HUB_LEAF) {
       const int64_t e = std::min<int64_t>(kk + HUB_LEAF, p1), w = e - kk, ki = kk / HUB_LEAF;
       double *blk = h->Dinv + ki * HUB_LEAF * HUB_LEAF;
-      HIP_TRY(hipMemcpyAsync(blk, h->eye96, (size_t)(HUB_LEAF * HUB_LEAF) * 8, hipMemcpyDeviceToDevice, m->stream));     // (a short last block: unit diagonal, positive pivots)
-      if ((rc = copy2d(k, blk, HUB_LEAF, Sd + kk * n + kk, n, w, w))) return rc;
-      {   // in-place inverse + pivot signs: one block, no chain, no border (iem_kkt_chain_factor's S = 1 case without its memset of all counters)
-        iem_model::KktMod *km = nullptr;
-        if ((rc = kkt_module(m, HUB_LEAF, 0, 4, &km))) return rc;
+      { struct { const double *src; double *dst; long long ld; int w, nb; } A{Sd + kk * n + kk, blk, (long long)n, (int)w, HUB_LEAF};
+        if ((rc = kkt_launch_raw(m, k->km->hub_leaf, &A, sizeof A, (HUB_LEAF * HUB_LEAF + 255) / 256, 256))) return rc; }
+      {   // in-place inverse + pivot signs: one block, no chain, no border
         KktArgsH A{blk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->d_dinfo + 3 * ki, 1, 1, 2, 1e-30};
-        if ((rc = kkt_launch_elim(m, km, A, 1))) return rc;
+        if ((rc = kkt_launch_elim(m, leaf, A, 1))) return rc;
       }
       if (e < n) {
-        double *A21 = h->Wbuf + e * HUB_PW + (kk - p0);      // rows e.., the block's columns: L21 D (the columns before scaling)
-        if ((rc = copy2d(k, A21, HUB_PW, Sd + e * n + kk, n, n - e, w))) return rc;
-        if ((rc = gemm_rm(k, false, false, n - e, w, w, 1.0, A21, HUB_PW, blk, HUB_LEAF, 0.0, Sd + e * n + kk, n))) return rc;                       // P = A21 D^-1
-        if (e < p1 && (rc = gemm_rm(k, false, true, n - e, p1 - e, w, -1.0, Sd + e * n + kk, n, A21, HUB_PW, 1.0, Sd + e * n + e, n))) return rc;    // the panel's own columns
+        if ((rc = gemm_rm(k, false, false, n - e, w, w, 1.0, Sd + e * n + kk, n, blk, HUB_LEAF, 0.0, Lm + e * n + kk, n))) return rc;                       // L = (L D) D^-1
+        if (e < p1 && (rc = gemm_rm(k, false, true, n - e, p1 - e, w, -1.0, Lm + e * n + kk, n, Sd + e * n + kk, n, 1.0, Sd + e * n + e, n))) return rc;    // the panel's own columns
       }
     }
     {   // the panel's unit lower triangle L_pp = I + N (N strictly block lower: N^5 = 0), inverted once: (I + N)^-1 = I - N (I - N (I - ...))
-      struct { const double *src; double *N, *X; long long ld; int pw, ldp, leaf; } A{Sd + p0 * n + p0, h->Nmat, h->X[0], (long long)n, (int)pw, HUB_PW, HUB_LEAF};
+      struct { const double *src; double *N, *X; long long ld; int pw, ldp, leaf; } A{Lm + p0 * n + p0, h->Nmat, h->X[0], (long long)n, (int)pw, HUB_PW, HUB_LEAF};
       if ((rc = kkt_launch_raw(m, k->km->hub_mask, &A, sizeof A, (pw * pw + 255) / 256, 256))) return rc;
       int cur = 0;
       for (int64_t it = 0; it < (pw - 1) / HUB_LEAF - 1; ++it) {
@@ -2318,9 +2321,13 @@ int hub_dense_factor(iem_kkt *k) {
       }
       HIP_TRY(hipMemcpyAsync(h->Linv + pi * HUB_PW * HUB_PW, h->X[cur], (size_t)(HUB_PW * HUB_PW) * 8, hipMemcpyDeviceToDevice, m->stream));
     }
+    if (p1 < n) {   // LT[p0:p1, p1:] = L[p1:, p0:p1]'  (column-major view: C ((n - p1) x pw) = A' with A = the pw x (n - p1) view of the panel)
+      const double one = 1.0, zero = 0.0;
+      RB_TRY(h->bl.dgeam(h->bl.handle, RB_T, RB_N, (int)(n - p1), (int)pw, &one, Lm + p1 * n + p0, (int)n, &zero, h->LT + p0 * n + p1, (int)n, h->LT + p0 * n + p1, (int)n));
+    }
     for (int64_t c0 = p1; c0 < n; c0 += HUB_CH) {   // the rest of the matrix, lower triangle only, once per panel (inner dimension = the panel's width)
       const int64_t c1 = std::min<int64_t>(c0 + HUB_CH, n);
-      if ((rc = gemm_rm(k, false, true, n - c0, c1 - c0, pw, -1.0, Sd + c0 * n + p0, n, h->Wbuf + c0 * HUB_PW, HUB_PW, 1.0, Sd + c0 * n + c0, n))) return rc;
+      if ((rc = gemm_rm(k, false, true, n - c0, c1 - c0, pw, -1.0, Lm + c0 * n + p0, n, Sd + c0 * n + p0, n, 1.0, Sd + c0 * n + c0, n))) return rc;
     }
   }
   return IEM_OK;
@@ -2336,7 +2343,7 @@ int hub_dense_solve(iem_kkt *k, double *x) {
     const int64_t p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
     if ((rc = gemv_rm(k, false, pw, pw, 1.0, h->Linv + pi * HUB_PW * HUB_PW, HUB_PW, x + p0, 0.0, h->tmp))) return rc;
     HIP_TRY(hipMemcpyAsync(x + p0, h->tmp, (size_t)pw * 8, hipMemcpyDeviceToDevice, m->stream));
-    if (p1 < n && (rc = gemv_rm(k, false, n - p1, pw, -1.0, h->Sd + p1 * n + p0, n, x + p0, 1.0, x + p1))) return rc;
+    if (p1 < n && (rc = gemv_rm(k, false, n - p1, pw, -1.0, h->Lmat + p1 * n + p0, n, x + p0, 1.0, x + p1))) return rc;
   }
   {   // D^-1: one 96 x 96 product per pivot block (x is padded up to the last whole block with zeros)
     const double one = 1.0, zero = 0.0;
@@ -2344,9 +2351,9 @@ int hub_dense_solve(iem_kkt *k, double *x) {
     RB_TRY(h->bl.dgemv_sb(h->bl.handle, RB_T, HUB_LEAF, HUB_LEAF, &one, h->Dinv, HUB_LEAF, (long long)HUB_LEAF * HUB_LEAF, x, 1, HUB_LEAF, &zero, h->w, 1, HUB_LEAF, (int)h->steps));
   }
   double *w = h->w;
-  for (int64_t pi = h->npanels - 1; pi >= 0; --pi) {               // L' x = w
+  for (int64_t pi = h->npanels - 1; pi >= 0; --pi) {               // L' x = w  (rows of LT: the same fast matrix-vector kernel as on the way down)
     const int64_t p0 = pi * HUB_PW, p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
-    if (p1 < n && (rc = gemv_rm(k, true, n - p1, pw, -1.0, h->Sd + p1 * n + p0, n, w + p1, 1.0, w + p0))) return rc;
+    if (p1 < n && (rc = gemv_rm(k, false, pw, n - p1, -1.0, h->LT + p0 * n + p1, n, w + p1, 1.0, w + p0))) return rc;
     if ((rc = gemv_rm(k, true, pw, pw, 1.0, h->Linv + pi * HUB_PW * HUB_PW, HUB_PW, w + p0, 0.0, h->tmp))) return rc;
     HIP_TRY(hipMemcpyAsync(w + p0, h->tmp, (size_t)pw * 8, hipMemcpyDeviceToDevice, m->stream));
   }

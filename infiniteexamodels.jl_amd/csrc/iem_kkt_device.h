@@ -924,6 +924,14 @@ extern "C" __global__ __launch_bounds__(256) void kkt_hub_mask(const KktHubMaskA
   A.N[r * A.ldp + c] = v;
   A.X[r * A.ldp + c] = (r == c ? 1.0 : 0.0) - v;
 }
+// a pivot block of the hubs' LDL' into its dense 96 x 96 buffer: the w x w square, a unit diagonal beyond it (a short last block)
+struct KktHubLeafArgs { const double *src; double *dst; long long ld; int w, nb; };
+extern "C" __global__ __launch_bounds__(256) void kkt_hub_leaf(const KktHubLeafArgs A) {
+  const int g = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (g >= A.nb * A.nb) return;
+  const int r = g / A.nb, c = g - r * A.nb;
+  A.dst[g] = (r < A.w && c < A.w) ? A.src[(long long)r * A.ld + c] : (r == c ? 1.0 : 0.0);
+}
 // out[t hw + k] -= sum over lanes and rows of Q of E0[t][lane][q][k] y[block (lane, t)][Q[q]]      (one wave per time block)
 struct KktHubVecArgs { const double *E0, *v; double *out; const int *q; long long T, lanes; int nb, nq, hw; };
 extern "C" __global__ __launch_bounds__(64) void kkt_hub_ety(const KktHubVecArgs A) {
