@@ -286,7 +286,8 @@ int iem_csr_spmv(iem_model *m, int64_t n, const int32_t *d_rowptr, const int32_t
  * phase 1) and writes rBp (S x ne: r_border_schur = r_border - sum_k rBp[k]); the caller solves the ne x ne border system;
  * phase 1 substitutes back (r becomes the solution).
  * d_Bt == NULL (and d_BR == d_rows == d_cols == d_z == NULL): the blocks couple to the border only (scenario blocks of a
- * two-stage problem) — one launch instead of the levels.  nb: multiple of 4 in 4..96, ne: multiple of 4 in 0..64, nc: multiple
+ * two-stage problem) — one launch instead of the levels (ne = -1: no border and a kernel shape for ONE block per launch — the pivot
+ * blocks of a dense block factorisation, S = 1).  nb: multiple of 4 in 4..96, ne: multiple of 4 in 0..128, nc: multiple
  * of 4 in 4..48, nc <= nb.  Asynchronous on the handle's stream. */
 int iem_kkt_chain_factor(iem_model *m, int64_t S, int nb, int ne, int nc, double *d_D, double *d_Bt, double *d_BR, const int32_t *d_rows,
                          const int32_t *d_cols, double *d_E, double *d_Z, double *d_Gp, int64_t *d_info, double tiny);

@@ -1883,12 +1883,15 @@ KktKnobs kkt_knobs() {
 // without a border that fit the lanes of a wave
 bool kkt_rowwise(int nb, int ne) {
   static const KktKnobs knobs = kkt_knobs();
-  if (ne > 0 || nb > 48) return false;
+  if (ne != 0 || nb > 48) return false;
   if (knobs.rowwise >= 0) return knobs.rowwise == 1;
   return nb <= 32;
 }
+// ne = -1: no border and ONE block per launch (the pivot blocks of the hubs' dense LDL', one after the other): nothing hides the
+// block's own latency, so every tile row gets a wave (96 x 96: 50 -> 38 us per block; profiles/r04_kkt_leaf_shape_ab.txt)
 void kkt_shape(int nb, int ne, int *wmax, int *wpe) {
   const int R = (nb + 15) / 16;
+  if (ne < 0) { *wmax = 6; *wpe = 0; return; }
   if (ne > 0 || R <= 2) { *wmax = 4; *wpe = nb <= 48 ? 4 : 0; }
   else if (R == 3) { *wmax = 1; *wpe = 3; }
   else if (R == 4) { *wmax = 2; *wpe = 3; }
@@ -1906,7 +1909,7 @@ std::string kkt_source(int nb, int ne, int nc) {
   // dependency chain, not on issue slots.  IEM_KKT_CONTRACT=fast switches them on; profiles/r03_kkt_shape_ab.txt)
   static const KktKnobs knobs = kkt_knobs();
   std::string s = std::string("// iem-flags: -O3 -ffp-contract=") + knobs.contract + " -std=c++17\n#ifndef __HIPCC_RTC__\n#include <hip/hip_runtime.h>\n#endif\n";
-  s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(ne) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
+  s += "#define KKT_NB " + std::to_string(nb) + "\n#define KKT_NE " + std::to_string(std::max(ne, 0)) + "\n#define KKT_NC " + std::to_string(nc) + "\n";
   int wmax, wpe;
   kkt_shape(nb, ne, &wmax, &wpe);
   if (wpe > 0) s += "#define KKT_WPE " + std::to_string(wpe) + "\n";
@@ -1924,7 +1927,7 @@ bool kkt_fits(int nb, int ne, int nc) {
   return elim <= 160 * 1024 && upd <= 160 * 1024;
 }
 int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
-  if (nb < 4 || nb > 96 || nb % 4 || ne < 0 || ne > 128 || ne % 4 || nc < 4 || nc > 48 || nc % 4 || nc > nb || !kkt_fits(nb, ne, nc))
+  if (nb < 4 || nb > 96 || nb % 4 || ne < -1 || ne > 128 || (ne > 0 && ne % 4) || nc < 4 || nc > 48 || nc % 4 || nc > nb || !kkt_fits(nb, ne, nc))
     return fail(IEM_E_ARG, "chain KKT: block size must be a multiple of 4 in 4..96, border size a multiple of 4 in 0..128, coupling width a multiple of 4 in 4..48 (and <= the block size), tiles within the LDS of a CU");
   auto it = m->kkt_mods.find({nb, ne * 64 + nc});
   if (it == m->kkt_mods.end()) {
@@ -2292,7 +2295,7 @@ int hub_dense_factor(iem_kkt *k) {
   double *Sd = h->Sd, *Lm = h->Lmat;
   int rc;
   iem_model::KktMod *leaf = nullptr;
-  if ((rc = kkt_module(m, HUB_LEAF, 0, 4, &leaf))) return rc;
+  if ((rc = kkt_module(m, HUB_LEAF, -1, 4, &leaf))) return rc;
   HIP_TRY(hipMemsetAsync(h->d_dinfo, 0, (size_t)(h->steps * 3) * 8, m->stream));
   for (int64_t p0 = 0, pi = 0; p0 < n; p0 += HUB_PW, ++pi) {
     const int64_t p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;

@@ -708,7 +708,7 @@ class HubChainKKT:
                 blk.copy_(eye)
                 blk[:w, :w] = Sd[k:e, k:e]                           # (the last block is padded with a unit diagonal: positive pivots)
                 if self._levels is None:
-                    _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, 0, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), 1e-30))
+                    _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, -1, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), 1e-30))   # (ne = -1: the one-block-per-launch shape)
                 else:
                     M = blk.clone().numpy()
                     for j in range(NB):
