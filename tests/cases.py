@@ -220,6 +220,28 @@ def eval_point_for(name, om, seed=0):
     return x, y
 
 
+def pandemic_two_controls(num_supports, num_scenarios):
+    """The SIR model of ESCAPE34/pandemic.jl with a SECOND control that lives on t alone (a treatment rate v(t) moving infected
+    to recovered): two hubs per time block for the chain KKT solver's hub border — not a reference model, a shape test."""
+    gamma, beta, N = 0.303, 0.727, 1e5
+    im = InfiniteModel()
+    t = im.infinite_parameter("t", 0.0, 200.0, num_supports=num_supports)
+    xi = im.infinite_parameter("ξ", supports=np.linspace(0.1, 0.6, num_scenarios))
+    im.add_supports(t, [0.001, 0.002, 0.004, 0.008, 0.02, 0.04, 0.08, 0.2, 0.4, 0.8])
+    s, e, i, r = (im.variable(n, t, xi, lb=0) for n in "seir")
+    u = im.variable("u", t, lb=0, ub=0.8, start=0.2)
+    v = im.variable("v", t, lb=0, ub=0.3, start=0.1)
+    im.objective("min", im.integral(u + 0.5 * v * v, t))
+    im.constraint(s(0, xi) == 1 - 1 / N); im.constraint(e(0, xi) == 1 / N); im.constraint(i(0, xi) == 0); im.constraint(r(0, xi) == 0)
+    d = lambda w: im.deriv(w, t)
+    im.constraint(d(s) == -(1 - u) * beta * s * i)
+    im.constraint(d(e) == (1 - u) * beta * s * i - xi * e)
+    im.constraint(d(i) == xi * e - gamma * i - v * i)
+    im.constraint(d(r) == gamma * i + v * i)
+    im.constraint(i <= 0.02)
+    return im
+
+
 def extra_cases():
     """Models only some test modules ask for by name (not part of the every-entry-point sweep over small_cases())."""
     return {
@@ -228,6 +250,8 @@ def extra_cases():
         "pandemic_100x7": lambda: workloads.pandemic(90, 7),
         # ... and with more time supports than a dense border holds (128): u(t) as span-sparse hubs (BASELINE config 3's shape)
         "pandemic_200x24": lambda: workloads.pandemic(190, 24),
+        "pandemic2_150x8": lambda: pandemic_two_controls(140, 8),      # two hubs per time block (u(t), v(t)): 300 border unknowns
+        "pandemic2_20x3": lambda: pandemic_two_controls(10, 3),
     }
 
 

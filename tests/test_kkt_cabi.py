@@ -54,7 +54,7 @@ def test_host_analysis_matches_the_python_layout(name, built):
     assert np.allclose(flat[oG:total].reshape(L.ne, L.ne), G, rtol=0, atol=1e-12 * max(1.0, np.abs(G).max() if G.size else 1.0))
 
 
-@pytest.mark.parametrize("name", ["pandemic_300x7", "pandemic_200x24"])
+@pytest.mark.parametrize("name", ["pandemic_300x7", "pandemic_200x24", "pandemic2_150x8"])      # (the last: two hubs per time block)
 def test_host_analysis_of_a_hub_border_matches_the_python_one(name, built):
     """A border beyond 128 unknowns on a laned grid: iem_kkt_create keeps it as span-sparse hubs.  The C++ analysis (grouping, hub
     order, the rows Q, the gather plan into D | Bt | E0 | S) against kkt_chain.HubChainKKT's, entry for entry."""
@@ -132,7 +132,7 @@ def test_analysis_refuses_what_the_solver_cannot_hold(built):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["quadrotor_100", "quadrotor_oc3_40", "farmer_5", "opf_7", "pandemic_20x3", "hovercraft", "kinetic_20", "quadrotor_1000", "opf_600", "farmer_1000",
-                                  "pandemic_100x7", "pandemic_300x7", "pandemic_200x24"])      # (the last two: 300 / 200 border unknowns -> HUB mode)
+                                  "pandemic_100x7", "pandemic_300x7", "pandemic_200x24", "pandemic2_150x8"])      # (the last three: 200 - 310 border unknowns -> HUB mode)
 def test_assemble_factor_solve_through_the_c_abi(name, built):
     import torch
     from infiniteexamodels.jl_amd import lib as iemlib
@@ -147,7 +147,7 @@ def test_assemble_factor_solve_through_the_c_abi(name, built):
     info = iemlib.KktInfo()
     iemlib.check(L_.iem_kkt_info(k, C.byref(info)))
     n = om.nvar + om.ncon
-    assert info.n == n and bool(info.hubs) == (name in ("pandemic_300x7", "pandemic_200x24"))
+    assert info.n == n and bool(info.hubs) == (name in ("pandemic_300x7", "pandemic_200x24", "pandemic2_150x8"))
     rng = np.random.default_rng(3)
     p = lambda t: C.c_void_p(t.data_ptr())
     for seed in (5, 9):

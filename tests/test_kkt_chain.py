@@ -89,7 +89,7 @@ def test_layout_picks_the_stencil_axis_and_refuses_oversized_blocks(built):
 
 def _pandemic_system(nt, nxi):
     from infiniteexamodels.jl_amd import transcribe, workloads
-    core = transcribe.exa_core(workloads.pandemic(nt, nxi))
+    core = transcribe.exa_core(workloads.pandemic(nt, nxi) if nxi > 0 else cases.pandemic_two_controls(nt, -nxi))   # (nxi < 0: the variant with two controls on t)
     om = OracleModel(core.to_blob())
     x, y = cases.eval_point_for("pandemic_x", om, 5)
     rng = np.random.default_rng(3)
@@ -99,7 +99,7 @@ def _pandemic_system(nt, nxi):
     return core, om, (x, y, sigma), K, rng.standard_normal(om.nvar + om.ncon)
 
 
-@pytest.mark.parametrize("nt,nxi", [(10, 4), (23, 3), (54, 5)])      # 20 / 33 / 64 time supports = time blocks per lane (padded to 32 / 64 / 64)
+@pytest.mark.parametrize("nt,nxi", [(10, 4), (23, 3), (54, 5), (13, -3)])      # 20 / 33 / 64 / 23 time blocks per lane; the last with TWO hubs per time block
 def test_hub_border_pipeline_on_cpu(nt, nxi, built):
     """kkt_chain.HubChainKKT (config 3's solver: one chain per scenario, u(t) as span-sparse hubs) with the chain levels done
     by the dense restatement (chain_reference.HubLevels) instead of the device: the span bookkeeping of the hubs' columns, the
@@ -114,7 +114,7 @@ def test_hub_border_pipeline_on_cpu(nt, nxi, built):
     kkt = types.SimpleNamespace(model=stub, n=n, rowptr=torch.as_tensor(K.indptr.astype(np.int32)), colind=torch.as_tensor(K.indices.astype(np.int32)),
                                 vals=torch.as_tensor(K.data))
     hub = HubChainKKT(kkt, levels=ref.HubLevels(), device="cpu")
-    assert hub.lanes == nxi and hub.H == nt + 10 and hub.nb == 20 and hub.Tp * hub.hw == nt + 10
+    assert hub.lanes == abs(nxi) and hub.hw == (1 if nxi > 0 else 2) and hub.H == hub.hw * (nt + 10) and hub.nb == 20 and hub.Tp == nt + 10
     hub.load().factor()
     neg_ref = int((np.linalg.eigvalsh(K.toarray()) < 0).sum())
     assert hub.inertia() == (n - neg_ref, neg_ref, 0)
@@ -126,7 +126,7 @@ def test_hub_border_pipeline_on_cpu(nt, nxi, built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nt,nxi", [(54, 5), (190, 24), (100, 7)])    # 64 / 200 (padded to 256) / 110 (padded to 128) time blocks per lane; 200 hubs = 3 pivot blocks
+@pytest.mark.parametrize("nt,nxi", [(54, 5), (190, 24), (100, 7), (140, -8)])    # 64 / 200 / 110 / 150 time blocks per lane (200 hubs = 3 pivot blocks); the last with two hubs per time block
 def test_hub_border_chain_kkt_on_gpu(nt, nxi, built):
     """The same through the device: iem_kkt_chain_level / iem_kkt_chain_solve for the lanes' chains, kkt_eliminate for the hubs'
     pivot blocks (the C-ABI entries), torch for the span-sparse GEMMs between them."""
