@@ -2184,7 +2184,7 @@ constexpr int HUB_LEAF = 96, HUB_PW = 5 * HUB_LEAF, HUB_CH = 10 * HUB_LEAF, HUB_
 constexpr int RB_N = 111, RB_T = 112;      // rocblas_operation_none / _transpose
 int hub_blas_load(iem_kkt *k) {
   RocBlas &b = k->hub->bl;
-  if (b.handle) return IEM_OK;
+  if (b.handle) return b.set_stream(b.handle, k->m->stream) == 0 ? IEM_OK : fail(IEM_E_HIP, "rocblas_set_stream");      // (the handle's stream may have been changed since)
   b.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
   if (!b.lib) b.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
   if (!b.lib) return fail(IEM_E_HIP, std::string("chain KKT (hub border): cannot load librocblas.so (") + dlerror() + ")");
@@ -2421,6 +2421,7 @@ int hub_solve(iem_kkt *k, const double *d_rhs, double *d_sol) {
   KktHub *h = k->hub;
   iem_model *m = k->m;
   int rc;
+  if ((rc = hub_blas_load(k))) return rc;
   const double *Dinv = k->d_flat + L.oD(), *Bt = k->d_flat + L.oB(), *E0 = k->d_flat + L.oE();
   struct Mv { double *dst; const double *src; const long long *di, *si; long long n; };
   struct Vec { const double *E0, *v; double *out; const int *q; long long T, lanes; int nb, nq, hw; };
