@@ -355,10 +355,14 @@ __device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *
 template <int K>
 __device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_NB], double (*rowbuf)[KKT_BPW * KKT_NB], int bs, int li, bool mine, double tiny, int &neg, int &bad) {
   if constexpr (K < KKT_NB) {
+    // The pivot row reaches the lanes as the pivot COLUMN: the block is symmetric, and the in-place elimination keeps it so up to
+    // the sign of the columns already processed (M[k][j] = -M[j][k] for j < k, = M[j][k] for j > k) — every lane posts the ONE entry
+    // it holds of column k instead of lane k posting its NB entries through masked stores.  The kernel is bound by the CU's LDS
+    // pipe (20 of its ~115 instructions per pivot were 16-byte LDS operations, 16 waves share the pipe: profiles/r04_kkt_pmc_hub.txt);
+    // this halves them.  (Row and column agree to rounding only: the elimination runs on a matrix perturbed at that level.)
     double *rb = rowbuf[K & 1] + bs * KKT_NB;
-    if (li == K && mine) {
-#pragma unroll
-      for (int j = 0; j < KKT_NB; j += 2) *reinterpret_cast<double2 *>(rb + j) = double2{m[j], m[j + 1]};
+    if (mine) rb[li] = m[K];
+    if (li == K) {
 #pragma unroll
       for (int j = 0; j < KKT_NB; ++j) m[j] = 0.0;
     }
@@ -372,7 +376,7 @@ __device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_NB], double (*rowb
     const double inv = kkt_rcp(piv);
     const double g = li == K ? -inv : m[K] * inv;              // the pivot row's own lane restarts from zero: it becomes r / p, its pivot entry 1 / p
 #pragma unroll
-    for (int j = 0; j < KKT_NB; ++j) if (j != K) m[j] = __builtin_fma(-g, r[j], m[j]);
+    for (int j = 0; j < KKT_NB; ++j) if (j != K) m[j] = __builtin_fma(j < K ? g : -g, r[j], m[j]);      // (row entry = -column entry for j < K)
     m[K] = -g;
     kkt_row_steps<K + 1>(m, rowbuf, bs, li, mine, tiny, neg, bad);
   }
