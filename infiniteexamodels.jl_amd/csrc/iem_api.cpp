@@ -1870,7 +1870,7 @@ KktKnobs kkt_knobs() {
   if (!on || std::strcmp(on, "1") != 0) return k;     // production: the environment cannot change kernel shape, numerics or source
   if (const char *e = getenv("IEM_KKT_WMAX")) { const int v = atoi(e); if (v >= 1 && v <= 6) k.wmax = v; }
   if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) k.wpe = v; }
-  if (const char *e = getenv("IEM_KKT_ROWWISE")) { const int v = atoi(e); if (v == 0 || v == 1) k.rowwise = v; }
+  if (const char *e = getenv("IEM_KKT_ROWWISE")) { const int v = atoi(e); if (v >= 0 && v <= 2) k.rowwise = v; }
   if (const char *e = getenv("IEM_KKT_CONTRACT")) { if (!std::strcmp(e, "fast") || !std::strcmp(e, "on") || !std::strcmp(e, "off")) k.contract = e; }
   if (const char *e = getenv("IEM_KKT_DEFS")) {        // extra "#define NAME VALUE" lines only: [A-Za-z0-9_ #\n]
     bool ok = true;
@@ -1881,11 +1881,15 @@ KktKnobs kkt_knobs() {
 }
 // kkt_eliminate's other form (KKT_ROWWISE of csrc/iem_kkt_device.h): lane = row, 64 / nb blocks per one-wave workgroup — blocks
 // without a border that fit the lanes of a wave
-bool kkt_rowwise(int nb, int ne) {
+// ... returns the rows a lane holds (KKT_RPL): 0 = the matrix-core panel form
+int kkt_rowwise(int nb, int ne) {
   static const KktKnobs knobs = kkt_knobs();
-  if (ne != 0 || nb > 48) return false;
-  if (knobs.rowwise >= 0) return knobs.rowwise == 1;
-  return nb <= 32;
+  if (ne != 0 || nb > 48) return 0;
+  if (knobs.rowwise >= 0) return knobs.rowwise;
+  // two rows per lane up to 24 x 24 (hovercraft 20 x 20 at 1e5 supports: 0.74 ms against 0.84 with one row and 1.66 in the panel form); one
+  // row up to 32; beyond that the panel form (40 x 40: 2.35 ms with one row per lane against 2.38 — and the 64-thread solves are faster there;
+  // two rows of 40 do not fit the register file: 19.9 ms).  profiles/r04_kkt_rpl_ab.txt
+  return nb <= 24 ? 2 : nb <= 32 ? 1 : 0;
 }
 // ne = -1: no border and ONE block per launch (the pivot blocks of the hubs' dense LDL', one after the other): nothing hides the
 // block's own latency, so every tile row gets a wave (96 x 96: 50 -> 38 us per block; profiles/r04_kkt_leaf_shape_ab.txt)
@@ -1914,7 +1918,7 @@ std::string kkt_source(int nb, int ne, int nc) {
   kkt_shape(nb, ne, &wmax, &wpe);
   if (wpe > 0) s += "#define KKT_WPE " + std::to_string(wpe) + "\n";
   if (wmax != 4) s += "#define KKT_WMAX " + std::to_string(wmax) + "\n";
-  if (kkt_rowwise(nb, ne)) s += "#define KKT_ROWWISE 1\n";
+  if (kkt_rowwise(nb, ne)) s += "#define KKT_ROWWISE " + std::to_string(kkt_rowwise(nb, ne)) + "\n";
   if (!knobs.defs.empty()) s += knobs.defs + "\n";     // (experiments, IEM_KKT_EXPERIMENTS=1 only: extra #define lines)
   s += kKktSource;
   return s;
@@ -1938,7 +1942,7 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     int wmax, wpe_;
     kkt_shape(nb, ne, &wmax, &wpe_);
     km.elim_wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);   // KKT_T of csrc/iem_kkt_device.h
-    if (kkt_rowwise(nb, ne)) { km.elim_wg = 64; km.elim_bpw = 64 / nb; }
+    if (kkt_rowwise(nb, ne)) { km.elim_wg = 64; km.elim_bpw = 64 / (nb / kkt_rowwise(nb, ne)); }
     HIP_TRY(hipModuleGetFunction(&km.upd, km.mod, "kkt_update"));
     HIP_TRY(hipModuleGetFunction(&km.fwd, km.mod, "kkt_forward"));
     HIP_TRY(hipModuleGetFunction(&km.bwd, km.mod, "kkt_backward"));

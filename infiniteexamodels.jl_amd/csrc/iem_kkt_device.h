@@ -343,69 +343,102 @@ __device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *
 #define KKT_OCC
 #endif
 #if defined(KKT_ROWWISE) && KKT_NE == 0
-// Blocks that fit the lanes of ONE wave (NB <= 48, no border): lane = row of the block, its NB entries in registers, and
-// 64 / NB blocks side by side in a wave (three 20 x 20 blocks, five 12 x 12 ones).  The in-place Gauss-Jordan inverse is then
+// Blocks that fit the lanes of ONE wave (NB <= 48, no border): lane = row(s) of the block, their NB entries in registers, and
+// several blocks side by side in a wave.  The in-place Gauss-Jordan inverse is then
 // the scalar algorithm itself — pivot k: the pivot row goes through LDS to every lane of its block (broadcast reads), each lane
 // does  m[j] -= (m[k] / p) r[j]  on its own row: NB fused multiply-adds per lane and step, no panel regrouping, no tile rim,
 // no transposes.  The matrix-core form above spends 590 instructions per 4 pivots around 9 MFMAs whatever the block size (a
 // 20 x 20 block costs what a 40 x 40 one does) and is bound by FP64 issue slots at these sizes; this one issues ~ 3 NB per pivot.
 // Same pivots in the same order, same pivot-sign count.
-#define KKT_BPW (64 / KKT_NB)
+// KKT_RPL rows per lane (host-chosen, KKT_ROWWISE = 1 or 2): a lane holds the rows li, li + LPB, ... of its block (LPB = NB / RPL lanes
+// per block, 64 / LPB blocks per wave).  What every lane must READ per pivot — the pivot row, NB doubles through LDS — is then shared
+// by RPL rows: the kernel is bound by the CU's LDS pipe (16 waves share it; profiles/r04_kkt_pmc_hub.txt), so two rows per lane
+// nearly double its rate, and bring 40 x 40 blocks (20 lanes each, three per wave) within reach of this form.
+#define KKT_RPL KKT_ROWWISE
+#define KKT_LPB (KKT_NB / KKT_RPL)
+#define KKT_BPW (64 / KKT_LPB)
 // pivot K (a template parameter: every register index is a compile-time constant whatever the unroller's thresholds say)
 template <int K>
-__device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_NB], double (*rowbuf)[KKT_BPW * KKT_NB], int bs, int li, bool mine, double tiny, int &neg, int &bad) {
+__device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_RPL][KKT_NB], double (*rowbuf)[KKT_BPW * KKT_NB], int bs, int li, bool mine, double tiny, int &neg, int &bad) {
   if constexpr (K < KKT_NB) {
     // The pivot row reaches the lanes as the pivot COLUMN: the block is symmetric, and the in-place elimination keeps it so up to
-    // the sign of the columns already processed (M[k][j] = -M[j][k] for j < k, = M[j][k] for j > k) — every lane posts the ONE entry
-    // it holds of column k instead of lane k posting its NB entries through masked stores.  The kernel is bound by the CU's LDS
-    // pipe (20 of its ~115 instructions per pivot were 16-byte LDS operations, 16 waves share the pipe: profiles/r04_kkt_pmc_hub.txt);
-    // this halves them.  (Row and column agree to rounding only: the elimination runs on a matrix perturbed at that level.)
+    // the sign of the columns already processed (M[k][j] = -M[j][k] for j < k, = M[j][k] for j > k) — every lane posts the entries
+    // it holds of column k instead of the row's owner posting NB entries through masked stores.  (Row and column agree to rounding
+    // only: the elimination runs on a matrix perturbed at that level.)
+    constexpr int KL = K % KKT_LPB, KH = K / KKT_LPB;          // lane and register set of row K
     double *rb = rowbuf[K & 1] + bs * KKT_NB;
-    if (mine) rb[li] = m[K];
-    if (li == K) {
+    if (mine) {
 #pragma unroll
-      for (int j = 0; j < KKT_NB; ++j) m[j] = 0.0;
+      for (int h = 0; h < KKT_RPL; ++h) rb[li + h * KKT_LPB] = m[h][K];
+    }
+    if (li == KL) {
+#pragma unroll
+      for (int j = 0; j < KKT_NB; ++j) m[KH][j] = 0.0;           // the pivot row restarts from zero: it becomes r / p, its pivot entry 1 / p
     }
     __syncthreads();       // (one wave: the barrier orders the LDS traffic; two buffers alternate, so one per pivot is enough)
-    double r[KKT_NB];
-#pragma unroll
-    for (int j = 0; j < KKT_NB; j += 2) { const double2 v = *reinterpret_cast<const double2 *>(rb + j); r[j] = v.x; r[j + 1] = v.y; }
-    double piv = r[K];
+    double piv = rb[K];
     if (piv < 0.0) ++neg;
     if (!(fabs(piv) >= tiny)) { ++bad; piv = piv < 0.0 ? -tiny : tiny; }
     const double inv = kkt_rcp(piv);
-    const double g = li == K ? -inv : m[K] * inv;              // the pivot row's own lane restarts from zero: it becomes r / p, its pivot entry 1 / p
+    double g[KKT_RPL];
 #pragma unroll
-    for (int j = 0; j < KKT_NB; ++j) if (j != K) m[j] = __builtin_fma(j < K ? g : -g, r[j], m[j]);      // (row entry = -column entry for j < K)
-    m[K] = -g;
+    for (int h = 0; h < KKT_RPL; ++h) g[h] = (h == KH && li == KL) ? -inv : m[h][K] * inv;
+#pragma unroll
+    for (int j0 = 0; j0 < KKT_NB; j0 += 4) {      // the pivot row four entries at a time: it never sits in registers as a whole
+      const double2 v0 = *reinterpret_cast<const double2 *>(rb + j0), v1 = *reinterpret_cast<const double2 *>(rb + j0 + 2);
+      const double r4[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+      for (int h = 0; h < KKT_RPL; ++h)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + jj;
+          if (j != K) m[h][j] = __builtin_fma(j < K ? g[h] : -g[h], r4[jj], m[h][j]);      // (row entry = -column entry for j < K)
+        }
+#if KKT_RPL > 1
+      __builtin_amdgcn_sched_barrier(0);      // (keeps the scheduler from issuing every read of the row up front: NB more doubles live)
+#endif
+    }
+#pragma unroll
+    for (int h = 0; h < KKT_RPL; ++h) m[h][K] = -g[h];
     kkt_row_steps<K + 1>(m, rowbuf, bs, li, mine, tiny, neg, bad);
   }
 }
-extern "C" __global__ __launch_bounds__(64) void kkt_eliminate(const KktArgs A) {
+// register budget: the rows (2 VGPRs per entry) + 112 for the step (with less the allocator spills: two rows of 20 under a three-wave
+// budget run at HALF the rate, profiles/r04_kkt_rpl_ab.txt); waves per SIMD from that
+#ifndef KKT_ROW_WAVES
+#define KKT_ROW_WAVES (512 / (2 * KKT_RPL * KKT_NB + 112) < 1 ? 1 : 512 / (2 * KKT_RPL * KKT_NB + 112) > 8 ? 8 : 512 / (2 * KKT_RPL * KKT_NB + 112))
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KKT_ROW_WAVES, KKT_ROW_WAVES))) void kkt_eliminate(const KktArgs A) {
   __shared__ double rowbuf[2][KKT_BPW * KKT_NB];
   __shared__ int cnt[2];
-  const int lane = (int)threadIdx.x, slot = lane / KKT_NB, li = lane - slot * KKT_NB;
+  const int lane = (int)threadIdx.x, slot = lane / KKT_LPB, li = lane - slot * KKT_LPB;
   const long long b = (long long)blockIdx.x * KKT_BPW + slot;
   const KktIdx ix = kkt_eliminated(b, A.s, A.S, A.T);
   const long long i = A.final_block == 2 ? b : A.final_block ? kkt_lane_first(b, A.S, A.T) : ix.i;
   const bool mine = slot < KKT_BPW, on = mine && i < A.S && (A.final_block || ix.valid);      // (the lanes beyond the last whole block shadow slot 0: they read, never write)
   const int bs = mine ? slot : 0;
   if (lane < 2) cnt[lane] = 0;
-  double m[KKT_NB];
-  double *Di = A.D + (on ? i : 0) * KKT_NB * KKT_NB + li * KKT_NB;
+  double m[KKT_RPL][KKT_NB];
+  double *Di = A.D + (on ? i : 0) * KKT_NB * KKT_NB;
 #pragma unroll
-  for (int j = 0; j < KKT_NB; j += 2) {
-    const double2 v = on ? *reinterpret_cast<const double2 *>(Di + j) : double2{j == li ? 1.0 : 0.0, j + 1 == li ? 1.0 : 0.0};
-    m[j] = v.x; m[j + 1] = v.y;
+  for (int h = 0; h < KKT_RPL; ++h) {
+    const int row = li + h * KKT_LPB;
+#pragma unroll
+    for (int j = 0; j < KKT_NB; j += 2) {
+      const double2 v = on ? *reinterpret_cast<const double2 *>(Di + row * KKT_NB + j) : double2{j == row ? 1.0 : 0.0, j + 1 == row ? 1.0 : 0.0};
+      m[h][j] = v.x; m[h][j + 1] = v.y;
+    }
   }
   if (on && !A.final_block && ix.right)
-    for (int e = li; e < KKT_NC * KKT_NC; e += KKT_NB) A.BR[i * KKT_NC * KKT_NC + e] = A.Bt[(i + A.s) * KKT_NC * KKT_NC + e];
+    for (int e = li; e < KKT_NC * KKT_NC; e += KKT_LPB) A.BR[i * KKT_NC * KKT_NC + e] = A.Bt[(i + A.s) * KKT_NC * KKT_NC + e];
   int neg = 0, bad = 0;
   kkt_row_steps<0>(m, rowbuf, bs, li, mine, A.tiny, neg, bad);
   if (on && li == 0) { if (neg) atomicAdd(&cnt[0], neg); if (bad) atomicAdd(&cnt[1], bad); }
   if (on) {
 #pragma unroll
-    for (int j = 0; j < KKT_NB; j += 2) *reinterpret_cast<double2 *>(Di + j) = double2{m[j], m[j + 1]};
+    for (int h = 0; h < KKT_RPL; ++h)
+#pragma unroll
+      for (int j = 0; j < KKT_NB; j += 2) *reinterpret_cast<double2 *>(Di + (li + h * KKT_LPB) * KKT_NB + j) = double2{m[h][j], m[h][j + 1]};
   }
   __syncthreads();
   if (lane < 2 && cnt[lane]) atomicAdd((unsigned long long *)(A.info + lane), (unsigned long long)cnt[lane]);
