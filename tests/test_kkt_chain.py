@@ -157,6 +157,56 @@ def test_hub_border_chain_kkt_on_gpu(nt, nxi, built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nt,nxi", [(54, 5), (30, -4)])
+def test_hub_level_kernels_against_the_library_products(nt, nxi, built):
+    """iem_kkt_hub_level (kkt_hub_z / kkt_hub_widen) on its own: Z = D^-1[Q, Q] E of the eliminated blocks and the survivors' widened
+    columns, level by level, against the same quantities formed with gathered operands and batched library products."""
+    import torch
+    from infiniteexamodels.jl_amd.kkt import KKTSystem
+    from infiniteexamodels.jl_amd.kkt_chain import HubChainKKT
+    from infiniteexamodels.jl_amd.model import ExaModel
+    core, om, (x, y, sigma), K, rhs = _pandemic_system(nt, nxi)
+    gm = ExaModel(core, device=0)
+    kkt = KKTSystem(gm)
+    hub = HubChainKKT(kkt)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    kkt.assemble(gm.hess_coord(xd, yd, obj_weight=1.0), gm.jac_coord(xd), torch.tensor(sigma, device="cuda"), 1e-2, 1e-6)
+    hub.load()
+    gm._sync_stream()
+    t = torch
+    lanes, Tp, nb, nc, hw, nQ = hub.lanes, hub.Tp, hub.nb, hub.nc, hub.hw, hub.nQ
+    D4, Bt = hub.D.view(lanes, Tp, nb * nb), hub.Bt.view(lanes, Tp, nc, nc)
+    R, Cc, Q = hub._qR, hub._qC, hub._Q
+    nR, nC = int(R.numel()), int(Cc.numel())
+    qq = (Q[:, None] * nb + Q[None, :]).reshape(-1)
+    E = hub.E0.view(Tp, lanes, nQ, hw).clone()
+    E += 0.01 * t.randn_like(E)                      # (fill every row of Q: at the first levels most of E is structurally zero)
+    hub._level(1, 3)
+    s, levels = 1, 0
+    while s < Tp:
+        hub._level(s, 0)
+        W = (2 * s - 1) * hw
+        n_alive = E.shape[0]; n_e, n_s = n_alive // 2, n_alive - n_alive // 2
+        Z = t.empty(n_e, lanes, nQ, W, dtype=t.float64, device="cuda")
+        En = t.empty(n_s, lanes, nQ, (4 * s - 1) * hw, dtype=t.float64, device="cuda")
+        hub._hub_level(s, E, Z, En, 0)
+        Dq = D4[:, s::2 * s][:, :, qq].permute(1, 0, 2).reshape(n_e, lanes, nQ, nQ)
+        Zr = t.matmul(Dq, E[1::2])
+        Er = t.zeros_like(En)
+        Er[..., s * hw: s * hw + W] = E[0::2]
+        if n_s > 1:
+            Er[1:, :, R, 0:W] -= t.matmul(Bt[:, 2 * s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC], Zr[:n_s - 1][:, :, Cc, :])
+        Er[:n_e, :, Cc, 2 * s * hw: 2 * s * hw + W] -= t.matmul(Bt[:, s::2 * s].permute(1, 0, 2, 3)[:, :, :nR, :nC].transpose(-1, -2), Zr[:, :, R, :])
+        scale = max(1.0, float(Zr.abs().max()))
+        assert float((Z - Zr).abs().max()) <= 1e-12 * scale and float((En - Er).abs().max()) <= 1e-12 * max(scale, float(Er.abs().max())), s
+        E = En
+        hub._level(s, 1)
+        s *= 2; levels += 1
+    assert levels >= 5 and E.shape[0] == 1
+    kkt.close(); gm.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", MODELS + ["quadrotor_1000", "opf_600", "farmer_1000"])
 def test_chain_kkt_on_gpu(name, built):
     import torch
