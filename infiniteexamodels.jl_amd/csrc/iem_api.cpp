@@ -1887,9 +1887,9 @@ int kkt_rowwise(int nb, int ne) {
   if (ne != 0 || nb > 48) return 0;
   if (knobs.rowwise >= 0) return knobs.rowwise;
   // two rows per lane up to 24 x 24 (hovercraft 20 x 20 at 1e5 supports: 0.74 ms against 0.84 with one row and 1.66 in the panel form); one
-  // row up to 32; beyond that the panel form (40 x 40: 2.35 ms with one row per lane against 2.38 — and the 64-thread solves are faster there;
-  // two rows of 40 do not fit the register file: 19.9 ms).  profiles/r04_kkt_rpl_ab.txt
-  return nb <= 24 ? 2 : nb <= 32 ? 1 : 0;
+  // row up to 40 (40 x 40: 2.24 ms against 2.40 in the panel form; two rows of 40 leave one wave per SIMD: 2.9 ms; 44 x 44 spills: 7.3 ms);
+  // beyond that the panel form.  profiles/r04_kkt_rpl_ab.txt
+  return nb <= 24 ? 2 : nb <= 40 ? 1 : 0;
 }
 // ne = -1: no border and ONE block per launch (the pivot blocks of the hubs' dense LDL', one after the other): nothing hides the
 // block's own latency, so every tile row gets a wave (96 x 96: 50 -> 38 us per block; profiles/r04_kkt_leaf_shape_ab.txt)
@@ -1955,7 +1955,7 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.hub_ety, km.mod, "kkt_hub_ety"));
     HIP_TRY(hipModuleGetFunction(&km.hub_ex, km.mod, "kkt_hub_ex"));
     HIP_TRY(hipModuleGetFunction(&km.hub_leaf, km.mod, "kkt_hub_leaf"));
-    if (kkt_rowwise(nb, ne)) {      // the lane-per-row solves (csrc/iem_kkt_device.h: kkt_fz / kkt_fs / kkt_bw) for the shapes whose eliminate is lane-per-row too:
+    if (kkt_rowwise(nb, ne) && nb <= 32) {      // the lane-per-row solves (csrc/iem_kkt_device.h: kkt_fz / kkt_fs / kkt_bw) for the shapes whose eliminate is lane-per-row too:
                                     // at 40 x 40 they lose 12 % to the 64-thread kernels (two launches per level, 40 of 64 lanes), at 20 x 20 they win 30 %
       HIP_TRY(hipModuleGetFunction(&km.fz, km.mod, "kkt_fz"));
       HIP_TRY(hipModuleGetFunction(&km.fs, km.mod, "kkt_fs"));

@@ -371,10 +371,20 @@ __device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_RPL][KKT_NB], doub
 #pragma unroll
       for (int h = 0; h < KKT_RPL; ++h) rb[li + h * KKT_LPB] = m[h][K];
     }
+    // the pivot row restarts from zero (it becomes r / p, its pivot entry 1 / p)
+#if KKT_RPL == 1 && KKT_NB > 32
+    {   // ... as an in-place product with 0 or 1: with 40 entries per lane the divergent assignment below costs the allocator a second
+        // copy of the row while it lasts (40 x 40 at 1e5 supports: 2.24 ms against 2.35; at 20 x 20 the assignment is the faster form)
+      const double keep = li == KL ? 0.0 : 1.0;
+#pragma unroll
+      for (int j = 0; j < KKT_NB; ++j) m[KH][j] *= keep;
+    }
+#else
     if (li == KL) {
 #pragma unroll
-      for (int j = 0; j < KKT_NB; ++j) m[KH][j] = 0.0;           // the pivot row restarts from zero: it becomes r / p, its pivot entry 1 / p
+      for (int j = 0; j < KKT_NB; ++j) m[KH][j] = 0.0;
     }
+#endif
     __syncthreads();       // (one wave: the barrier orders the LDS traffic; two buffers alternate, so one per pivot is enough)
     double piv = rb[K];
     if (piv < 0.0) ++neg;
