@@ -2336,7 +2336,7 @@ static int64_t union_read_bytes(const Builders &bs) {
 // works on every body), the last n % 8 tiles of each body behind them.  `dec`: decode table {first, gx, gy, gz} per body.
 static void emit_dispatch_chain(std::ostream &src, size_t nb, size_t dec, size_t run, int mode, const std::vector<bool> &remap, const std::string &b,
                                 const std::function<std::string(size_t, const std::string &)> &call,
-                                const std::function<std::string(size_t)> &extra) {
+                                const std::function<std::string(size_t)> &extra, bool shift_first = false) {
   size_t j0 = 0;
   if (run >= 2) {
     const size_t e = dec;
@@ -2350,6 +2350,7 @@ static void emit_dispatch_chain(std::ostream &src, size_t nb, size_t dec, size_t
       src << "    { const long long f_ = (n_ >> 3) * " << (8 * run) << ";\n"
           << "      if (r_ < f_) { j_ = (r_ >> 3) % " << run << "; lq_ = (r_ / " << (8 * run) << ") * 8 + (r_ & 7); }\n"
           << "      else { const long long t_ = n_ & 7, q_ = r_ - f_; j_ = q_ / t_; lq_ = (n_ & ~7LL) + q_ % t_; } }\n";
+    if (shift_first) src << "    if (j_ == 0) { lq_ += n_ >> 1; if (lq_ >= n_) lq_ -= n_; }\n";
     src << "    const long long lb = " << (remap[0] ? "iem_xcd_remap(lq_, n_)" : "lq_") << ";\n";
     for (size_t j = 0; j < run; ++j) {
       src << "    " << (j ? "else " : "");
@@ -2890,7 +2891,7 @@ Program generate(const Model &m, const Options &opt_in) {
     } else {
       std::ostringstream ch;
       emit_dispatch_chain(ch, ks.size(), ipb + dec, E.si ? 1 : E.run, opt.jac_split == 1 ? 1 : 2, E.remap, b, call,
-                          [&](size_t j) { return E.si ? "    wg_ = A.ip[" + std::to_string(ipb + E.sh_off + j) + "] + lb;\n" : std::string(); });
+                          [&](size_t j) { return E.si ? "    wg_ = A.ip[" + std::to_string(ipb + E.sh_off + j) + "] + lb;\n" : std::string(); }, opt.split_shift != 0);
       c << ch.str();
     }
     if (E.si) c << KernelBuilder::shared_epilogue(*E.si, "A.ip + " + std::to_string(ipb + E.sh_tbl), "wg_", "lds_blk", E.sh_lds);
@@ -3245,7 +3246,7 @@ Program generate(const Model &m, const Options &opt_in) {
           while (run < ord.size() && same(0, run)) ++run;
           std::vector<bool> rm;
           for (size_t jj = 0; jj < ord.size(); ++jj) rm.push_back(pxcd[ord[jj]]);
-          emit_dispatch_chain(src, ord.size(), dec, run, opt.jac_split == 1 ? 1 : 2, rm, "b", call, [](size_t) { return std::string(); });
+          emit_dispatch_chain(src, ord.size(), dec, run, opt.jac_split == 1 ? 1 : 2, rm, "b", call, [](size_t) { return std::string(); }, opt.split_shift != 0);
         }
         src << "}\n\n";
         P.kernels.push_back(F);
