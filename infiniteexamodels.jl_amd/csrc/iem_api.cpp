@@ -209,7 +209,7 @@ struct iem_model {
   bool reads_halo_x[iem::KK_LAST + 1] = {}, reads_halo_v[iem::KK_LAST + 1] = {}, carrier[iem::KK_LAST + 1] = {};
   uint64_t nonce = 0;
   // chain KKT solver (iem_kkt_chain_*): one code object per (block size, border size)
-  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr, hub_leaf = nullptr, fz = nullptr, fs = nullptr, bw = nullptr; int solve_bpw = 0; };
+  struct KktMod { unsigned elim_wg = 64; int elim_bpw = 1; hipModule_t mod = nullptr; hipFunction_t elim = nullptr, upd = nullptr, fwd = nullptr, bwd = nullptr, gather = nullptr, move = nullptr, colsum = nullptr, hub_z = nullptr, hub_widen = nullptr, hub_mask = nullptr, hub_ety = nullptr, hub_ex = nullptr, hub_leaf = nullptr, hub_diagmax = nullptr, fz = nullptr, fs = nullptr, bw = nullptr; int solve_bpw = 0; };
   std::map<std::pair<int, int>, KktMod> kkt_mods;
   std::map<int, void *> d_arrays;  // model array id -> device copy
   std::vector<std::vector<uint64_t>> argbuf;  // per kernel: launch argument block; only the six head words change per call
@@ -1956,6 +1956,7 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     HIP_TRY(hipModuleGetFunction(&km.hub_ety, km.mod, "kkt_hub_ety"));
     HIP_TRY(hipModuleGetFunction(&km.hub_ex, km.mod, "kkt_hub_ex"));
     HIP_TRY(hipModuleGetFunction(&km.hub_leaf, km.mod, "kkt_hub_leaf"));
+    HIP_TRY(hipModuleGetFunction(&km.hub_diagmax, km.mod, "kkt_hub_diagmax"));
     if (kkt_rowwise(nb, ne) && nb <= 32) {      // the lane-per-row solves (csrc/iem_kkt_device.h: kkt_fz / kkt_fs / kkt_bw) for the shapes whose eliminate is lane-per-row too:
                                     // at 40 x 40 they lose 12 % to the 64-thread kernels (two launches per level, 40 of 64 lanes), at 20 x 20 they win 30 %
       HIP_TRY(hipModuleGetFunction(&km.fz, km.mod, "kkt_fz"));
@@ -2302,6 +2303,17 @@ int hub_dense_factor(iem_kkt *k) {
   iem_model::KktMod *leaf = nullptr;
   if ((rc = kkt_module(m, HUB_LEAF, -1, 4, &leaf))) return rc;
   HIP_TRY(hipMemsetAsync(h->d_dinfo, 0, (size_t)(h->steps * 3) * 8, m->stream));
+  // pivot threshold of the hubs' blocks: RELATIVE to the largest diagonal entry of their Schur complement — a pivot at rounding level of
+  // that scale is neither sign and is reported as doubtful (as the dense border's near-zero eigenvalues are: ADVICE r03), not as positive
+  double tiny = 1e-30;
+  {
+    struct { const double *S; double *out; long long n, ld; } A{Sd, h->tmp, (long long)n, (long long)n};
+    if ((rc = kkt_launch_raw(m, k->km->hub_diagmax, &A, sizeof A, 1, 256))) return rc;
+    double dmax = 0.0;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(&dmax, h->tmp, 8, hipMemcpyDeviceToHost));
+    if (dmax > 0.0 && std::isfinite(dmax)) tiny = std::max(tiny, 1e-14 * dmax);
+  }
   for (int64_t p0 = 0, pi = 0; p0 < n; p0 += HUB_PW, ++pi) {
     const int64_t p1 = std::min<int64_t>(p0 + HUB_PW, n), pw = p1 - p0;
     for (int64_t kk = p0; kk < p1; kk += HUB_LEAF) {
@@ -2310,7 +2322,7 @@ int hub_dense_factor(iem_kkt *k) {
       { struct { const double *src; double *dst; long long ld; int w, nb; } A{Sd + kk * n + kk, blk, (long long)n, (int)w, HUB_LEAF};
         if ((rc = kkt_launch_raw(m, k->km->hub_leaf, &A, sizeof A, (HUB_LEAF * HUB_LEAF + 255) / 256, 256))) return rc; }
       {   // in-place inverse + pivot signs: one block, no chain, no border
-        KktArgsH A{blk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->d_dinfo + 3 * ki, 1, 1, 2, 1e-30};
+        KktArgsH A{blk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->d_dinfo + 3 * ki, 1, 1, 2, tiny};
         if ((rc = kkt_launch_elim(m, leaf, A, 1))) return rc;
       }
       if (e < n) {

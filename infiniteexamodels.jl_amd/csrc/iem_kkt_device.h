@@ -971,6 +971,17 @@ extern "C" __global__ __launch_bounds__(256) void kkt_hub_mask(const KktHubMaskA
   A.N[r * A.ldp + c] = v;
   A.X[r * A.ldp + c] = (r == c ? 1.0 : 0.0) - v;
 }
+// max |S_ii| of the hubs' Schur complement (one workgroup): the scale of its pivot threshold
+struct KktHubDiagArgs { const double *S; double *out; long long n, ld; };
+extern "C" __global__ __launch_bounds__(256) void kkt_hub_diagmax(const KktHubDiagArgs A) {
+  __shared__ double red[256];
+  double v = 0.0;
+  for (long long i = threadIdx.x; i < A.n; i += 256) v = fmax(v, fabs(A.S[i * A.ld + i]));
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) A.out[0] = red[0];
+}
 // a pivot block of the hubs' LDL' into its dense 96 x 96 buffer: the w x w square, a unit diagonal beyond it (a short last block)
 struct KktHubLeafArgs { const double *src; double *dst; long long ld; int w, nb; };
 extern "C" __global__ __launch_bounds__(256) void kkt_hub_leaf(const KktHubLeafArgs A) {

@@ -695,6 +695,9 @@ class HubChainKKT:
         self._Dinv = t.zeros(steps, NB, NB, dtype=t.float64, device=dev)
         self._dinfo = t.zeros(steps, 3, dtype=t.int64, device=dev)
         eye = t.eye(NB, dtype=t.float64, device=dev)
+        # pivot threshold RELATIVE to the largest diagonal entry: a pivot at rounding level of that scale is doubtful, not positive
+        dmax = float(Sd.diagonal().abs().max().item())
+        tiny = max(1e-30, 1e-14 * dmax) if np.isfinite(dmax) else 1e-30
         Wbuf = t.empty(n, PW, dtype=t.float64, device=dev)          # L21 D of the current panel (= the columns before scaling)
         self._Linv, self._panel = [], PW
         eyeP = t.eye(PW, dtype=t.float64, device=dev)
@@ -708,11 +711,12 @@ class HubChainKKT:
                 blk.copy_(eye)
                 blk[:w, :w] = Sd[k:e, k:e]                           # (the last block is padded with a unit diagonal: positive pivots)
                 if self._levels is None:
-                    _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, -1, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), 1e-30))   # (ne = -1: the one-block-per-launch shape)
+                    _lib.check(m._L.iem_kkt_chain_factor(m._h, 1, NB, -1, 4, p(blk), None, None, None, None, None, None, None, p(self._dinfo[ki]), tiny))   # (ne = -1: the one-block-per-launch shape)
                 else:
                     M = blk.clone().numpy()
                     for j in range(NB):
                         self._dinfo[ki, 0] += int(M[j, j] < 0)
+                        self._dinfo[ki, 1] += int(not abs(M[j, j]) >= tiny)
                         M[j + 1:, j + 1:] -= np.outer(M[j + 1:, j], M[j, j + 1:]) / M[j, j]
                     blk.copy_(t.linalg.inv(blk))
                 if e < n:

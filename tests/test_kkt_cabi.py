@@ -216,3 +216,34 @@ def test_a_singular_system_is_reported_as_doubtful(built):
     assert (inertia[1], inertia[2]) == (om.ncon, 0), tuple(inertia)
     iemlib.check(gm._L.iem_kkt_destroy(k))
     gm.close()
+
+
+@pytest.mark.gpu
+def test_a_singular_system_is_reported_as_doubtful_in_hub_mode(built):
+    """The same for a hub border (pandemic 310 x 7): without any regularisation the KKT matrix of the point is singular or
+    numerically so — the chain's blocks or the hubs' pivot blocks (threshold relative to the largest diagonal entry of their Schur
+    complement) must report DOUBTFUL pivots; regularised, the same object factorises cleanly again."""
+    import torch
+    from infiniteexamodels.jl_amd import lib as iemlib
+    from infiniteexamodels.jl_amd.model import ExaModel
+    core = cases.build_core("pandemic_300x7")
+    blob = core.to_blob()
+    om = OracleModel(blob)
+    gm = ExaModel(core, device=0, blob=blob)
+    k = C.c_void_p()
+    iemlib.check(gm._L.iem_kkt_create(gm._h, 0, C.byref(k)))
+    x, y = cases.eval_point_for("pandemic_300x7", om, 5)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    sd = torch.zeros(om.nvar, dtype=torch.float64, device="cuda")
+    hv, jv = gm.hess_coord(xd, yd, obj_weight=1.0), gm.jac_coord(xd)
+    gm._sync_stream()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    iemlib.check(gm._L.iem_kkt_assemble(k, p(hv), p(jv), p(sd), 0.0, 0.0))
+    inertia = (C.c_int64 * 3)()
+    iemlib.check(gm._L.iem_kkt_factor(k, inertia))
+    assert inertia[2] > 0, tuple(inertia)
+    iemlib.check(gm._L.iem_kkt_assemble(k, p(hv), p(jv), p(sd + 0.5), 1e-2, 1e-6))
+    iemlib.check(gm._L.iem_kkt_factor(k, inertia))
+    assert inertia[1] >= om.ncon and inertia[2] == 0 and inertia[0] + inertia[1] == om.nvar + om.ncon, tuple(inertia)
+    iemlib.check(gm._L.iem_kkt_destroy(k))
+    gm.close()
