@@ -1864,13 +1864,14 @@ namespace {
 // chain's latency — beat one wave per tile row (quadrotor_oc3, 84 x 84 blocks: 11.6 ms with four waves, 10.3 with six, 5.8
 // with two; 40 x 40: 2.60 -> 2.40 with one).  With a border the products Z = D^-1 E and E' Z dominate and want the waves
 // (OPF, 60 + 52: 3.6 ms with four, 4.6 with two, 7.0 with one).  profiles/r03_kkt_shape_ab.txt
-struct KktKnobs { int wmax = -1, wpe = -1, rowwise = -1; std::string contract = "off", defs; };
+struct KktKnobs { int wmax = -1, wpe = -1, rowwise = -1, wpg = -1; std::string contract = "off", defs; };
 KktKnobs kkt_knobs() {
   KktKnobs k;
   const char *on = getenv("IEM_KKT_EXPERIMENTS");
   if (!on || std::strcmp(on, "1") != 0) return k;     // production: the environment cannot change kernel shape, numerics or source
   if (const char *e = getenv("IEM_KKT_WMAX")) { const int v = atoi(e); if (v >= 1 && v <= 6) k.wmax = v; }
   if (const char *e = getenv("IEM_KKT_WPE")) { const int v = atoi(e); if (v >= 0 && v <= 8) k.wpe = v; }
+  if (const char *e = getenv("IEM_KKT_WPG")) { const int v = atoi(e); if (v == 1 || v == 2) k.wpg = v; }
   if (const char *e = getenv("IEM_KKT_ROWWISE")) { const int v = atoi(e); if (v >= 0 && v <= 2) k.rowwise = v; }
   if (const char *e = getenv("IEM_KKT_CONTRACT")) { if (!std::strcmp(e, "fast") || !std::strcmp(e, "on") || !std::strcmp(e, "off")) k.contract = e; }
   if (const char *e = getenv("IEM_KKT_DEFS")) {        // extra "#define NAME VALUE" lines only: [A-Za-z0-9_ #\n]
@@ -1894,6 +1895,16 @@ int kkt_rowwise(int nb, int ne) {
 }
 // ne = -1: no border and ONE block per launch (the pivot blocks of the hubs' dense LDL', one after the other): nothing hides the
 // block's own latency, so every tile row gets a wave (96 x 96: 50 -> 38 us per block; profiles/r04_kkt_leaf_shape_ab.txt)
+// waves per workgroup of the lane-per-row eliminate: two when that fills the lanes better (40 lanes per block: 3 blocks on 128 lanes
+// instead of 1 on 64 — the kernel is bound by the LDS reads every lane of the workgroup makes, idle or not)
+int kkt_row_wpg(int nb, int ne) {
+  static const KktKnobs knobs = kkt_knobs();
+  const int rpl = kkt_rowwise(nb, ne);
+  if (!rpl) return 1;
+  if (knobs.wpg >= 1) return knobs.wpg;
+  const int lpb = nb / rpl;
+  return (128 / lpb) * 64 > (64 / lpb) * 128 ? 2 : 1;      // blocks per lane, two waves against one
+}
 void kkt_shape(int nb, int ne, int *wmax, int *wpe) {
   const int R = (nb + 15) / 16;
   if (ne < 0) { *wmax = 6; *wpe = 0; return; }
@@ -1919,7 +1930,7 @@ std::string kkt_source(int nb, int ne, int nc) {
   kkt_shape(nb, ne, &wmax, &wpe);
   if (wpe > 0) s += "#define KKT_WPE " + std::to_string(wpe) + "\n";
   if (wmax != 4) s += "#define KKT_WMAX " + std::to_string(wmax) + "\n";
-  if (kkt_rowwise(nb, ne)) s += "#define KKT_ROWWISE " + std::to_string(kkt_rowwise(nb, ne)) + "\n";
+  if (kkt_rowwise(nb, ne)) s += "#define KKT_ROWWISE " + std::to_string(kkt_rowwise(nb, ne)) + "\n#define KKT_ROW_WPG " + std::to_string(kkt_row_wpg(nb, ne)) + "\n";
   if (!knobs.defs.empty()) s += knobs.defs + "\n";     // (experiments, IEM_KKT_EXPERIMENTS=1 only: extra #define lines)
   s += kKktSource;
   return s;
@@ -1943,7 +1954,7 @@ int kkt_module(iem_model *m, int nb, int ne, int nc, iem_model::KktMod **out) {
     int wmax, wpe_;
     kkt_shape(nb, ne, &wmax, &wpe_);
     km.elim_wg = 64u * (unsigned)std::min((nb + 15) / 16, wmax);   // KKT_T of csrc/iem_kkt_device.h
-    if (kkt_rowwise(nb, ne)) { km.elim_wg = 64; km.elim_bpw = 64 / (nb / kkt_rowwise(nb, ne)); }
+    if (kkt_rowwise(nb, ne)) { km.elim_wg = 64u * (unsigned)kkt_row_wpg(nb, ne); km.elim_bpw = (int)km.elim_wg / (nb / kkt_rowwise(nb, ne)); }
     HIP_TRY(hipModuleGetFunction(&km.upd, km.mod, "kkt_update"));
     HIP_TRY(hipModuleGetFunction(&km.fwd, km.mod, "kkt_forward"));
     HIP_TRY(hipModuleGetFunction(&km.bwd, km.mod, "kkt_backward"));

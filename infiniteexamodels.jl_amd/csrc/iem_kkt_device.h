@@ -356,7 +356,12 @@ __device__ __forceinline__ void kkt_gj_all(kkt_d4 (&m)[KKT_TRW][KKT_R], double *
 // nearly double its rate, and bring 40 x 40 blocks (20 lanes each, three per wave) within reach of this form.
 #define KKT_RPL KKT_ROWWISE
 #define KKT_LPB (KKT_NB / KKT_RPL)
-#define KKT_BPW (64 / KKT_LPB)
+// waves per workgroup (host-chosen): 40 lanes per block leave 24 of a wave idle, three blocks share the 128 lanes of two waves
+#ifndef KKT_ROW_WPG
+#define KKT_ROW_WPG 1
+#endif
+#define KKT_ROW_T (64 * KKT_ROW_WPG)
+#define KKT_BPW (KKT_ROW_T / KKT_LPB)
 // pivot K (a template parameter: every register index is a compile-time constant whatever the unroller's thresholds say)
 template <int K>
 __device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_RPL][KKT_NB], double (*rowbuf)[KKT_BPW * KKT_NB], int bs, int li, bool mine, double tiny, int &neg, int &bad) {
@@ -418,7 +423,7 @@ __device__ __forceinline__ void kkt_row_steps(double (&m)[KKT_RPL][KKT_NB], doub
 #ifndef KKT_ROW_WAVES
 #define KKT_ROW_WAVES (512 / (2 * KKT_RPL * KKT_NB + 112) < 1 ? 1 : 512 / (2 * KKT_RPL * KKT_NB + 112) > 8 ? 8 : 512 / (2 * KKT_RPL * KKT_NB + 112))
 #endif
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KKT_ROW_WAVES, KKT_ROW_WAVES))) void kkt_eliminate(const KktArgs A) {
+extern "C" __global__ __launch_bounds__(KKT_ROW_T) __attribute__((amdgpu_waves_per_eu(KKT_ROW_WAVES, KKT_ROW_WAVES))) void kkt_eliminate(const KktArgs A) {
   __shared__ double rowbuf[2][KKT_BPW * KKT_NB];
   __shared__ int cnt[2];
   const int lane = (int)threadIdx.x, slot = lane / KKT_LPB, li = lane - slot * KKT_LPB;
