@@ -1889,7 +1889,8 @@ int kkt_rowwise(int nb, int ne) {
   if (ne != 0 || nb > 48) return 0;
   if (knobs.rowwise >= 0) return knobs.rowwise;
   // two rows per lane up to 24 x 24 (hovercraft 20 x 20 at 1e5 supports: 0.74 ms against 0.84 with one row and 1.66 in the panel form); one
-  // row up to 40 (40 x 40: 2.24 ms against 2.40 in the panel form; two rows of 40 leave one wave per SIMD: 2.9 ms; 44 x 44 spills: 7.3 ms);
+  // row up to 40 (40 x 40: 1.96 ms against 2.40 in the panel form, three blocks per two-wave workgroup — kkt_row_wpg; two rows of 40 leave one
+  // wave per SIMD: 2.9 ms; 44 x 44 spills: 7.3 ms);
   // beyond that the panel form.  profiles/r04_kkt_rpl_ab.txt
   return nb <= 24 ? 2 : nb <= 40 ? 1 : 0;
 }
