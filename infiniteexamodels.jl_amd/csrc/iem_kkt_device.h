@@ -541,6 +541,22 @@ extern "C" __global__ __launch_bounds__(KKT_TU) void kkt_update(const KktArgs A)
   for (int e = t; e < KKT_NC; e += KKT_TU) { rr[e] = A.rows[e]; cc[e] = A.cols[e]; }
   __syncthreads();
   double *Dj = A.D + j * KKT_NB * KKT_NB;
+  // the right neighbour's operands are fetched NOW, behind the left half's loads: the two halves are a chain of barriers, and each
+  // would otherwise wait for its own HBM round trip (the kernel moves ~14 KB of 128-byte lines per block and ran at half that rate)
+  constexpr int NPRE = (KKT_NC * KKT_NC + KKT_TU - 1) / KKT_TU;
+  double preB[NPRE], preG[NPRE];
+  if (hq) {
+    const double *Dq = A.D + q * KKT_NB * KKT_NB;
+#pragma unroll
+    for (int n = 0; n < NPRE; ++n) {
+      const int e = t + n * KKT_TU;
+      if (e < KKT_NC * KKT_NC) {
+        const int a = e / KKT_NC, b = e - a * KKT_NC;
+        preB[n] = A.Bt[q * KKT_NC * KKT_NC + e];
+        preG[n] = (rr[a] >= 0 && rr[b] >= 0) ? Dq[rr[a] * KKT_NB + rr[b]] : 0.0;
+      } else { preB[n] = 0.0; preG[n] = 0.0; }
+    }
+  }
   if (hp) {
     const double *Dp = A.D + p * KKT_NB * KKT_NB;
     for (int e = t; e < NN; e += KKT_TU) {
@@ -579,11 +595,10 @@ extern "C" __global__ __launch_bounds__(KKT_TU) void kkt_update(const KktArgs A)
     __syncthreads();       // (R and C may share an entry of D_j: the two halves touch it one after the other)
   }
   if (hq) {
-    const double *Dq = A.D + q * KKT_NB * KKT_NB;
-    for (int e = t; e < NN; e += KKT_TU) {
-      const int a = e / KKT_NC, b = e - a * KKT_NC;
-      Bo[a * KKT_LN + b] = A.Bt[q * NN + e];
-      G1[a * KKT_LN + b] = (rr[a] >= 0 && rr[b] >= 0) ? Dq[rr[a] * KKT_NB + rr[b]] : 0.0;
+#pragma unroll
+    for (int n = 0; n < NPRE; ++n) {
+      const int e = t + n * KKT_TU;
+      if (e < NN) { const int a = e / KKT_NC, b = e - a * KKT_NC; Bo[a * KKT_LN + b] = preB[n]; G1[a * KKT_LN + b] = preG[n]; }
     }
     __syncthreads();
     for (int e = t; e < NN; e += KKT_TU) {
