@@ -848,6 +848,7 @@ static int apply_option(iem::Options &o, int &poll_obj, const char *name, int64_
   if (std::strcmp(name, "jac_split_min") == 0) { if (value < 0) return fail(IEM_E_ARG, "jac_split_min must be >= 0"); o.jac_split_min = value; return IEM_OK; }
   if (std::strcmp(name, "pair_inter") == 0) { o.pair_inter = value != 0; return IEM_OK; }
   if (std::strcmp(name, "split_shift") == 0) { o.split_shift = value != 0; return IEM_OK; }
+  if (std::strcmp(name, "cons_direct_2d") == 0) { o.cons_direct_2d = value != 0; return IEM_OK; }
   if (std::strcmp(name, "comm_timeout_ms") == 0) {
     if (value < 1 || value > 600000) return fail(IEM_E_ARG, "comm_timeout_ms must be in 1..600000");
     o.comm_timeout_ms = (int)value;

@@ -2288,6 +2288,21 @@ static void launch_grid(const Group &g, int64_t qs, KernelDesc &kd) {
 // — and one decision per kind: the kernels (bodies) of a kind share launches, hence a workgroup size.
 static Options kind_options(const Options &opt, const std::vector<Group> &groups, int kind) {
   Options ko = opt;
+  // cons! on a 2-D support grid: one value per row and template, lane-consecutive — the plain stores are coalesced as they are, and on
+  // the short rows of such a grid (256-lane tiles, 16 of them recomputed per seam) the LDS re-cut costs more than the whole lines it
+  // buys: pandemic 5 000 x 100: 15.7 -> 12.3 us (on a 1-D grid of 512-lane tiles the re-cut wins, quadrotor: 55.7 against 60.2;
+  // profiles/r04_kind_ab_cons_store_modes.txt).  Decided by the LARGEST grid of the kind — its shape, not its size.
+  if ((kind == KK_CONS || kind == KK_JPROD) && opt.store_mode == 2 && opt.cons_direct_2d && !opt.no_fuse) {      // (J v has cons!'s output shape)
+    const Group *big = nullptr;
+    int64_t pts = 0;
+    for (const Group &g : groups) {
+      if (g.grid_id <= 0) continue;
+      const int64_t n = g.ext[0] * g.ext[1] * g.ext[2];
+      if (n > pts) { pts = n; big = &g; }
+    }
+    if (big && big->nd >= 2 && !big->flat) ko.store_mode = 1;
+    return ko;
+  }
   if ((kind != KK_JAC && kind != KK_HESS) || opt.store_mode != 2 || opt.no_fuse || opt.big_batch_slots <= opt.lds_slots) return ko;
   const int64_t thr = kind == KK_JAC ? opt.big_batch_jac : opt.big_batch_hess;
   if (thr <= 0) return ko;

@@ -123,6 +123,7 @@ struct Options {
   // 1: bodies alternate workgroup by workgroup; 2: in runs of 8 workgroups (one per XCD), so every XCD sees both; 0: off
   int jac_split = 1;
   int64_t jac_split_min = 0;    // ... only grids of more workgroups than this (0: every lane-fused grid — the source stays size-independent)
+  int cons_direct_2d = 1;  // cons! of a model whose largest grid is 2-D: plain coalesced stores instead of the LDS re-cut (kind_options)
   int split_shift = 0;     // jac_split's bodies: 1 = the FIRST body of an interleaved run (the data rows) takes its tiles half a grid away from the
                            // others' — its store fronts then sit in another part of the output while the computed rows' fronts pass
   int pair_inter = 0;      // the fused pair: 1 = bodies of equal grids (jac_coord!'s halves, hess_coord!) interleaved the same way; 0 (default,

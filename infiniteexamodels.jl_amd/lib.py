@@ -204,7 +204,7 @@ def set_option(name: str, value: int):
 OPTION_DEFAULTS = dict(store_mode=2, nt_stores=1, block=0, lds_slots=24, reorder=1, no_fuse=0, hess_merge=0, ablate=0,
                        min_waves=0, fp_contract=0, fuse_zero=1, fuse_groups=1, split_small=64, poll_obj=1, xcd_remap=0, overlap=1, wide_stores=1, obj_wgs=1024, det_shared=1, obj_unroll=1, flat2d=0, flush32=2, autotune=0, autotune_min_blocks=400, pull_scatter=1, fold_colloc=2, fold_max_n=6, det_axis=1, det_scatter=1, det_scatter_max=1 << 28, lazy_loads=2, lazy_min_loads=48, lazy_all_kinds=0, name_tag=0,
                        big_batch_slots=48, big_batch_jac=4000, big_batch_hess=4000, big_xcd=1, big_tile=1024, pair_kernel=1, store_wait=0, comm_timeout_ms=5000,
-                       carrier=0, phase_kernels=1, jac_split=1, jac_split_min=0, pair_inter=0, split_shift=0)
+                       carrier=0, phase_kernels=1, jac_split=1, jac_split_min=0, pair_inter=0, split_shift=0, cons_direct_2d=1)
 
 
 def option_array(opts: dict):
